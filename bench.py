@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the duplex codec-LM hot path on MI355X.
+
+Contract (driver): python bench.py --gpus N --steps K --warmup W  -> ONE JSON line on rank 0.
+
+Workload at N=1 = BASELINE.json configs[1]: batch MagiCodec-style encode of synthetic 16 kHz
+stereo, 0.1 s chunks with 2.0 s left context, 256 windows per pass (encode_audio_gpu_1.sh:2-8).
+One STEP = one pass = 256 windows (128 chunk positions x 2 channels = 12.8 s of new stereo audio);
+the default K=282 steps is ~1 h of stereo.  Inputs are resident in HBM before the timed region.
+`value` = hours of (stereo) audio encoded per wall-clock hour, summed over all ranks (the path
+shards by chunk range with no collective: weak scaling, "replicas only" for RCCL).
+
+The same line carries the duplex-stream leg (BASELINE configs[2]/[3]: ~1B random-init
+codec-LM, 80 ms frames) as `duplex`: xRT and p50 frame-step latency, plus `roofline` for the
+dominant kernel of the headline workload and `cpu_baseline` (the CPU oracle timed on the host
+cores on a bounded sample, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (matrix), dense
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def synth_audio(n: int, seed: int, device) -> torch.Tensor:
+    """SURVEY.md 8d generator (3 sines @ 0.1 + N(0, 0.01), clipped), built on the device."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    t = torch.arange(n, device=device, dtype=torch.float64) / 16000.0
+    x = torch.zeros(n, device=device, dtype=torch.float64)
+    for f in (220.0, 440.0, 1330.0):
+        x += 0.1 * torch.sin(2 * np.pi * f * t)
+    x = x.float() + 0.01 * torch.randn(n, device=device, generator=g)
+    return x.clamp_(-1.0, 1.0)
+
+
+def cpu_baseline_encode(cfg, weights, chunk, ctx, n_chunks, channels):
+    """The CPU oracle (kind 'port': the reference's codec arithmetic is a third-party package that
+    is absent offline) on a bounded sample of the same workload, all host cores."""
+    from oracle.codec import OracleCodec
+    oc = OracleCodec(cfg, weights)
+    rng = np.random.default_rng(0)
+    n = ctx + n_chunks * chunk
+    audio = np.clip(rng.normal(0, 0.1, (channels, n)), -1, 1).astype(np.float32)
+    W = max(chunk, ctx)
+    wins = np.stack([audio[c, (i + 1) * chunk + ctx - W:(i + 1) * chunk + ctx] for i in range(n_chunks) for c in range(channels)])
+    oc.encode(wins[:2])  # warm
+    t0 = time.perf_counter()
+    oc.encode(wins)
+    dt = time.perf_counter() - t0
+    return dict(value=(n_chunks * chunk / 16000.0) / dt, unit="audio-hours/hour", cores=os.cpu_count(), kind="port",
+                sample=f"{len(wins)} windows of {W} samples ({n_chunks} chunk positions x {channels} ch) in {dt:.2f} s, OpenMP x{os.cpu_count()}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=282)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-windows", type=int, default=256)
+    ap.add_argument("--chunk-secs", type=float, default=0.1)
+    ap.add_argument("--context-secs", type=float, default=2.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-duplex", action="store_true")
+    ap.add_argument("--duplex-secs", type=float, default=20.0)
+    ap.add_argument("--variant", type=int, default=1)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from realtime_codec_agent_amd import _native
+    if _native.needs_build() and rank == 0:
+        _native.build()
+    if dist is not None:
+        dist.barrier()
+    from realtime_codec_agent_amd.codec import HipCodec
+    from realtime_codec_agent_amd.codec_model import CodecConfig, init_codec_weights
+
+    cfg = CodecConfig()
+    weights = init_codec_weights(cfg, seed=0)
+    hip = HipCodec(cfg, weights, device=local_rank)
+    hip.set_variant(args.variant)
+
+    C = 2
+    chunk = int(args.chunk_secs * cfg.sample_rate)
+    ctx = int(args.context_secs * cfg.sample_rate)
+    chunks_per_step = args.batch_windows // C
+    fpc = hip.frames_per_chunk(chunk)
+    first = (ctx + chunk - 1) // chunk  # first chunk whose window is full (no warm-up passes in the timed region)
+    total_steps = args.warmup + args.steps
+    n_chunks = first + total_steps * chunks_per_step
+    N = n_chunks * chunk
+    audio = torch.stack([synth_audio(N, 1000 * rank + 1 + c, dev) for c in range(C)]).contiguous()
+    codes = torch.empty((C, chunks_per_step * fpc * total_steps), dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step(i):
+        c0 = first + i * chunks_per_step
+        hip.encode_chunk_range_dev(audio.data_ptr(), C, N, chunk, ctx, args.batch_windows, c0, c0 + chunks_per_step,
+                                   codes.data_ptr() + 8 * i * chunks_per_step * fpc, codes.shape[1], stream)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    hip.profile(True)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total_steps):
+        step(i)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    hip.profile(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    prof = {k: hip.profile_read(k) for k in (0, 1, 2, 3)}
+    audio_secs = args.steps * chunks_per_step * chunk / cfg.sample_rate  # per rank, stereo seconds
+    value = world * audio_secs / elapsed
+    conv = prof[0]
+    achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+    # sanity: emitted ids are in range and not constant
+    sample = codes[:, : 64 * fpc].cpu().numpy()
+    assert sample.min() >= 0 and sample.max() < cfg.codebook_size
+
+    out = {
+        "metric": "batch-encode audio-hours/hour (+ xRT and p50 frame-step latency of 1 duplex stream in `duplex`)",
+        "value": value,
+        "unit": "audio-hours/hour",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "batch MagiCodec-style encode, 16 kHz stereo, 0.1 s chunks / 2.0 s context, 256 windows per step (BASELINE configs[1])",
+            "windows_per_step": args.batch_windows,
+            "audio_hours_timed_per_gpu": audio_secs / 3600.0,
+            "channel_hours_per_hour": value * C,
+            "codebook": f"{cfg.codebook_size}x{cfg.codebook_dim}",
+            "encoder_gflop_per_window": cfg.encoder_flops_per_sample() * ctx / 1e9,
+            "sharding": "chunk ranges per rank, no collective (replicas only)",
+        },
+        "roofline": {
+            "kernel": "conv1d_mfma_kernel (implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
+            "bound": "mfma",
+            "achieved": achieved,
+            "peak": F32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+            "traffic": None,
+            "avg_launch_ms": conv["ms"] / max(1, conv["launches"]),
+            "launches": conv["launches"],
+            "flop_per_launch": conv["flops"] / max(1, conv["launches"]),
+            "share_of_step_time": conv["ms"] * 1e-3 / elapsed if elapsed > 0 else None,
+            "other_kernels_ms": {"vq_search": prof[1]["ms"], "conv_in": prof[2]["ms"], "other": prof[3]["ms"]},
+            "conv_in_hbm_gbs": prof[2]["bytes"] / (prof[2]["ms"] * 1e-3) / 1e9 if prof[2]["ms"] > 0 else None,
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_encode(cfg, weights, chunk, ctx, 64, C)
+    if world == 1 and not args.no_duplex:
+        try:
+            from realtime_codec_agent_amd.duplex_bench import run_duplex_bench
+        except ImportError:
+            run_duplex_bench = None
+        if run_duplex_bench is not None:
+            out["duplex"] = run_duplex_bench(dev, secs=args.duplex_secs)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,239 @@
+/*
+ * rca.h -- C ABI of the MI355X-native duplex codec-LM hot path.
+ *
+ * The reference (AbrahamSanders/realtime-codec-agent) has no FFI of its own: its
+ * seams are two duck-typed Python objects held by RealtimeAgentResources
+ * (realtime_agent_resources.py:19-39).  This header is the C boundary that sits
+ * *behind* Python classes with those surfaces.  Each entry
+ * point cites the reference call it replaces.
+ *
+ * Conventions
+ *   - every function returns int: 0 = RCA_OK, <0 = error (rca_last_error() has text);
+ *     no exception crosses the boundary
+ *   - plain pointers and sizes only; no torch / C++ types
+ *   - the caller owns every I/O buffer; the library owns weights, KV cache, workspace
+ *   - one handle per stream, handles are not re-entrant (matches the reference:
+ *     AudioTokenizer and llama_cpp.Llama are single-threaded objects)
+ *   - "_dev" variants take device (HBM) pointers and a hipStream_t passed as void*;
+ *     the plain variants take host pointers and do the H2D/D2H copies themselves
+ */
+#ifndef RCA_H
+#define RCA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RCA_OK 0
+#define RCA_ERR_ARG -1      /* bad argument / shape */
+#define RCA_ERR_HIP -2      /* a HIP runtime call failed */
+#define RCA_ERR_STATE -3    /* wrong call order / context overflow */
+#define RCA_ERR_MISSING -4  /* a named tensor was not supplied */
+
+#define RCA_MAX_STAGES 8
+
+typedef struct rca_codec rca_codec_t;
+typedef struct rca_lm rca_lm_t;
+
+/* dtype tags for rca_tensor_t */
+#define RCA_F32 0
+#define RCA_BF16 1
+
+/* A named host tensor handed to a create() call (weights). */
+typedef struct {
+    const char* name;
+    const void* data;  /* host pointer */
+    int64_t numel;
+    int32_t dtype;     /* RCA_F32 or RCA_BF16 */
+} rca_tensor_t;
+
+const char* rca_last_error(void);
+int rca_device_count(int* n);
+const char* rca_version(void);
+
+/* ------------------------------------------------------------------ codec --
+ * MagiCodec-style model object.  Architecture is described by
+ * rca_codec_config_t; tensors are named as in oracle/codec_ref.py:
+ *   enc.conv_in.{weight,bias}            [C0,1,k_in]
+ *   enc.down.{i}.{weight,bias}           [C(i+1),C(i),2*s_i]
+ *   enc.conv_out.{weight,bias}           [D,C_last,k_latent]
+ *   quantizer.in_proj.{weight,bias}      [cd,D]
+ *   quantizer.codebook.weight            [N,raw]
+ *   quantizer.codebook_proj.{weight,bias}[cd,raw]
+ *   dec.conv_in.{weight,bias}            [C_last,cd,k_latent]
+ *   dec.up.{i}.{weight,bias}             [C(n-i),C(n-i-1),2*s]  (ConvTranspose1d layout [Cin,Cout,k])
+ *   dec.conv_out.{weight,bias}           [1,C0,k_in]
+ */
+typedef struct {
+    int32_t sample_rate;                  /* 16000 */
+    int32_t n_stages;                     /* 4 */
+    int32_t strides[RCA_MAX_STAGES];      /* 2,4,5,8 -> hop 320 (50 Hz) */
+    int32_t channels[RCA_MAX_STAGES + 1]; /* 32,64,128,256,512 */
+    int32_t k_in;                         /* 7 */
+    int32_t k_latent;                     /* 3 */
+    int32_t latent_dim;                   /* 256 */
+    int32_t codebook_size;                /* 131072 */
+    int32_t codebook_raw_dim;             /* 32 */
+    int32_t codebook_dim;                 /* 16 */
+    float leaky_slope;                    /* 0.1 */
+} rca_codec_config_t;
+
+/* replaces codec_bpe.tools.codec_utils.load_magicodec_model + .eval().to(device)
+ * (audio_tokenizer.py:26-28).  The projected codebook and its half-norms are
+ * computed once here instead of on every decode (audio_tokenizer.py:198). */
+int rca_codec_create(const rca_codec_config_t* cfg, const rca_tensor_t* tensors, int32_t n_tensors,
+                     int32_t device, rca_codec_t** out);
+int rca_codec_destroy(rca_codec_t* h);
+/* total stride of the encoder (samples per frame) */
+int rca_codec_hop(const rca_codec_t* h, int32_t* hop);
+/* frames produced for T samples: ceil(T / hop) (pad_audio right-pads to a hop multiple) */
+int rca_codec_num_frames(const rca_codec_t* h, int32_t T, int32_t* F);
+
+/* AudioTokenizer._magicodec_encode (audio_tokenizer.py:189-194):
+ * pad_audio -> encoder -> quantizer.inference.  pcm [B,T] f32 -> codes [B,F] int64. */
+int rca_codec_encode(rca_codec_t* h, const float* pcm_host, int32_t B, int32_t T, int64_t* codes_host);
+int rca_codec_encode_dev(rca_codec_t* h, const float* pcm_dev, int32_t B, int32_t T, int64_t* codes_dev,
+                         void* stream);
+
+/* codec_bpe.audio_to_codes as driven by encode_audio_gpu_*.sh (--chunk_size_secs,
+ * --context_secs, --batch_size): every `hop_samples` chunk of a long signal is
+ * encoded with `ctx_samples` of left context and only the chunk's own codes are
+ * kept (same rule as AudioTokenizer.tokenize_audio, audio_tokenizer.py:72-101).
+ * audio [C,N] f32 resident in HBM -> codes [C, n_chunks*frames_per_chunk] int64.
+ * Windows are cut on the device; `batch_windows` windows are encoded per pass. */
+int rca_codec_encode_windows_dev(rca_codec_t* h, const float* audio_dev, int32_t C, int64_t N,
+                                 int32_t chunk_samples, int32_t ctx_samples, int32_t batch_windows,
+                                 int64_t* codes_dev, int64_t codes_per_channel, void* stream);
+
+/* Same, restricted to chunks [chunk_begin, chunk_end) of the signal (left context is read from
+ * the signal itself): the unit of work a batch shard / one bench step encodes.  Codes of chunk i
+ * land at codes_dev[c * codes_per_channel + (i - chunk_begin) * frames_per_chunk ...]. */
+int rca_codec_encode_chunk_range_dev(rca_codec_t* h, const float* audio_dev, int32_t C, int64_t N,
+                                     int32_t chunk_samples, int32_t ctx_samples, int32_t batch_windows,
+                                     int64_t chunk_begin, int64_t chunk_end, int64_t* codes_dev,
+                                     int64_t codes_per_channel, void* stream);
+
+/* AudioTokenizer._magicodec_decode (audio_tokenizer.py:196-201):
+ * embedding(codes, codebook_proj(codebook.weight)) -> decoder -> f32 PCM.
+ * codes [B,F] int64 -> pcm [B,F*hop] f32. */
+int rca_codec_decode(rca_codec_t* h, const int64_t* codes_host, int32_t B, int32_t F, float* pcm_host);
+int rca_codec_decode_dev(rca_codec_t* h, const int64_t* codes_dev, int32_t B, int32_t F, float* pcm_dev,
+                         void* stream);
+
+/* The three sub-steps of the model object, for callers that drive them separately the way
+ * the reference does (audio_tokenizer.py:190-192,198-200):
+ *   codec_model.encoder(pad_audio(x))      pcm [B,T] -> z_e [B,F,D] f32
+ *   codec_model.quantizer.inference(z_e)   z_e [R,D] -> idx [R] int64 (R = B*F rows)
+ *   codec_model.decoder(z_q)               z_q [B,F,cd] -> pcm [B,F*hop] f32 */
+int rca_codec_encoder_dev(rca_codec_t* h, const float* pcm_dev, int32_t B, int32_t T, float* ze_dev, void* stream);
+int rca_codec_quantize_dev(rca_codec_t* h, const float* ze_dev, int64_t rows, int64_t* codes_dev, void* stream);
+int rca_codec_decoder_dev(rca_codec_t* h, const float* zq_dev, int32_t B, int32_t F, float* pcm_dev, void* stream);
+/* device pointer of the projected codebook [codebook_size, codebook_dim] f32 (owned by the handle) */
+int rca_codec_codebook_dev(rca_codec_t* h, const float** out_dev);
+
+/* AudioTokenizer.get_codec_embeddings (audio_tokenizer.py:151-159): projected
+ * codebook [codebook_size, codebook_dim] f32, copied to the host. */
+int rca_codec_codebook(rca_codec_t* h, float* out_host);
+
+/* Debug/parity taps (tests only): run the encoder and copy the activation after
+ * layer `layer` (0=conv_in, 1..n=down, n+1=conv_out, n+2=in_proj z) to the host. */
+int rca_codec_encode_tap(rca_codec_t* h, const float* pcm_host, int32_t B, int32_t T, int32_t layer,
+                         float* out_host, int64_t out_numel);
+
+/* Kernel-variant switch (parity tests compare variants): 0 = scalar-chain kernels,
+ * 1 = MFMA/LDS kernels (default when available). */
+int rca_codec_set_variant(rca_codec_t* h, int32_t variant);
+
+/* Per-kernel HIP-event timing for bench.py's roofline object: when enabled, every launch of a
+ * profiled kernel class is bracketed by hipEventRecord on the stream it is launched on.
+ * classes: 0 = implicit-GEMM conv (MFMA), 1 = codebook search, 2 = conv_in, 3 = everything else.
+ * _read synchronises, returns the summed device time, the launch count and the summed ALGORITHMIC
+ * FLOPs (2 per multiply-add over the real, unpadded K) and bytes since the last _read. */
+int rca_codec_profile(rca_codec_t* h, int32_t enable);
+int rca_codec_profile_read(rca_codec_t* h, int32_t kclass, double* total_ms, int64_t* launches, double* flops,
+                           double* bytes);
+
+/* --------------------------------------------------------------------- LM --
+ * Llama-architecture decoder with a llama_cpp.Llama-like control surface
+ * (SURVEY.md 8b-3): the deployed model is codec_llama.py after
+ * persist_codec_embeddings (codec_llama.py:178-206), i.e. a vanilla Llama with
+ * an untied lm_head.  Tensor names follow the HF state dict:
+ *   model.embed_tokens.weight [V,H]; model.layers.{i}.self_attn.{q,k,v,o}_proj.weight;
+ *   model.layers.{i}.mlp.{gate,up,down}_proj.weight; model.layers.{i}.input_layernorm.weight;
+ *   model.layers.{i}.post_attention_layernorm.weight; model.norm.weight; lm_head.weight [V,H]
+ */
+typedef struct {
+    int32_t vocab_size;
+    int32_t hidden;
+    int32_t n_layers;
+    int32_t n_heads;
+    int32_t n_kv_heads;
+    int32_t head_dim;
+    int32_t ffn;
+    int32_t n_ctx;            /* KV slots allocated (llm_n_ctx, realtime_agent_resources.py:13) */
+    float rms_eps;
+    float rope_theta;
+    int32_t rope_scaling;     /* 0 = none, 1 = llama3 */
+    float rope_factor;        /* 32 */
+    float rope_low_freq_factor;   /* 1 */
+    float rope_high_freq_factor;  /* 4 */
+    int32_t rope_orig_ctx;    /* 8192 */
+    int32_t logits_all;       /* keep logits of every evaluated position (aux_llm) */
+} rca_lm_config_t;
+
+typedef struct {
+    int32_t top_k;   /* <=0: whole vocabulary */
+    float top_p;     /* 1.0 = off */
+    float min_p;     /* 0.0 = off */
+    float temp;      /* <=0: greedy */
+    uint32_t seed;
+    int32_t n_bias;          /* logit bias entries (llamacpp_utils.py:8-24) */
+    const int32_t* bias_ids;
+    const float* bias_vals;
+} rca_sampler_params_t;
+
+/* llama_cpp.Llama(model_path=..., n_ctx=..., n_gpu_layers=-1) (realtime_agent_resources.py:19-33) */
+int rca_lm_create(const rca_lm_config_t* cfg, const rca_tensor_t* tensors, int32_t n_tensors,
+                  int32_t device, rca_lm_t** out);
+/* random-init weights generated on the device from a counter hash (bench configs 3/4:
+ * there are no checkpoints offline).  oracle/lm_ref.py regenerates the same values. */
+int rca_lm_create_random(const rca_lm_config_t* cfg, uint64_t seed, float init_std, int32_t device,
+                         rca_lm_t** out);
+int rca_lm_destroy(rca_lm_t* h);
+
+/* Llama.reset(): n_tokens = 0 (realtime_agent_v2.py:68) */
+int rca_lm_reset(rca_lm_t* h);
+/* Llama.eval(tokens): append n ids at position n_tokens, run the forward, keep the
+ * last position's logits (every position's when logits_all) (llamacpp_utils.py:150) */
+int rca_lm_eval(rca_lm_t* h, const int32_t* ids, int32_t n);
+/* read / write Llama.n_tokens: the agent rolls the KV cache back by writing it
+ * (realtime_agent_v2.py:208,219,261,465,730); stale slots are overwritten by the next eval */
+int rca_lm_get_n_tokens(const rca_lm_t* h, int32_t* n);
+int rca_lm_set_n_tokens(rca_lm_t* h, int32_t n);
+/* llm._ctx.get_logits(): V floats of the last evaluated position (realtime_agent_v2.py:449,461) */
+int rca_lm_get_logits(rca_lm_t* h, float* out_host);
+/* llm._scores[row] for logits_all handles: row counts back from the last eval'd position */
+int rca_lm_get_logits_row(rca_lm_t* h, int32_t pos, float* out_host);
+/* device pointer of the last logits (V floats); valid until the next eval */
+int rca_lm_logits_dev(rca_lm_t* h, const float** out_dev);
+
+/* init_sampler_for_generate (llamacpp_utils.py:39-77) */
+int rca_lm_sampler_init(rca_lm_t* h, const rca_sampler_params_t* p);
+/* sample() (llamacpp_utils.py:79-95): draw from the last logits */
+int rca_lm_sample(rca_lm_t* h, int32_t* token);
+/* next(generate(tokens, reset=False)) (llamacpp_utils.py:145-161; realtime_agent_v2.py:355):
+ * eval + sample with no host round trip in between; hipGraph-replayed for n<=2 */
+int rca_lm_step(rca_lm_t* h, const int32_t* ids, int32_t n, int32_t* token);
+/* softmax(logits)[token] of the last position, reduced on the device
+ * (measure_event_prob, realtime_agent_v2.py:448-452) */
+int rca_lm_token_probs(rca_lm_t* h, const int32_t* token_ids, int32_t n, float* probs_out);
+/* synchronise the handle's stream (timing) */
+int rca_lm_sync(rca_lm_t* h);
+int rca_codec_sync(rca_codec_t* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCA_H */

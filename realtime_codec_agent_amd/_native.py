@@ -1,0 +1,183 @@
+"""ctypes binding of the C ABI in include/rca.h (librca_hip.so, built in-tree by hipcc).
+
+There is NO CPU fallback: if the library is missing or cannot be loaded, `lib()` raises
+RuntimeError and every product entry point that needs it fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import numpy as np
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC_DIR = os.path.join(_PKG_DIR, "csrc")
+LIB_PATH = os.path.join(_PKG_DIR, "librca_hip.so")
+HIP_SOURCES = ["rca_codec.hip", "rca_lm.hip"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
+               "-Wno-unused-result"]
+
+MAX_STAGES = 8
+RCA_F32, RCA_BF16 = 0, 1
+
+
+class RcaError(RuntimeError):
+    pass
+
+
+class Tensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64), ("dtype", C.c_int32)]
+
+
+class CodecConfigC(C.Structure):
+    _fields_ = [
+        ("sample_rate", C.c_int32),
+        ("n_stages", C.c_int32),
+        ("strides", C.c_int32 * MAX_STAGES),
+        ("channels", C.c_int32 * (MAX_STAGES + 1)),
+        ("k_in", C.c_int32),
+        ("k_latent", C.c_int32),
+        ("latent_dim", C.c_int32),
+        ("codebook_size", C.c_int32),
+        ("codebook_raw_dim", C.c_int32),
+        ("codebook_dim", C.c_int32),
+        ("leaky_slope", C.c_float),
+    ]
+
+
+class LMConfigC(C.Structure):
+    _fields_ = [
+        ("vocab_size", C.c_int32),
+        ("hidden", C.c_int32),
+        ("n_layers", C.c_int32),
+        ("n_heads", C.c_int32),
+        ("n_kv_heads", C.c_int32),
+        ("head_dim", C.c_int32),
+        ("ffn", C.c_int32),
+        ("n_ctx", C.c_int32),
+        ("rms_eps", C.c_float),
+        ("rope_theta", C.c_float),
+        ("rope_scaling", C.c_int32),
+        ("rope_factor", C.c_float),
+        ("rope_low_freq_factor", C.c_float),
+        ("rope_high_freq_factor", C.c_float),
+        ("rope_orig_ctx", C.c_int32),
+        ("logits_all", C.c_int32),
+    ]
+
+
+class SamplerParamsC(C.Structure):
+    _fields_ = [
+        ("top_k", C.c_int32),
+        ("top_p", C.c_float),
+        ("min_p", C.c_float),
+        ("temp", C.c_float),
+        ("seed", C.c_uint32),
+        ("n_bias", C.c_int32),
+        ("bias_ids", C.POINTER(C.c_int32)),
+        ("bias_vals", C.POINTER(C.c_float)),
+    ]
+
+
+def sources() -> List[str]:
+    return [os.path.join(CSRC_DIR, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC_DIR, s))]
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    deps = sources() + [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith(".h")]
+    deps.append(os.path.join(os.path.dirname(_PKG_DIR), "include", "rca.h"))
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc cross-compiles every HIP source for gfx950 into ONE in-tree shared library."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    cmd = [hipcc] + HIPCC_FLAGS + sources() + ["-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+_lib = None
+
+# every symbol include/rca.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "rca_last_error", "rca_device_count", "rca_version",
+    "rca_codec_create", "rca_codec_destroy", "rca_codec_hop", "rca_codec_num_frames",
+    "rca_codec_encode", "rca_codec_encode_dev", "rca_codec_encode_windows_dev", "rca_codec_encode_chunk_range_dev",
+    "rca_codec_decode", "rca_codec_decode_dev",
+    "rca_codec_encoder_dev", "rca_codec_quantize_dev", "rca_codec_decoder_dev", "rca_codec_codebook_dev",
+    "rca_codec_codebook", "rca_codec_encode_tap", "rca_codec_set_variant", "rca_codec_sync",
+    "rca_codec_profile", "rca_codec_profile_read",
+    "rca_lm_create", "rca_lm_create_random", "rca_lm_destroy", "rca_lm_reset", "rca_lm_eval",
+    "rca_lm_get_n_tokens", "rca_lm_set_n_tokens", "rca_lm_get_logits", "rca_lm_get_logits_row",
+    "rca_lm_logits_dev", "rca_lm_sampler_init", "rca_lm_sample", "rca_lm_step", "rca_lm_token_probs",
+    "rca_lm_sync",
+]
+
+
+def lib():
+    """Load librca_hip.so; raise (never fall back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RcaError(
+            f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "There is no CPU fallback for the product path."
+        )
+    try:
+        _lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise RcaError(f"cannot load {LIB_PATH}: {e}") from e
+    _lib.rca_last_error.restype = C.c_char_p
+    _lib.rca_version.restype = C.c_char_p
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().rca_last_error()
+        raise RcaError(f"{what} failed (rc={rc}): {msg.decode(errors='replace') if msg else ''}")
+
+
+def make_tensors(weights: Dict[str, np.ndarray]) -> Tuple[C.Array, list]:
+    """dict name -> ndarray (float32, or uint16 holding bf16 bits) -> rca_tensor_t[]; returns keep-alive list."""
+    keep = []
+    arr = (Tensor * len(weights))()
+    for i, (name, a) in enumerate(weights.items()):
+        if a.dtype == np.uint16:
+            dt = RCA_BF16
+        else:
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            dt = RCA_F32
+        a = np.ascontiguousarray(a)
+        nb = name.encode()
+        keep += [a, nb]
+        arr[i] = Tensor(nb, a.ctypes.data, a.size, dt)
+    return arr, keep
+
+
+def codec_config_c(cfg) -> CodecConfigC:
+    c = CodecConfigC()
+    c.sample_rate = cfg.sample_rate
+    c.n_stages = len(cfg.strides)
+    for i, s in enumerate(cfg.strides):
+        c.strides[i] = s
+    for i, ch in enumerate(cfg.channels):
+        c.channels[i] = ch
+    c.k_in, c.k_latent, c.latent_dim = cfg.k_in, cfg.k_latent, cfg.latent_dim
+    c.codebook_size, c.codebook_raw_dim, c.codebook_dim = cfg.codebook_size, cfg.codebook_raw_dim, cfg.codebook_dim
+    c.leaky_slope = cfg.leaky_slope
+    return c

@@ -1,0 +1,1111 @@
+// rca_codec.hip -- MagiCodec-style codec on gfx950 (MI355X): strided conv1d encoder,
+// 131072x16 codebook nearest-neighbour search, transposed-conv decoder.
+//
+// Replaces the third-party arithmetic behind AudioTokenizer._magicodec_encode/_decode
+// (reference audio_tokenizer.py:189-201).  All arithmetic is f32 with every
+// multiply-accumulate an fma in a fixed k order (ci-major, tap-minor), so results are
+// bit-identical to oracle/codec_oracle.c:
+//   * variant 0 ("chain")  : one thread per output element, scalar v_fma_f32 chain
+//   * variant 1 ("mfma")   : implicit-GEMM conv on v_mfma_f32_32x32x2_f32 with an
+//                            LDS-staged im2col sliding window, and an MFMA scoring
+//                            kernel for the codebook search.  gfx950's f32 MFMA is a
+//                            k-ordered fma chain (one rounding per product), so the
+//                            same bits come out.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no implicit contraction).
+#include <stdarg.h>
+
+#include <algorithm>
+#include <cmath>
+
+#include "rca_common.h"
+
+namespace rca {
+thread_local char g_err[512] = {0};
+}
+using namespace rca;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// Source addressing for the first layer: row r of the batch reads
+//   src + (r % C) * chan_stride + (r / C) * win_stride,  T valid samples (zero beyond).
+// Plain encode: C = B, chan_stride = T, win_stride = 0.  Window mode (batch encode): rows are
+// (window, channel) pairs cut out of a long [C][N] signal on the fly -- no window copy in HBM.
+struct RowSrc {
+    const float* base;
+    int C;
+    long chan_stride;
+    long win_stride;
+    int T;
+};
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v >= 0.0f ? v : v * slope; }
+
+// ---------------------------------------------------------------------------- conv_in (Cin = 1)
+// HBM-bound (448 FLOP per 128 B written): one thread per (row, t) computes every output channel
+// from a k-tap register window; stores are coalesced along t for each channel.
+template <int KS>
+__global__ __launch_bounds__(256) void conv_in_kernel(RowSrc src, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ y,
+                                                      int B, int Cout, int Lout) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * Lout) return;
+    const int b = (int)(idx / Lout);
+    const int t = (int)(idx - (long)b * Lout);
+    const float* xr = src.base + (long)(b % src.C) * src.chan_stride + (long)(b / src.C) * src.win_stride;
+    constexpr int padL = KS / 2;
+    float xv[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        const int i = t + kk - padL;
+        xv[kk] = (i >= 0 && i < src.T) ? xr[i] : 0.0f;
+    }
+    float* yo = y + (long)b * Cout * Lout + t;
+    for (int co = 0; co < Cout; ++co) {
+        float acc = bias[co];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int i = t + kk - padL;
+            // skip out-of-range taps exactly like the oracle (keeps -0.0 bookkeeping identical)
+            if (i >= 0 && i < src.T) acc = __builtin_fmaf(w[co * KS + kk], xv[kk], acc);
+        }
+        yo[(long)co * Lout] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------- generic chain conv
+// y[b][co][t] = bias[co] + sum_{ci} sum_{kk} w[co][ci][kk] * pre(x[b][ci][t*s + kk - padL])
+__global__ __launch_bounds__(256) void conv1d_chain_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           int B, int Cin, int Lin, int Cout, int Lout, int k, int s,
+                                                           int pre, float slope, int clamp_out) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * Cout * Lout) return;
+    const int t = (int)(idx % Lout);
+    const long r = idx / Lout;
+    const int co = (int)(r % Cout);
+    const int b = (int)(r / Cout);
+    const int padL = (k - s + 1) / 2;
+    const float* xb = x + (long)b * Cin * Lin;
+    const float* wr = w + (long)co * Cin * k;
+    float acc = bias[co];
+    const int i0 = t * s - padL;
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float* xr = xb + (long)ci * Lin;
+        for (int kk = 0; kk < k; ++kk) {
+            const int i = i0 + kk;
+            if (i >= 0 && i < Lin) {
+                float v = xr[i];
+                if (pre) v = lrelu(v, slope);
+                acc = __builtin_fmaf(wr[ci * k + kk], v, acc);
+            }
+        }
+    }
+    if (clamp_out) acc = acc > 1.0f ? 1.0f : (acc < -1.0f ? -1.0f : acc);
+    y[idx] = acc;
+}
+
+// ConvTranspose1d, weights [Cin][Cout][k], k = 2s, padL = (k-s+1)/2, Lout = Lin*s
+__global__ __launch_bounds__(256) void convtr1d_chain_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ y,
+                                                             int B, int Cin, int Lin, int Cout, int k, int s, int pre,
+                                                             float slope) {
+    const int Lout = Lin * s;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * Cout * Lout) return;
+    const int u = (int)(idx % Lout);
+    const long r = idx / Lout;
+    const int co = (int)(r % Cout);
+    const int b = (int)(r / Cout);
+    const int padL = (k - s + 1) / 2;
+    const int kk0 = (u + padL) % s;
+    const float* xb = x + (long)b * Cin * Lin;
+    float acc = bias[co];
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float* xr = xb + (long)ci * Lin;
+        const float* wr = w + ((long)ci * Cout + co) * k;
+        for (int kk = kk0; kk < k; kk += s) {
+            const int t = (u + padL - kk) / s;
+            if (t >= 0 && t < Lin) {
+                float v = xr[t];
+                if (pre) v = lrelu(v, slope);
+                acc = __builtin_fmaf(wr[kk], v, acc);
+            }
+        }
+    }
+    y[idx] = acc;
+}
+
+// ----------------------------------------------------------------- implicit-GEMM conv on f32 MFMA
+// GEMM view: M = Cout, N = B*Lout (columns flattened over windows), K = Cin*KS (ci-major).
+// Workgroup = 4 waves; tile = (GM*WM*32) channels x (GN*WN*32) columns.  K is walked in chunks of
+// 32: the im2col slice [32][NT] of the (pre-activated, zero-padded) input is staged into LDS by
+// coalesced-along-t global loads, double buffered; each wave then issues v_mfma_f32_32x32x2_f32 in
+// ascending k into WM x WN accumulator tiles.  A operands (weights) come pre-packed in fragment
+// order from L2: wp[co_tile][kquad][lane][4], element e of quad q = W[co_tile*32 + (lane&31)]
+// [2*(4q+e) + (lane>>5)], so every wave load is 1 KiB contiguous.
+template <int KS, int S, int WM, int WN, int GM, int GN>
+__global__ __launch_bounds__(256) void conv1d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                          int Cin, int Lin, int Cout, int Lout, long Ncols, int K,
+                                                          int Kpad, int pre, float slope) {
+    constexpr int KC = 32;
+    constexpr int MT = GM * WM * 32;
+    constexpr int NT = GN * WN * 32;
+    constexpr int ROWSTEP = 256 / NT;  // staging: threads cover ROWSTEP k-rows x NT columns per pass
+    constexpr int NST = KC / ROWSTEP;  // staged elements per thread per chunk
+    static_assert(256 % NT == 0, "NT must divide 256");
+    constexpr int padL = (KS - S + 1) / 2;
+
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [2][KC][NT]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gm = wave / GN, gn = wave % GN;
+    const long n0 = (long)blockIdx.x * NT;
+    const int co0 = blockIdx.y * MT;
+
+    // staging role: fixed column, rotating k rows
+    const int scol = tid % NT;
+    const int srow0 = tid / NT;
+    const long sn = n0 + scol;
+    const bool svalid = sn < Ncols;
+    const int sb = svalid ? (int)(sn / Lout) : 0;
+    const int st = svalid ? (int)(sn - (long)sb * Lout) : 0;
+    const float* sx = x + (long)sb * Cin * Lin;
+    const int si0 = st * S - padL;
+
+    const int nchunks = Kpad / KC;
+    const int kquads = Kpad / 8;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int wm = 0; wm < WM; ++wm) {
+        const int cot = co0 + (gm * WM + wm) * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cot + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float bv = co < Cout ? bias[co] : 0.0f;
+#pragma unroll
+            for (int wn = 0; wn < WN; ++wn) acc[wm][wn][r] = bv;
+        }
+    }
+
+    float sreg[NST];
+    auto stage_load = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+            const int kg = c * KC + srow0 + j * ROWSTEP;
+            const int ci = kg / KS;
+            const int kk = kg - ci * KS;
+            const int i = si0 + kk;
+            float v = 0.0f;
+            if (svalid && kg < K && i >= 0 && i < Lin) {
+                v = sx[(long)ci * Lin + i];
+                if (pre) v = lrelu(v, slope);
+            }
+            sreg[j] = v;
+        }
+    };
+    auto stage_write = [&](int buf) {
+        float* dst = xs + buf * KC * NT;
+#pragma unroll
+        for (int j = 0; j < NST; ++j) dst[(srow0 + j * ROWSTEP) * NT + scol] = sreg[j];
+    };
+
+    // weight fragments for one chunk: 4 quads x WM tiles
+    float4 aw[WM][4];
+    auto load_w = [&](int c) {
+#pragma unroll
+        for (int wm = 0; wm < WM; ++wm) {
+            const int cot = blockIdx.y * (GM * WM) + gm * WM + wm;
+            const float4* p = reinterpret_cast<const float4*>(wp) + ((long)cot * kquads + (long)c * 4) * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) aw[wm][q] = p[q * 64];
+        }
+    };
+
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = (c + 1) < nchunks;
+        load_w(c);
+        if (more) stage_load(c + 1);
+        const float* xb = xs + (c & 1) * KC * NT + (lane >> 5) * NT + gn * WN * 32 + (lane & 31);
+#pragma unroll
+        for (int kp = 0; kp < 16; ++kp) {
+            float bfr[WN];
+#pragma unroll
+            for (int wn = 0; wn < WN; ++wn) bfr[wn] = xb[kp * 2 * NT + wn * 32];
+#pragma unroll
+            for (int wm = 0; wm < WM; ++wm) {
+                const float4 q4 = aw[wm][kp >> 2];
+                const float a = (kp & 3) == 0 ? q4.x : (kp & 3) == 1 ? q4.y : (kp & 3) == 2 ? q4.z : q4.w;
+#pragma unroll
+                for (int wn = 0; wn < WN; ++wn)
+                    acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bfr[wn], acc[wm][wn], 0, 0, 0);
+            }
+        }
+        if (more) stage_write((c + 1) & 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout col = lane&31 (column), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel)
+#pragma unroll
+    for (int wn = 0; wn < WN; ++wn) {
+        const long n = n0 + (gn * WN + wn) * 32 + (lane & 31);
+        if (n >= Ncols) continue;
+        const int b = (int)(n / Lout);
+        const int t = (int)(n - (long)b * Lout);
+        float* yb = y + (long)b * Cout * Lout + t;
+#pragma unroll
+        for (int wm = 0; wm < WM; ++wm) {
+            const int cot = co0 + (gm * WM + wm) * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cot + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < Cout) yb[(long)co * Lout] = acc[wm][wn][r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- quantizer pieces
+// z[row][j] = b[j] + sum_d w[j][d] * ze[b][d][f]   for rows (b, f in [f0, f0+fc)); row = b*fc + (f-f0)
+__global__ __launch_bounds__(256) void in_proj_kernel(const float* __restrict__ ze, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ z, int B,
+                                                      int D, int F, int f0, int fc, int J, int ze_is_rows) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * fc * J) return;
+    const int j = (int)(idx % J);
+    const long row = idx / J;
+    const int f = f0 + (int)(row % fc);
+    const int b = (int)(row / fc);
+    float acc = bias[j];
+    if (ze_is_rows) {  // ze laid out [B*F][D] (public quantizer.inference entry)
+        const float* zr = ze + ((long)b * F + f) * D;
+        for (int d = 0; d < D; ++d) acc = __builtin_fmaf(w[j * D + d], zr[d], acc);
+    } else {  // encoder-native [B][D][F]
+        const float* zr = ze + (long)b * D * F + f;
+        for (int d = 0; d < D; ++d) acc = __builtin_fmaf(w[j * D + d], zr[(long)d * F], acc);
+    }
+    z[idx] = acc;
+}
+
+// cb[c][j] = pb[j] + sum_r pw[j][r] * raw[c][r]
+__global__ __launch_bounds__(256) void codebook_proj_kernel(const float* __restrict__ raw, const float* __restrict__ pw,
+                                                            const float* __restrict__ pb, float* __restrict__ cb,
+                                                            int N, int R, int J) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)N * J) return;
+    const int j = (int)(idx % J);
+    const long c = idx / J;
+    float acc = pb[j];
+    for (int r = 0; r < R; ++r) acc = __builtin_fmaf(pw[j * R + r], raw[c * R + r], acc);
+    cb[idx] = acc;
+}
+
+// hc[c] = -0.5 * sum_j cb[c][j]^2 ; also the MFMA-packed codebook:
+// cbp[tile][h][lane][4]: element e of half h = cb[tile*32 + (lane&31)][2*(4h+e) + (lane>>5)]
+__global__ __launch_bounds__(256) void codebook_norm_pack_kernel(const float* __restrict__ cb, float* __restrict__ hc,
+                                                                 float* __restrict__ cbp, int N, int J) {
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float a = 0.0f;
+    for (int j = 0; j < J; ++j) a = __builtin_fmaf(cb[c * J + j], cb[c * J + j], a);
+    hc[c] = -0.5f * a;
+    if (cbp && J == 16) {
+        const long tile = c >> 5;
+        const int l31 = (int)(c & 31);
+        for (int k = 0; k < 16; ++k) {
+            const int kp = k >> 1, hi = k & 1;  // k = 2*kp + hi
+            const int h = kp >> 2, e = kp & 3;
+            const int lane = l31 + 32 * hi;
+            cbp[((tile * 2 + h) * 64 + lane) * 4 + e] = cb[c * J + k];
+        }
+    }
+}
+
+__device__ __forceinline__ unsigned long long pack_key(float s, unsigned idx) {
+    unsigned u = __float_as_uint(s);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone float -> uint
+    return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - idx);  // ties -> lower idx wins
+}
+
+// chain variant: block = 256 threads, FB frames per block, thread strides over codes.
+template <int FB>
+__global__ __launch_bounds__(256) void vq_chain_kernel(const float* __restrict__ z, const float* __restrict__ cb,
+                                                       const float* __restrict__ hc, unsigned long long* __restrict__ keys,
+                                                       long F, int N, int c_per_split) {
+    const long f0 = (long)blockIdx.x * FB;
+    const int cbeg = blockIdx.y * c_per_split;
+    const int cend = min(N, cbeg + c_per_split);
+    float zr[FB][16];
+#pragma unroll
+    for (int i = 0; i < FB; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) zr[i][j] = (f0 + i < F) ? z[(f0 + i) * 16 + j] : 0.0f;
+    float best[FB];
+    unsigned bidx[FB];
+#pragma unroll
+    for (int i = 0; i < FB; ++i) { best[i] = -INFINITY; bidx[i] = 0xFFFFFFFFu; }
+    for (int c = cbeg + threadIdx.x; c < cend; c += 256) {
+        const float4* cr = reinterpret_cast<const float4*>(cb + (long)c * 16);
+        const float4 c0 = cr[0], c1 = cr[1], c2 = cr[2], c3 = cr[3];
+        const float cv[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
+        const float h = hc[c];
+#pragma unroll
+        for (int i = 0; i < FB; ++i) {
+            float a = h;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a = __builtin_fmaf(zr[i][j], cv[j], a);
+            if (a > best[i]) { best[i] = a; bidx[i] = (unsigned)c; }
+        }
+    }
+    __shared__ unsigned long long red[FB][4];
+#pragma unroll
+    for (int i = 0; i < FB; ++i) {
+        unsigned long long key = bidx[i] == 0xFFFFFFFFu ? 0ull : pack_key(best[i], bidx[i]);
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(key, o);
+            key = other > key ? other : key;
+        }
+        if ((threadIdx.x & 63) == 0) red[i][threadIdx.x >> 6] = key;
+    }
+    __syncthreads();
+    if (threadIdx.x < FB && f0 + threadIdx.x < F) {
+        unsigned long long key = red[threadIdx.x][0];
+        for (int w = 1; w < 4; ++w) key = red[threadIdx.x][w] > key ? red[threadIdx.x][w] : key;
+        atomicMax(&keys[f0 + threadIdx.x], key);
+    }
+}
+
+// MFMA variant: scores[c][f] = hc[c] + sum_k cb[c][k] * z[f][k] on v_mfma_f32_32x32x2_f32
+// (A = codebook tile 32 codes x 2 k, B = z tile 2 k x 32 frames, C initialised to hc[c]).
+// Workgroup = 4 waves sharing FN*32 frames; the block's code range is dealt to the waves in
+// interleaved 32-code tiles.  Per lane the running best over its rows is kept in registers
+// (strict '>' on ascending codes = lowest index on ties), packed into a monotone 64-bit key at the
+// end and merged by wave shuffle -> LDS -> one global atomicMax per frame.
+template <int FN>
+__global__ __launch_bounds__(256) void vq_mfma_kernel(const float* __restrict__ z, const float* __restrict__ cbp,
+                                                      const float* __restrict__ hc, unsigned long long* __restrict__ keys,
+                                                      long F, int N, int tiles_per_split) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long f0 = (long)blockIdx.x * (FN * 32);
+    const int tile_beg = blockIdx.y * tiles_per_split;
+    const int tile_end = min(N / 32, tile_beg + tiles_per_split);
+    const int half = lane >> 5;
+
+    // B fragments: zb[ft][kp] = z[f0 + ft*32 + (lane&31)][2*kp + half]
+    float zb[FN][8];
+#pragma unroll
+    for (int ft = 0; ft < FN; ++ft) {
+        const long f = f0 + ft * 32 + (lane & 31);
+#pragma unroll
+        for (int kp = 0; kp < 8; ++kp) zb[ft][kp] = f < F ? z[f * 16 + 2 * kp + half] : 0.0f;
+    }
+    float best[FN];
+    unsigned bidx[FN];
+#pragma unroll
+    for (int ft = 0; ft < FN; ++ft) { best[ft] = -INFINITY; bidx[ft] = 0xFFFFFFFFu; }
+
+    for (int tile = tile_beg + wave; tile < tile_end; tile += 4) {
+        const float4* ap = reinterpret_cast<const float4*>(cbp) + ((long)tile * 2) * 64 + lane;
+        const float4 a0 = ap[0], a1 = ap[64];
+        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const int c0 = tile * 32;
+        f32x16 cinit;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 h4 = *reinterpret_cast<const float4*>(hc + c0 + 8 * g + 4 * half);
+            cinit[4 * g + 0] = h4.x; cinit[4 * g + 1] = h4.y; cinit[4 * g + 2] = h4.z; cinit[4 * g + 3] = h4.w;
+        }
+#pragma unroll
+        for (int ft = 0; ft < FN; ++ft) {
+            f32x16 acc = cinit;
+#pragma unroll
+            for (int kp = 0; kp < 8; ++kp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp], zb[ft][kp], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned c = (unsigned)(c0 + (r & 3) + 8 * (r >> 2) + 4 * half);
+                if (acc[r] > best[ft]) { best[ft] = acc[r]; bidx[ft] = c; }
+            }
+        }
+    }
+    __shared__ unsigned long long red[FN][4][32];
+#pragma unroll
+    for (int ft = 0; ft < FN; ++ft) {
+        unsigned long long key = bidx[ft] == 0xFFFFFFFFu ? 0ull : pack_key(best[ft], bidx[ft]);
+        const unsigned long long other = __shfl_xor(key, 32);
+        key = other > key ? other : key;
+        if (lane < 32) red[ft][wave][lane] = key;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < FN * 32; i += 256) {
+        const int ft = i >> 5, l = i & 31;
+        const long f = f0 + i;
+        if (f < F) {
+            unsigned long long key = red[ft][0][l];
+            for (int w = 1; w < 4; ++w) key = red[ft][w][l] > key ? red[ft][w][l] : key;
+            atomicMax(&keys[f], key);
+        }
+    }
+}
+
+// keys -> int64 codes with the output mapping of RowDst; also re-arms keys for the next call
+struct RowDst {
+    int64_t* base;
+    int C;            // rows are (win, chan): chan = row_b % C, win = row_b / C
+    long chan_stride;
+    long win_stride;
+    int fc;           // frames kept per row
+};
+__global__ __launch_bounds__(256) void vq_finalize_kernel(unsigned long long* __restrict__ keys, RowDst dst, long rows) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const unsigned long long key = keys[i];
+    keys[i] = 0ull;
+    const long b = i / dst.fc;
+    const int j = (int)(i - b * dst.fc);
+    dst.base[(b % dst.C) * dst.chan_stride + (b / dst.C) * dst.win_stride + j] =
+        (int64_t)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+}
+
+// zq[b][j][f] = cb[codes[b][f]][j]
+__global__ __launch_bounds__(256) void embed_codes_kernel(const int64_t* __restrict__ codes, const float* __restrict__ cb,
+                                                          float* __restrict__ zq, int B, int F, int J, int N,
+                                                          int* __restrict__ err) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * J * F) return;
+    const int f = (int)(idx % F);
+    const long r = idx / F;
+    const int j = (int)(r % J);
+    const int b = (int)(r / J);
+    int64_t c = codes[(long)b * F + f];
+    if (c < 0 || c >= N) { atomicExch(err, 1); c = 0; }
+    zq[idx] = cb[c * J + j];
+}
+
+// [B][F][J] -> [B][J][F]
+__global__ __launch_bounds__(256) void transpose_fj_kernel(const float* __restrict__ in, float* __restrict__ out, int B,
+                                                           int F, int J) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * J * F) return;
+    const int f = (int)(idx % F);
+    const long r = idx / F;
+    const int j = (int)(r % J);
+    const int b = (int)(r / J);
+    out[idx] = in[((long)b * F + f) * J + j];
+}
+// [B][D][F] -> [B][F][D]
+__global__ __launch_bounds__(256) void transpose_df_kernel(const float* __restrict__ in, float* __restrict__ out, int B,
+                                                           int D, int F) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * D * F) return;
+    const int d = (int)(idx % D);
+    const long r = idx / D;
+    const int f = (int)(r % F);
+    const int b = (int)(r / F);
+    out[idx] = in[((long)b * D + d) * F + f];
+}
+
+// =============================================================================================
+struct ConvLayer {
+    int cin, cout, k, s, pre, tr;
+    float* w = nullptr;     // original layout
+    float* b = nullptr;
+    float* wp = nullptr;    // MFMA-packed (encoder non-transposed layers with cin*k >= 32)
+    int K = 0, Kpad = 0, cout_pad = 0;
+};
+
+struct rca_codec {
+    rca_codec_config_t cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int hop = 1;
+    int variant = 1;
+    std::vector<ConvLayer> enc, dec;
+    float *q_in_w = nullptr, *q_in_b = nullptr;
+    float *cb = nullptr, *hc = nullptr, *cbp = nullptr;
+    DevBuf act[2], zbuf, keys, io_a, io_b;
+    int* err_flag = nullptr;
+    // bench profiling (rca_codec_profile): event pairs around profiled launches
+    struct Prof { hipEvent_t a, b; int kclass; double flops, bytes; };
+    bool profile = false;
+    std::vector<Prof> prof;       // recorded this interval
+    std::vector<Prof> prof_pool;  // reusable events
+};
+
+struct ProfScope {
+    rca_codec* h; hipStream_t st; rca_codec::Prof p; bool on;
+    ProfScope(rca_codec* h_, hipStream_t st_, int kclass, double flops, double bytes) : h(h_), st(st_), on(h_->profile) {
+        if (!on) return;
+        if (!h->prof_pool.empty()) { p = h->prof_pool.back(); h->prof_pool.pop_back(); }
+        else { (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); }
+        p.kclass = kclass; p.flops = flops; p.bytes = bytes;
+        (void)hipEventRecord(p.a, st);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(p.b, st);
+        h->prof.push_back(p);
+    }
+};
+
+static int upload(const rca_tensor_t* ts, int n, const std::string& name, long numel, float** out) {
+    const rca_tensor_t* t = find_tensor(ts, n, name);
+    if (!t) return fail(RCA_ERR_MISSING, "tensor '%s' missing", name.c_str());
+    if (t->numel != numel) return fail(RCA_ERR_ARG, "tensor '%s': numel %ld, expected %ld", name.c_str(), (long)t->numel, numel);
+    if (t->dtype != RCA_F32) return fail(RCA_ERR_ARG, "tensor '%s' must be f32", name.c_str());
+    RCA_HIP(hipMalloc((void**)out, (size_t)numel * sizeof(float)));
+    RCA_HIP(hipMemcpy(*out, t->data, (size_t)numel * sizeof(float), hipMemcpyHostToDevice));
+    return RCA_OK;
+}
+
+// pack W[cout][K] into MFMA A-fragment order, zero padded to cout_pad x Kpad
+static int pack_weights(const float* w_host, ConvLayer& L) {
+    L.K = L.cin * L.k;
+    L.Kpad = (L.K + 31) / 32 * 32;
+    L.cout_pad = (L.cout + 127) / 128 * 128;  // whole number of the largest workgroup tile
+    const long n = (long)(L.cout_pad / 32) * (L.Kpad / 8) * 64 * 4;
+    std::vector<float> p((size_t)n, 0.0f);
+    for (int cot = 0; cot < L.cout_pad / 32; ++cot)
+        for (int q = 0; q < L.Kpad / 8; ++q)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) {
+                    const int co = cot * 32 + (lane & 31);
+                    const int k = 2 * (4 * q + e) + (lane >> 5);
+                    float v = 0.0f;
+                    if (co < L.cout && k < L.K) v = w_host[(long)co * L.K + k];
+                    p[(((long)cot * (L.Kpad / 8) + q) * 64 + lane) * 4 + e] = v;
+                }
+    RCA_HIP(hipMalloc((void**)&L.wp, (size_t)n * sizeof(float)));
+    RCA_HIP(hipMemcpy(L.wp, p.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    return RCA_OK;
+}
+
+static bool mfma_supported(int k, int s) {
+    return (k == 4 && s == 2) || (k == 8 && s == 4) || (k == 10 && s == 5) || (k == 16 && s == 8) || (k == 3 && s == 1);
+}
+
+extern "C" const char* rca_last_error(void) { return g_err; }
+extern "C" const char* rca_version(void) { return "rca-hip 0.1 (gfx950)"; }
+extern "C" int rca_device_count(int* n) {
+    if (!n) return fail(RCA_ERR_ARG, "null");
+    RCA_HIP(hipGetDeviceCount(n));
+    return RCA_OK;
+}
+
+extern "C" int rca_codec_destroy(rca_codec_t* h) {
+    if (!h) return RCA_OK;
+    (void)hipSetDevice(h->device);
+    for (auto* v : {&h->enc, &h->dec})
+        for (auto& L : *v) {
+            if (L.w) (void)hipFree(L.w);
+            if (L.b) (void)hipFree(L.b);
+            if (L.wp) (void)hipFree(L.wp);
+        }
+    for (float* p : {h->q_in_w, h->q_in_b, h->cb, h->hc, h->cbp})
+        if (p) (void)hipFree(p);
+    if (h->err_flag) (void)hipFree(h->err_flag);
+    h->act[0].release(); h->act[1].release(); h->zbuf.release(); h->keys.release(); h->io_a.release(); h->io_b.release();
+    for (auto* v : {&h->prof, &h->prof_pool})
+        for (auto& p : *v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return RCA_OK;
+}
+
+extern "C" int rca_codec_create(const rca_codec_config_t* cfg, const rca_tensor_t* ts, int32_t nt, int32_t device,
+                                rca_codec_t** out) {
+    if (!cfg || !ts || !out) return fail(RCA_ERR_ARG, "null argument");
+    if (cfg->n_stages < 1 || cfg->n_stages > RCA_MAX_STAGES) return fail(RCA_ERR_ARG, "n_stages out of range");
+    if (cfg->codebook_dim != 16) return fail(RCA_ERR_ARG, "codebook_dim must be 16 (got %d)", cfg->codebook_dim);
+    if (cfg->codebook_size % 128 != 0) return fail(RCA_ERR_ARG, "codebook_size must be a multiple of 128");
+    if (cfg->k_in != 7 && cfg->k_in != 3 && cfg->k_in != 5) return fail(RCA_ERR_ARG, "k_in must be 3, 5 or 7");
+    RCA_HIP(hipSetDevice(device));
+    rca_codec* h = new rca_codec();
+    h->cfg = *cfg;
+    h->device = device;
+    int rc = RCA_OK;
+    auto bail = [&](int code) { rca_codec_destroy(h); return code; };
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(RCA_ERR_HIP, "stream create"));
+    const int n = cfg->n_stages;
+    h->hop = 1;
+    for (int i = 0; i < n; ++i) h->hop *= cfg->strides[i];
+
+    auto add = [&](std::vector<ConvLayer>& v, const std::string& name, int cin, int cout, int k, int s, int pre, int tr,
+                   bool pack) -> int {
+        ConvLayer L;
+        L.cin = cin; L.cout = cout; L.k = k; L.s = s; L.pre = pre; L.tr = tr;
+        if ((rc = upload(ts, nt, name + ".weight", (long)cin * cout * k, &L.w)) != RCA_OK) return rc;
+        if ((rc = upload(ts, nt, name + ".bias", cout, &L.b)) != RCA_OK) { v.push_back(L); return rc; }
+        if (pack && !tr && mfma_supported(k, s)) {
+            const rca_tensor_t* t = find_tensor(ts, nt, name + ".weight");
+            if ((rc = pack_weights((const float*)t->data, L)) != RCA_OK) { v.push_back(L); return rc; }
+        }
+        v.push_back(L);
+        return RCA_OK;
+    };
+    if ((rc = add(h->enc, "enc.conv_in", 1, cfg->channels[0], cfg->k_in, 1, 0, 0, false)) != RCA_OK) return bail(rc);
+    for (int i = 0; i < n; ++i) {
+        const int s = cfg->strides[i];
+        if ((rc = add(h->enc, "enc.down." + std::to_string(i), cfg->channels[i], cfg->channels[i + 1], 2 * s, s, 1, 0, true)) != RCA_OK)
+            return bail(rc);
+    }
+    if ((rc = add(h->enc, "enc.conv_out", cfg->channels[n], cfg->latent_dim, cfg->k_latent, 1, 1, 0, true)) != RCA_OK) return bail(rc);
+    if ((rc = add(h->dec, "dec.conv_in", cfg->codebook_dim, cfg->channels[n], cfg->k_latent, 1, 0, 0, true)) != RCA_OK) return bail(rc);
+    for (int i = 0; i < n; ++i) {
+        const int s = cfg->strides[n - 1 - i];
+        if ((rc = add(h->dec, "dec.up." + std::to_string(i), cfg->channels[n - i], cfg->channels[n - 1 - i], 2 * s, s, 1, 1, false)) != RCA_OK)
+            return bail(rc);
+    }
+    if ((rc = add(h->dec, "dec.conv_out", cfg->channels[0], 1, cfg->k_in, 1, 1, 0, false)) != RCA_OK) return bail(rc);
+
+    const int J = cfg->codebook_dim, N = cfg->codebook_size, R = cfg->codebook_raw_dim, D = cfg->latent_dim;
+    if ((rc = upload(ts, nt, "quantizer.in_proj.weight", (long)J * D, &h->q_in_w)) != RCA_OK) return bail(rc);
+    if ((rc = upload(ts, nt, "quantizer.in_proj.bias", J, &h->q_in_b)) != RCA_OK) return bail(rc);
+    float *raw = nullptr, *pw = nullptr, *pb = nullptr;
+    auto free3 = [&]() { for (float* p : {raw, pw, pb}) if (p) (void)hipFree(p); };
+    if ((rc = upload(ts, nt, "quantizer.codebook.weight", (long)N * R, &raw)) != RCA_OK) { free3(); return bail(rc); }
+    if ((rc = upload(ts, nt, "quantizer.codebook_proj.weight", (long)J * R, &pw)) != RCA_OK) { free3(); return bail(rc); }
+    if ((rc = upload(ts, nt, "quantizer.codebook_proj.bias", J, &pb)) != RCA_OK) { free3(); return bail(rc); }
+    if (hipMalloc((void**)&h->cb, (size_t)N * J * 4) != hipSuccess || hipMalloc((void**)&h->hc, (size_t)N * 4) != hipSuccess ||
+        hipMalloc((void**)&h->cbp, (size_t)N * J * 4) != hipSuccess || hipMalloc((void**)&h->err_flag, 4) != hipSuccess) {
+        free3();
+        return bail(fail(RCA_ERR_HIP, "codebook alloc"));
+    }
+    (void)hipMemsetAsync(h->err_flag, 0, 4, h->stream);
+    // projected codebook + half norms are constants of the model: computed once (the reference
+    // recomputes the projection on every decode call, audio_tokenizer.py:198)
+    codebook_proj_kernel<<<cdiv((long)N * J, 256), 256, 0, h->stream>>>(raw, pw, pb, h->cb, N, R, J);
+    codebook_norm_pack_kernel<<<cdiv(N, 256), 256, 0, h->stream>>>(h->cb, h->hc, h->cbp, N, J);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    free3();
+    if (e != hipSuccess) return bail(fail(RCA_ERR_HIP, "codebook init: %s", hipGetErrorString(e)));
+    *out = h;
+    return RCA_OK;
+}
+
+extern "C" int rca_codec_hop(const rca_codec_t* h, int32_t* hop) {
+    if (!h || !hop) return fail(RCA_ERR_ARG, "null");
+    *hop = h->hop;
+    return RCA_OK;
+}
+extern "C" int rca_codec_num_frames(const rca_codec_t* h, int32_t T, int32_t* F) {
+    if (!h || !F || T < 0) return fail(RCA_ERR_ARG, "bad argument");
+    *F = (T + h->hop - 1) / h->hop;
+    return RCA_OK;
+}
+extern "C" int rca_codec_set_variant(rca_codec_t* h, int32_t v) {
+    if (!h || v < 0 || v > 1) return fail(RCA_ERR_ARG, "variant must be 0 or 1");
+    h->variant = v;
+    return RCA_OK;
+}
+extern "C" int rca_codec_sync(rca_codec_t* h) {
+    if (!h) return fail(RCA_ERR_ARG, "null");
+    RCA_HIP(hipSetDevice(h->device));
+    RCA_HIP(hipStreamSynchronize(h->stream));
+    return RCA_OK;
+}
+
+template <int KS, int S>
+static int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B, int Lin, int Lout, float slope, hipStream_t st) {
+    const long Ncols = (long)B * Lout;
+    // tile choice: big tiles when they still fill the chip, otherwise 64x64 tiles (4x the workgroups)
+    const long wg_big = (long)cdiv(Ncols, 128) * cdiv(L.cout, 128);
+    if (L.cout <= 64) {
+        if ((long)cdiv(Ncols, 256) >= 512) {
+            constexpr int NT = 256;
+            dim3 grid(cdiv(Ncols, NT), cdiv(L.cout, 64));
+            conv1d_mfma_kernel<KS, S, 2, 2, 1, 4><<<grid, 256, 2 * 32 * NT * 4, st>>>(x, L.wp, L.b, y, L.cin, Lin, L.cout, Lout, Ncols, L.K, L.Kpad, L.pre, slope);
+        } else {
+            constexpr int NT = 64;
+            dim3 grid(cdiv(Ncols, NT), cdiv(L.cout, 64));
+            conv1d_mfma_kernel<KS, S, 1, 1, 2, 2><<<grid, 256, 2 * 32 * NT * 4, st>>>(x, L.wp, L.b, y, L.cin, Lin, L.cout, Lout, Ncols, L.K, L.Kpad, L.pre, slope);
+        }
+    } else if (wg_big >= 512) {
+        constexpr int NT = 128;
+        dim3 grid(cdiv(Ncols, NT), cdiv(L.cout, 128));
+        conv1d_mfma_kernel<KS, S, 2, 2, 2, 2><<<grid, 256, 2 * 32 * NT * 4, st>>>(x, L.wp, L.b, y, L.cin, Lin, L.cout, Lout, Ncols, L.K, L.Kpad, L.pre, slope);
+    } else {
+        constexpr int NT = 64;
+        dim3 grid(cdiv(Ncols, NT), cdiv(L.cout, 64));
+        conv1d_mfma_kernel<KS, S, 1, 1, 2, 2><<<grid, 256, 2 * 32 * NT * 4, st>>>(x, L.wp, L.b, y, L.cin, Lin, L.cout, Lout, Ncols, L.K, L.Kpad, L.pre, slope);
+    }
+    RCA_LAUNCH_CHECK();
+    return RCA_OK;
+}
+
+static int run_conv(rca_codec* h, const ConvLayer& L, const float* x, float* y, int B, int Lin, int clamp_out, hipStream_t st) {
+    const float slope = h->cfg.leaky_slope;
+    if (L.tr) {
+        const long total = (long)B * L.cout * Lin * L.s;
+        convtr1d_chain_kernel<<<cdiv(total, 256), 256, 0, st>>>(x, L.w, L.b, y, B, L.cin, Lin, L.cout, L.k, L.s, L.pre, slope);
+        RCA_LAUNCH_CHECK();
+        return RCA_OK;
+    }
+    const int Lout = Lin / L.s;
+    const double cflops = 2.0 * L.cin * L.k * L.cout * (double)B * Lout;
+    const double cbytes = 4.0 * ((double)B * L.cin * Lin + (double)B * L.cout * Lout + (double)L.cin * L.k * L.cout);
+    if (h->variant == 1 && L.wp && !clamp_out) {
+        ProfScope ps(h, st, 0, cflops, cbytes);
+        if (L.k == 4 && L.s == 2) return launch_conv_mfma<4, 2>(L, x, y, B, Lin, Lout, slope, st);
+        if (L.k == 8 && L.s == 4) return launch_conv_mfma<8, 4>(L, x, y, B, Lin, Lout, slope, st);
+        if (L.k == 10 && L.s == 5) return launch_conv_mfma<10, 5>(L, x, y, B, Lin, Lout, slope, st);
+        if (L.k == 16 && L.s == 8) return launch_conv_mfma<16, 8>(L, x, y, B, Lin, Lout, slope, st);
+        if (L.k == 3 && L.s == 1) return launch_conv_mfma<3, 1>(L, x, y, B, Lin, Lout, slope, st);
+    }
+    const long total = (long)B * L.cout * Lout;
+    ProfScope ps(h, st, 3, cflops, cbytes);
+    conv1d_chain_kernel<<<cdiv(total, 256), 256, 0, st>>>(x, L.w, L.b, y, B, L.cin, Lin, L.cout, Lout, L.k, L.s, L.pre, slope, clamp_out);
+    RCA_LAUNCH_CHECK();
+    return RCA_OK;
+}
+
+// encoder stack: rows described by src -> ze [B][D][F] left in *ze_out (a workspace buffer).
+// tap_layer >= 0 copies that layer's output (device->device) into tap_dev.
+static int run_encoder(rca_codec* h, RowSrc src, int B, hipStream_t st, float** ze_out, int* F_out, int tap_layer, float* tap_dev) {
+    const rca_codec_config_t& c = h->cfg;
+    const int F = (src.T + h->hop - 1) / h->hop;
+    const int Tp = F * h->hop;
+    if (F < 1) return fail(RCA_ERR_ARG, "empty audio (T=%d)", src.T);
+    size_t max_elems = 0;
+    {
+        long L = Tp;
+        max_elems = std::max(max_elems, (size_t)B * c.channels[0] * L);
+        for (int i = 0; i < c.n_stages; ++i) { L /= c.strides[i]; max_elems = std::max(max_elems, (size_t)B * c.channels[i + 1] * L); }
+        max_elems = std::max(max_elems, (size_t)B * c.latent_dim * L);
+    }
+    int rc;
+    if ((rc = h->act[0].ensure(max_elems * 4)) != RCA_OK) return rc;
+    if ((rc = h->act[1].ensure(max_elems * 4)) != RCA_OK) return rc;
+    int cur = 0;
+    int L = Tp;
+    {
+        const ConvLayer& L0 = h->enc[0];
+        const long total = (long)B * L;
+        float* y = h->act[cur].as<float>();
+        ProfScope ps(h, st, 2, 2.0 * L0.k * L0.cout * (double)total, 4.0 * ((double)total + (double)total * L0.cout));
+        if (L0.k == 7) conv_in_kernel<7><<<cdiv(total, 256), 256, 0, st>>>(src, L0.w, L0.b, y, B, L0.cout, L);
+        else if (L0.k == 5) conv_in_kernel<5><<<cdiv(total, 256), 256, 0, st>>>(src, L0.w, L0.b, y, B, L0.cout, L);
+        else conv_in_kernel<3><<<cdiv(total, 256), 256, 0, st>>>(src, L0.w, L0.b, y, B, L0.cout, L);
+        RCA_LAUNCH_CHECK();
+        if (tap_layer == 0) RCA_HIP(hipMemcpyAsync(tap_dev, y, (size_t)B * L0.cout * L * 4, hipMemcpyDeviceToDevice, st));
+    }
+    for (size_t li = 1; li < h->enc.size(); ++li) {
+        const ConvLayer& Ly = h->enc[li];
+        float* x = h->act[cur].as<float>();
+        float* y = h->act[cur ^ 1].as<float>();
+        if ((rc = run_conv(h, Ly, x, y, B, L, 0, st)) != RCA_OK) return rc;
+        L /= Ly.s;
+        cur ^= 1;
+        if (tap_layer == (int)li) RCA_HIP(hipMemcpyAsync(tap_dev, y, (size_t)B * Ly.cout * L * 4, hipMemcpyDeviceToDevice, st));
+    }
+    *ze_out = h->act[cur].as<float>();
+    *F_out = F;
+    return RCA_OK;
+}
+
+// in_proj + nearest-neighbour search over rows (b, f in [f0, f0+fc)); writes int64 codes via dst
+static int run_quantize(rca_codec* h, const float* ze, int ze_is_rows, int B, int F, int f0, int fc, RowDst dst, hipStream_t st,
+                        float* ztap_dev) {
+    const rca_codec_config_t& c = h->cfg;
+    const long rows = (long)B * fc;
+    const int J = c.codebook_dim, N = c.codebook_size;
+    int rc;
+    if ((rc = h->zbuf.ensure((size_t)rows * J * 4)) != RCA_OK) return rc;
+    const size_t need_keys = (size_t)rows;
+    if (h->keys.cap < need_keys * 8) {
+        if ((rc = h->keys.ensure(need_keys * 8)) != RCA_OK) return rc;
+        RCA_HIP(hipMemsetAsync(h->keys.p, 0, h->keys.cap, st));
+    }
+    float* z = h->zbuf.as<float>();
+    in_proj_kernel<<<cdiv(rows * J, 256), 256, 0, st>>>(ze, h->q_in_w, h->q_in_b, z, B, c.latent_dim, F, f0, fc, J, ze_is_rows);
+    RCA_LAUNCH_CHECK();
+    if (ztap_dev) RCA_HIP(hipMemcpyAsync(ztap_dev, z, (size_t)rows * J * 4, hipMemcpyDeviceToDevice, st));
+    unsigned long long* keys = h->keys.as<unsigned long long>();
+    ProfScope ps(h, st, 1, 2.0 * (double)rows * N * J, 4.0 * ((double)N * (J + 1) + (double)rows * J) + 8.0 * rows);
+    if (h->variant == 1) {
+        constexpr int FN = 2;
+        const int ftiles = (int)cdiv(rows, FN * 32);
+        const int total_tiles = N / 32;
+        // enough code splits to put >= ~1024 workgroups on the chip, each wave keeping >= 4 tiles
+        int splits = (int)std::max(1L, std::min((long)total_tiles / 16, (1024 + ftiles - 1) / (long)ftiles));
+        int tps = (total_tiles + splits - 1) / splits;
+        tps = (tps + 3) / 4 * 4;
+        splits = (total_tiles + tps - 1) / tps;
+        dim3 grid(ftiles, splits);
+        vq_mfma_kernel<FN><<<grid, 256, 0, st>>>(z, h->cbp, h->hc, keys, rows, N, tps);
+    } else {
+        constexpr int FB = 4;
+        const int fblocks = (int)cdiv(rows, FB);
+        int splits = (int)std::max(1L, std::min((long)N / 1024, (1024 + fblocks - 1) / (long)fblocks));
+        int cps = (N + splits - 1) / splits;
+        cps = (cps + 255) / 256 * 256;
+        splits = (N + cps - 1) / cps;
+        dim3 grid(fblocks, splits);
+        vq_chain_kernel<FB><<<grid, 256, 0, st>>>(z, h->cb, h->hc, keys, rows, N, cps);
+    }
+    RCA_LAUNCH_CHECK();
+    dst.fc = fc;
+    vq_finalize_kernel<<<cdiv(rows, 256), 256, 0, st>>>(keys, dst, rows);
+    RCA_LAUNCH_CHECK();
+    return RCA_OK;
+}
+
+static hipStream_t pick_stream(rca_codec* h, void* stream) { return stream ? (hipStream_t)stream : h->stream; }
+
+extern "C" int rca_codec_encode_dev(rca_codec_t* h, const float* pcm, int32_t B, int32_t T, int64_t* codes, void* stream) {
+    if (!h || !pcm || !codes || B < 1 || T < 1) return fail(RCA_ERR_ARG, "encode: bad argument (B=%d T=%d)", B, T);
+    RCA_HIP(hipSetDevice(h->device));
+    hipStream_t st = pick_stream(h, stream);
+    RowSrc src{pcm, B, (long)T, 0, T};
+    float* ze; int F, rc;
+    if ((rc = run_encoder(h, src, B, st, &ze, &F, -1, nullptr)) != RCA_OK) return rc;
+    RowDst dst{codes, B, (long)F, 0, F};
+    return run_quantize(h, ze, 0, B, F, 0, F, dst, st, nullptr);
+}
+
+extern "C" int rca_codec_encode(rca_codec_t* h, const float* pcm_host, int32_t B, int32_t T, int64_t* codes_host) {
+    if (!h || !pcm_host || !codes_host || B < 1 || T < 1) return fail(RCA_ERR_ARG, "encode: bad argument (B=%d T=%d)", B, T);
+    RCA_HIP(hipSetDevice(h->device));
+    const int F = (T + h->hop - 1) / h->hop;
+    int rc;
+    if ((rc = h->io_a.ensure((size_t)B * T * 4)) != RCA_OK) return rc;
+    if ((rc = h->io_b.ensure((size_t)B * F * 8)) != RCA_OK) return rc;
+    RCA_HIP(hipMemcpyAsync(h->io_a.p, pcm_host, (size_t)B * T * 4, hipMemcpyHostToDevice, h->stream));
+    if ((rc = rca_codec_encode_dev(h, h->io_a.as<float>(), B, T, h->io_b.as<int64_t>(), h->stream)) != RCA_OK) return rc;
+    RCA_HIP(hipMemcpyAsync(codes_host, h->io_b.p, (size_t)B * F * 8, hipMemcpyDeviceToHost, h->stream));
+    RCA_HIP(hipStreamSynchronize(h->stream));
+    return RCA_OK;
+}
+
+extern "C" int rca_codec_encode_tap(rca_codec_t* h, const float* pcm_host, int32_t B, int32_t T, int32_t layer, float* out_host,
+                                    int64_t out_numel) {
+    if (!h || !pcm_host || !out_host || B < 1 || T < 1) return fail(RCA_ERR_ARG, "tap: bad argument");
+    RCA_HIP(hipSetDevice(h->device));
+    const int n = h->cfg.n_stages;
+    if (layer < 0 || layer > n + 2) return fail(RCA_ERR_ARG, "tap layer out of range");
+    int rc;
+    if ((rc = h->io_a.ensure((size_t)B * T * 4)) != RCA_OK) return rc;
+    if ((rc = h->io_b.ensure((size_t)out_numel * 4)) != RCA_OK) return rc;
+    RCA_HIP(hipMemcpyAsync(h->io_a.p, pcm_host, (size_t)B * T * 4, hipMemcpyHostToDevice, h->stream));
+    RowSrc src{h->io_a.as<float>(), B, (long)T, 0, T};
+    float* ze; int F;
+    // element-count check
+    {
+        const int Fx = (T + h->hop - 1) / h->hop;
+        long L = (long)Fx * h->hop, want;
+        if (layer == 0) want = (long)B * h->cfg.channels[0] * L;
+        else if (layer <= n) { for (int i = 0; i < layer; ++i) L /= h->cfg.strides[i]; want = (long)B * h->cfg.channels[layer] * L; }
+        else if (layer == n + 1) want = (long)B * h->cfg.latent_dim * Fx;
+        else want = (long)B * Fx * h->cfg.codebook_dim;
+        if (want != out_numel) return fail(RCA_ERR_ARG, "tap: out_numel %ld, expected %ld", (long)out_numel, want);
+    }
+    if ((rc = run_encoder(h, src, B, h->stream, &ze, &F, layer <= n + 1 ? layer : -1, h->io_b.as<float>())) != RCA_OK) return rc;
+    if (layer == n + 2) {
+        DevBuf tmp;
+        if ((rc = tmp.ensure((size_t)B * F * 8)) != RCA_OK) return rc;
+        RowDst dst{tmp.as<int64_t>(), B, (long)F, 0, F};
+        rc = run_quantize(h, ze, 0, B, F, 0, F, dst, h->stream, h->io_b.as<float>());
+        hipError_t e = hipStreamSynchronize(h->stream);
+        tmp.release();
+        if (rc != RCA_OK) return rc;
+        if (e != hipSuccess) return fail(RCA_ERR_HIP, "tap sync: %s", hipGetErrorString(e));
+    }
+    RCA_HIP(hipMemcpyAsync(out_host, h->io_b.p, (size_t)out_numel * 4, hipMemcpyDeviceToHost, h->stream));
+    RCA_HIP(hipStreamSynchronize(h->stream));
+    return RCA_OK;
+}
+
+extern "C" int rca_codec_encode_chunk_range_dev(rca_codec_t* h, const float* audio, int32_t C, int64_t N, int32_t chunk, int32_t ctx,
+                                                int32_t batch_windows, int64_t chunk_begin, int64_t chunk_end, int64_t* codes,
+                                                int64_t codes_per_channel, void* stream) {
+    if (!h || !audio || !codes || C < 1 || N < 1 || chunk < 1 || ctx < 0 || batch_windows < 1)
+        return fail(RCA_ERR_ARG, "encode_windows: bad argument");
+    RCA_HIP(hipSetDevice(h->device));
+    hipStream_t st = pick_stream(h, stream);
+    const int sr = h->cfg.sample_rate;
+    // int(audio_secs * framerate) exactly as audio_tokenizer.py:99-100 computes it
+    const double framerate = (double)sr / (double)h->hop;
+    const int fpc = (int)(((double)chunk / (double)sr) * framerate);
+    const long n_chunks = N / chunk;
+    if (chunk_begin < 0 || chunk_end > n_chunks || chunk_begin > chunk_end)
+        return fail(RCA_ERR_ARG, "chunk range [%ld,%ld) outside [0,%ld]", (long)chunk_begin, (long)chunk_end, n_chunks);
+    if (fpc < 1) return fail(RCA_ERR_ARG, "chunk of %d samples holds no whole frame", chunk);
+    if (codes_per_channel < (chunk_end - chunk_begin) * fpc)
+        return fail(RCA_ERR_ARG, "codes buffer too small: %ld < %ld", (long)codes_per_channel, (long)(chunk_end - chunk_begin) * fpc);
+    const int W = std::max(chunk, ctx);
+    int rc;
+    long i = chunk_begin;
+    // warm-up: the rolling context is still shorter than ctx (audio_tokenizer.py:72-74)
+    for (; i < chunk_end && (i + 1) * (long)chunk < W; ++i) {
+        const int T = (int)((i + 1) * chunk);
+        RowSrc src{audio, C, (long)N, 0, T};
+        float* ze; int F;
+        if ((rc = run_encoder(h, src, C, st, &ze, &F, -1, nullptr)) != RCA_OK) return rc;
+        if (F < fpc) return fail(RCA_ERR_STATE, "window of %d samples has %d frames < %d kept", T, F, fpc);
+        RowDst dst{codes + (i - chunk_begin) * fpc, C, (long)codes_per_channel, 0, fpc};
+        if ((rc = run_quantize(h, ze, 0, C, F, F - fpc, fpc, dst, st, nullptr)) != RCA_OK) return rc;
+    }
+    // steady state: full windows [end - W, end), batch_windows rows (window x channel) per pass
+    const int wins_per_pass = std::max(1, batch_windows / C);
+    while (i < chunk_end) {
+        const int nw = (int)std::min<long>(wins_per_pass, chunk_end - i);
+        const long start0 = (i + 1) * (long)chunk - W;
+        RowSrc src{audio + start0, C, (long)N, (long)chunk, W};
+        float* ze; int F;
+        if ((rc = run_encoder(h, src, nw * C, st, &ze, &F, -1, nullptr)) != RCA_OK) return rc;
+        if (F < fpc) return fail(RCA_ERR_STATE, "window has %d frames < %d kept", F, fpc);
+        RowDst dst{codes + (i - chunk_begin) * fpc, C, (long)codes_per_channel, (long)fpc, fpc};
+        if ((rc = run_quantize(h, ze, 0, nw * C, F, F - fpc, fpc, dst, st, nullptr)) != RCA_OK) return rc;
+        i += nw;
+    }
+    return RCA_OK;
+}
+
+extern "C" int rca_codec_encode_windows_dev(rca_codec_t* h, const float* audio, int32_t C, int64_t N, int32_t chunk, int32_t ctx,
+                                            int32_t batch_windows, int64_t* codes, int64_t codes_per_channel, void* stream) {
+    if (chunk < 1) return fail(RCA_ERR_ARG, "encode_windows: bad argument");
+    return rca_codec_encode_chunk_range_dev(h, audio, C, N, chunk, ctx, batch_windows, 0, N / chunk, codes, codes_per_channel, stream);
+}
+
+extern "C" int rca_codec_encoder_dev(rca_codec_t* h, const float* pcm, int32_t B, int32_t T, float* ze_out, void* stream) {
+    if (!h || !pcm || !ze_out || B < 1 || T < 1) return fail(RCA_ERR_ARG, "encoder: bad argument");
+    RCA_HIP(hipSetDevice(h->device));
+    hipStream_t st = pick_stream(h, stream);
+    RowSrc src{pcm, B, (long)T, 0, T};
+    float* ze; int F, rc;
+    if ((rc = run_encoder(h, src, B, st, &ze, &F, -1, nullptr)) != RCA_OK) return rc;
+    const long total = (long)B * h->cfg.latent_dim * F;
+    transpose_df_kernel<<<cdiv(total, 256), 256, 0, st>>>(ze, ze_out, B, h->cfg.latent_dim, F);
+    RCA_LAUNCH_CHECK();
+    return RCA_OK;
+}
+
+extern "C" int rca_codec_quantize_dev(rca_codec_t* h, const float* ze_rows, int64_t rows, int64_t* codes, void* stream) {
+    if (!h || !ze_rows || !codes || rows < 1) return fail(RCA_ERR_ARG, "quantize: bad argument");
+    RCA_HIP(hipSetDevice(h->device));
+    hipStream_t st = pick_stream(h, stream);
+    RowDst dst{codes, 1, 0, (long)rows, (int)rows};
+    // one "batch row" holding `rows` frames: B=1, F=rows
+    return run_quantize(h, ze_rows, 1, 1, (int)rows, 0, (int)rows, dst, st, nullptr);
+}
+
+static int run_decoder(rca_codec* h, float* zq /*[B][J][F] in act[0]*/, int B, int F, float* pcm_out, hipStream_t st) {
+    const rca_codec_config_t& c = h->cfg;
+    int rc;
+    int cur = 0;
+    int L = F;
+    for (size_t li = 0; li < h->dec.size(); ++li) {
+        const ConvLayer& Ly = h->dec[li];
+        const bool last = li + 1 == h->dec.size();
+        float* x = h->act[cur].as<float>();
+        float* y = last ? pcm_out : h->act[cur ^ 1].as<float>();
+        if ((rc = run_conv(h, Ly, x, y, B, L, last ? 1 : 0, st)) != RCA_OK) return rc;
+        if (Ly.tr) L *= Ly.s;
+        cur ^= 1;
+    }
+    (void)c; (void)zq;
+    return RCA_OK;
+}
+
+static int decoder_workspace(rca_codec* h, int B, int F) {
+    const rca_codec_config_t& c = h->cfg;
+    const int n = c.n_stages;
+    size_t max_elems = (size_t)B * c.codebook_dim * F;
+    long L = F;
+    max_elems = std::max(max_elems, (size_t)B * c.channels[n] * L);
+    for (int i = 0; i < n; ++i) { L *= c.strides[n - 1 - i]; max_elems = std::max(max_elems, (size_t)B * c.channels[n - 1 - i] * L); }
+    int rc;
+    if ((rc = h->act[0].ensure(max_elems * 4)) != RCA_OK) return rc;
+    return h->act[1].ensure(max_elems * 4);
+}
+
+extern "C" int rca_codec_decode_dev(rca_codec_t* h, const int64_t* codes, int32_t B, int32_t F, float* pcm, void* stream) {
+    if (!h || !codes || !pcm || B < 1 || F < 1) return fail(RCA_ERR_ARG, "decode: bad argument (B=%d F=%d)", B, F);
+    RCA_HIP(hipSetDevice(h->device));
+    hipStream_t st = pick_stream(h, stream);
+    int rc;
+    if ((rc = decoder_workspace(h, B, F)) != RCA_OK) return rc;
+    const int J = h->cfg.codebook_dim;
+    float* zq = h->act[0].as<float>();
+    embed_codes_kernel<<<cdiv((long)B * J * F, 256), 256, 0, st>>>(codes, h->cb, zq, B, F, J, h->cfg.codebook_size, h->err_flag);
+    RCA_LAUNCH_CHECK();
+    return run_decoder(h, zq, B, F, pcm, st);
+}
+
+extern "C" int rca_codec_decoder_dev(rca_codec_t* h, const float* zq_bfj, int32_t B, int32_t F, float* pcm, void* stream) {
+    if (!h || !zq_bfj || !pcm || B < 1 || F < 1) return fail(RCA_ERR_ARG, "decoder: bad argument");
+    RCA_HIP(hipSetDevice(h->device));
+    hipStream_t st = pick_stream(h, stream);
+    int rc;
+    if ((rc = decoder_workspace(h, B, F)) != RCA_OK) return rc;
+    const int J = h->cfg.codebook_dim;
+    float* zq = h->act[0].as<float>();
+    transpose_fj_kernel<<<cdiv((long)B * J * F, 256), 256, 0, st>>>(zq_bfj, zq, B, F, J);
+    RCA_LAUNCH_CHECK();
+    return run_decoder(h, zq, B, F, pcm, st);
+}
+
+extern "C" int rca_codec_decode(rca_codec_t* h, const int64_t* codes_host, int32_t B, int32_t F, float* pcm_host) {
+    if (!h || !codes_host || !pcm_host || B < 1 || F < 1) return fail(RCA_ERR_ARG, "decode: bad argument (B=%d F=%d)", B, F);
+    RCA_HIP(hipSetDevice(h->device));
+    int rc;
+    const size_t T = (size_t)F * h->hop;
+    if ((rc = h->io_a.ensure((size_t)B * F * 8)) != RCA_OK) return rc;
+    if ((rc = h->io_b.ensure((size_t)B * T * 4)) != RCA_OK) return rc;
+    RCA_HIP(hipMemcpyAsync(h->io_a.p, codes_host, (size_t)B * F * 8, hipMemcpyHostToDevice, h->stream));
+    if ((rc = rca_codec_decode_dev(h, h->io_a.as<int64_t>(), B, F, h->io_b.as<float>(), h->stream)) != RCA_OK) return rc;
+    int err = 0;
+    RCA_HIP(hipMemcpyAsync(pcm_host, h->io_b.p, (size_t)B * T * 4, hipMemcpyDeviceToHost, h->stream));
+    RCA_HIP(hipMemcpyAsync(&err, h->err_flag, 4, hipMemcpyDeviceToHost, h->stream));
+    RCA_HIP(hipStreamSynchronize(h->stream));
+    if (err) {
+        RCA_HIP(hipMemsetAsync(h->err_flag, 0, 4, h->stream));
+        return fail(RCA_ERR_ARG, "decode: code out of range [0, %d)", h->cfg.codebook_size);
+    }
+    return RCA_OK;
+}
+
+extern "C" int rca_codec_codebook_dev(rca_codec_t* h, const float** out) {
+    if (!h || !out) return fail(RCA_ERR_ARG, "null");
+    *out = h->cb;
+    return RCA_OK;
+}
+extern "C" int rca_codec_codebook(rca_codec_t* h, float* out_host) {
+    if (!h || !out_host) return fail(RCA_ERR_ARG, "null");
+    RCA_HIP(hipSetDevice(h->device));
+    RCA_HIP(hipMemcpy(out_host, h->cb, (size_t)h->cfg.codebook_size * h->cfg.codebook_dim * 4, hipMemcpyDeviceToHost));
+    return RCA_OK;
+}
+
+extern "C" int rca_codec_profile(rca_codec_t* h, int32_t enable) {
+    if (!h) return fail(RCA_ERR_ARG, "null");
+    h->profile = enable != 0;
+    return RCA_OK;
+}
+extern "C" int rca_codec_profile_read(rca_codec_t* h, int32_t kclass, double* total_ms, int64_t* launches, double* flops,
+                                      double* bytes) {
+    if (!h || !total_ms || !launches || !flops || !bytes) return fail(RCA_ERR_ARG, "null");
+    RCA_HIP(hipSetDevice(h->device));
+    double ms = 0, fl = 0, by = 0;
+    int64_t n = 0;
+    std::vector<rca_codec::Prof> keep;
+    for (auto& p : h->prof) {
+        if (p.kclass != kclass) { keep.push_back(p); continue; }
+        RCA_HIP(hipEventSynchronize(p.b));
+        float t = 0;
+        RCA_HIP(hipEventElapsedTime(&t, p.a, p.b));
+        ms += t; fl += p.flops; by += p.bytes; ++n;
+        h->prof_pool.push_back(p);
+    }
+    h->prof.swap(keep);
+    *total_ms = ms; *launches = n; *flops = fl; *bytes = by;
+    return RCA_OK;
+}

@@ -1,0 +1,166 @@
+"""GPU parity tests (MI355X): the HIP codec, called through the C ABI, against the CPU oracle.
+Bit-exact: code ids, every encoder activation, the projected codebook and the decoded PCM."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, bench_signal, rich_signal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip_tiny(tiny_codec):
+    from realtime_codec_agent_amd.codec import HipCodec
+    return HipCodec(*tiny_codec, device=0)
+
+
+@pytest.fixture(scope="module")
+def hip_full(full_codec):
+    from realtime_codec_agent_amd.codec import HipCodec
+    return HipCodec(*full_codec, device=0)
+
+
+def _pair(tag, hip_tiny, hip_full, tiny_oracle, full_oracle):
+    return (hip_tiny, tiny_oracle) if tag == "tiny" else (hip_full, full_oracle)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_codebook_bit_exact(tag, hip_tiny, hip_full, tiny_oracle, full_oracle):
+    hip, oc = _pair(tag, hip_tiny, hip_full, tiny_oracle, full_oracle)
+    assert np.array_equal(hip.codebook(), oc.codebook())
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_encoder_layers_bit_exact(tag, variant, hip_tiny, hip_full, tiny_oracle, full_oracle):
+    hip, oc = _pair(tag, hip_tiny, hip_full, tiny_oracle, full_oracle)
+    hip.set_variant(variant)
+    x = np.stack([bench_signal(6400, 0), rich_signal(6400, 5), rich_signal(6400, 9)])
+    for layer in range(oc.cfg.n_stages + 3):
+        _, want = oc.encode(x, tap_layer=layer)
+        got = hip.encode_tap(x, layer)
+        assert got.shape == want.shape
+        bad = np.flatnonzero(got.ravel() != want.ravel())
+        assert bad.size == 0, f"layer {layer}: {bad.size} mismatches, first at {bad[:5]}, max|d|={np.abs(got - want).max()}"
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_encode_matches_golden_and_oracle(tag, variant, hip_tiny, hip_full, tiny_oracle, full_oracle):
+    hip, oc = _pair(tag, hip_tiny, hip_full, tiny_oracle, full_oracle)
+    hip.set_variant(variant)
+    g = np.load(f"{GOLDEN}/codec_{tag}.npz")
+    pcm = np.stack([bench_signal(32000, 0), rich_signal(32000, 5)])
+    codes = hip.encode(pcm)
+    assert codes.dtype == np.int64 and np.array_equal(codes, g["codes"])
+    assert np.array_equal(hip.encode(rich_signal(4000, 7)[None, :]), g["codes_ragged"])
+    # ragged / edge shapes the reference exercises: one chunk (1600), one frame, < one frame, 10 s probe
+    for T, B in ((1600, 1), (320, 2), (100, 1), (1280, 3), (33000, 1)):
+        x = np.stack([rich_signal(T, 11 + b) for b in range(B)])
+        assert np.array_equal(hip.encode(x), oc.encode(x)), (T, B)
+    if tag == "tiny":
+        x = rich_signal(160000, 3)[None, :]
+        assert np.array_equal(hip.encode(x), oc.encode(x))
+    z = np.zeros((1, 160000), np.float32)  # AudioTokenizer._compute_framerate probe (audio_tokenizer.py:181-187)
+    assert hip.encode(z).shape == (1, 500)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_decode_bit_exact(tag, hip_tiny, hip_full, tiny_oracle, full_oracle):
+    hip, oc = _pair(tag, hip_tiny, hip_full, tiny_oracle, full_oracle)
+    g = np.load(f"{GOLDEN}/codec_{tag}.npz")
+    rec = hip.decode(g["codes"])
+    assert np.array_equal(rec[:, :3200], g["pcm_head"]) and np.array_equal(rec[:, -3200:], g["pcm_tail"])
+    rng = np.random.default_rng(0)
+    for F, B in ((1, 1), (5, 2), (100, 1)):
+        codes = rng.integers(0, oc.cfg.codebook_size, (B, F))
+        want = oc.decode(codes)
+        got = hip.decode(codes)
+        assert np.array_equal(got, want), (F, B, np.abs(got - want).max())
+    assert np.abs(rec).max() <= 1.0
+
+
+def test_decode_rejects_out_of_range(hip_tiny, tiny_codec):
+    from realtime_codec_agent_amd._native import RcaError
+    cfg, _ = tiny_codec
+    with pytest.raises(RcaError):
+        hip_tiny.decode(np.array([[0, cfg.codebook_size]]))
+    with pytest.raises(RcaError):
+        hip_tiny.decode(np.array([[-1]]))
+    # the handle stays usable
+    assert hip_tiny.decode(np.array([[0, 1]])).shape == (1, 640)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_batch_windows_match_streaming_semantics(variant, hip_full, full_oracle):
+    """rca_codec_encode_windows_dev == chunk-by-chunk tokenize_audio semantics (oracle.encode_windows)
+    on 4 s of stereo, for both standard chunk sizes, including the warm-up windows."""
+    import torch
+    hip_full.set_variant(variant)
+    audio = np.stack([bench_signal(64000, 1), rich_signal(64000, 2)])
+    dev = torch.from_numpy(audio).cuda()
+    for chunk in (1600, 1280):
+        n_chunks = 64000 // chunk
+        fpc = hip_full.frames_per_chunk(chunk)
+        out = torch.full((2, n_chunks * fpc), -1, dtype=torch.int64, device="cuda")
+        hip_full.encode_windows_dev(dev.data_ptr(), 2, 64000, chunk, 32000, 16, out.data_ptr(), n_chunks * fpc,
+                                    torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        want = full_oracle.encode_windows(audio, chunk, 32000)
+        got = out.cpu().numpy()
+        assert np.array_equal(got, want), (chunk, int((got != want).sum()))
+
+
+def test_variants_agree_at_bench_batch_size(hip_full):
+    """Size-independent property at the BASELINE batch size (256 windows of 2 s): MFMA kernels and
+    scalar-chain kernels emit identical ids; windows with identical content give identical codes."""
+    import torch
+    x = np.stack([rich_signal(32000, 100 + (i % 7)) for i in range(256)])
+    dev = torch.from_numpy(x).cuda()
+    outs = []
+    for v in (1, 0):
+        hip_full.set_variant(v)
+        codes = torch.empty((256, 100), dtype=torch.int64, device="cuda")
+        hip_full.encode_dev(dev.data_ptr(), 256, 32000, codes.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        outs.append(codes.cpu().numpy())
+    hip_full.set_variant(1)
+    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0][0], outs[0][7]) and not np.array_equal(outs[0][0], outs[0][1])
+    assert outs[0].min() >= 0 and outs[0].max() < 131072
+
+
+def test_audio_tokenizer_streaming_on_gpu(full_codec, full_oracle):
+    """AudioTokenizer over MagiCodecHIP: chunked tokenize/detokenize equals the oracle driven the same way."""
+    import torch
+    from realtime_codec_agent_amd.audio_tokenizer import AudioTokenizer
+    from realtime_codec_agent_amd.codec import MagiCodecHIP
+    from realtime_codec_agent_amd.codec_chars import chars_to_codes
+    cfg, w = full_codec
+    model = MagiCodecHIP(cfg, w, device="cuda:0")
+    tok = AudioTokenizer(codec_model=model, device="cuda:0")
+    assert tok.framerate == 50.0 and tok.codebook_size == 131072 and tok.sampling_rate == 16000
+    sig = rich_signal(48000, 21)
+    s = ""
+    pcm_chunks = []
+    for i in range(0, 48000, 1600):
+        cs = tok.tokenize_audio(sig[i:i + 1600])
+        s += cs
+        (sr, pcm), _, _ = tok.detokenize_audio(cs, preroll_samples=320)
+        pcm_chunks.append(pcm)
+    got = chars_to_codes(s, 1, cfg.codebook_size)[0]
+    want = full_oracle.encode_windows(sig[None, :], 1600, 32000)[0]
+    assert np.array_equal(got, want)
+    # last detokenize call: 100-code context decoded, last 1600+320 samples returned
+    ctx_codes = want[-100:][None, :]
+    want_pcm = full_oracle.decode(ctx_codes)[0, -1920:]
+    assert np.array_equal(pcm_chunks[-1], want_pcm)
+    # the three-call path of the reference (encoder / quantizer.inference / decoder) gives the same ids
+    x = torch.from_numpy(sig[None, :32000]).cuda()
+    ze = model.encoder(model.pad_audio(x))
+    zq, idx = model.quantizer.inference(ze)
+    assert np.array_equal(idx.cpu().numpy(), full_oracle.encode(sig[None, :32000]))
+    rec = model.decoder(zq)
+    assert np.array_equal(rec.cpu().numpy()[:, 0], full_oracle.decode(idx.cpu().numpy()))
+    emb = tok.get_codec_embeddings()
+    assert np.array_equal(emb.cpu().numpy(), full_oracle.codebook())
