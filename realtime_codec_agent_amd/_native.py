@@ -137,6 +137,10 @@ def lib():
             f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
             "There is no CPU fallback for the product path."
         )
+    # torch bundles its own libamdhip64.so.7; whichever copy of that soname is loaded first serves the
+    # whole process.  Load torch's first so its allocator/streams and our kernels share ONE runtime
+    # (loading the system copy first leaves torch unable to see the GPU).
+    import torch  # noqa: F401
     try:
         _lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
