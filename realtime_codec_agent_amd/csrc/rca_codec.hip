@@ -137,47 +137,93 @@ __global__ __launch_bounds__(256) void convtr1d_chain_kernel(const float* __rest
 }
 
 // ----------------------------------------------------------------- implicit-GEMM conv on f32 MFMA
-// GEMM view: M = Cout, N = B*Lout (columns flattened over windows), K = Cin*KS (ci-major).
-// Workgroup = 4 waves; tile = (GM*WM*32) channels x (GN*WN*32) columns.  K is walked in chunks of
-// 32: the im2col slice [32][NT] of the (pre-activated, zero-padded) input is staged into LDS by
-// coalesced-along-t global loads, double buffered; each wave then issues v_mfma_f32_32x32x2_f32 in
-// ascending k into WM x WN accumulator tiles.  A operands (weights) come pre-packed in fragment
-// order from L2: wp[co_tile][kquad][lane][4], element e of quad q = W[co_tile*32 + (lane&31)]
-// [2*(4q+e) + (lane>>5)], so every wave load is 1 KiB contiguous.
-template <int KS, int S, int WM, int WN, int GM, int GN>
+// GEMM view: M = Cout, N = B*Lout (columns flattened over windows, so Lout = 100 wastes nothing),
+// K = Cin*KS walked ci-major / tap-minor in chunks of CIC input channels.
+//
+// LDS sliding window: for every input channel of the chunk the workgroup stages the contiguous
+// input span of its NT columns ONCE (coalesced loads, LeakyReLU fused), de-interleaved by stride
+// phase:  xs[ci][p][slot] = act(x[b][ci][t*S + p]) for the column (b,t) in `slot` (one halo slot on
+// each side).  Tap kk of column j is then xs[ci][(kk-padL) mod S][j + floor((kk-padL)/S)], i.e.
+// consecutive lanes read consecutive LDS words (no bank conflicts, no im2col copy).  Reads that
+// would cross a window edge are zeroed by a per-lane bit mask (fma(w, 0, acc) == acc, the oracle
+// skips those taps).  Each wave issues v_mfma_f32_32x32x2_f32 in ascending k into WM x WN
+// accumulator tiles; A operands (weights) come pre-packed in fragment order from L2
+// (wp[co_tile][kquad][lane][4]) and are prefetched one chunk ahead.
+template <int S>
+struct ConvLds {
+    // row stride U (in floats) for NT columns: NT + 2 halo slots, padded so that the S phase rows a
+    // staging wave writes together fall on different banks
+    static constexpr int want = (S == 8) ? 4 : (S == 4) ? 8 : (S == 2) ? 16 : (S == 5) ? 6 : 2;
+    static constexpr int stride(int NT) {
+        int u = NT + 2;
+        while ((u % 32) != want % 32) ++u;
+        return u;
+    }
+};
+
+template <int KS, int S, int CIC, int WM, int WN, int GM, int GN>
 __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                           const float* __restrict__ bias, float* __restrict__ y,
-                                                          int Cin, int Lin, int Cout, int Lout, long Ncols, int K,
-                                                          int Kpad, int pre, float slope) {
-    constexpr int KC = 32;
+                                                          int Cin, int Lin, int Cout, int Lout, long Ncols, int nchunks,
+                                                          int pre, float slope) {
     constexpr int MT = GM * WM * 32;
     constexpr int NT = GN * WN * 32;
-    constexpr int ROWSTEP = 256 / NT;  // staging: threads cover ROWSTEP k-rows x NT columns per pass
-    constexpr int NST = KC / ROWSTEP;  // staged elements per thread per chunk
-    static_assert(256 % NT == 0, "NT must divide 256");
+    constexpr int U = ConvLds<S>::stride(NT);
+    constexpr int KPC = CIC * KS / 2;      // k pairs per chunk
+    constexpr int QPC = KPC / 4;           // float4 weight quads per chunk per co-tile
+    constexpr int E = (NT + 2) * S;        // staged elements per input channel
+    constexpr int RE = (E + 255) / 256;    // per thread
     constexpr int padL = (KS - S + 1) / 2;
+    constexpr int BUF = CIC * S * U;
+    static_assert((CIC * KS) % 8 == 0, "chunk must hold whole weight quads");
 
-    extern __shared__ __attribute__((aligned(16))) float xs[];  // [2][KC][NT]
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [2][CIC][S][U]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    const int half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int gm = wave / GN, gn = wave % GN;
     const long n0 = (long)blockIdx.x * NT;
     const int co0 = blockIdx.y * MT;
 
-    // staging role: fixed column, rotating k rows
-    const int scol = tid % NT;
-    const int srow0 = tid / NT;
-    const long sn = n0 + scol;
-    const bool svalid = sn < Ncols;
-    const int sb = svalid ? (int)(sn / Lout) : 0;
-    const int st = svalid ? (int)(sn - (long)sb * Lout) : 0;
-    const float* sx = x + (long)sb * Cin * Lin;
-    const int si0 = st * S - padL;
-
-    const int nchunks = Kpad / KC;
-    const int kquads = Kpad / 8;
+    // ---- staging role: element e -> (slot, phase); fixed per thread, channel added per load
+    long s_goff[RE];   // offset of x[b][0][t*S + p]
+    int s_loff[RE];    // p*U + slot, or -1
+    bool s_ok[RE];
+#pragma unroll
+    for (int r = 0; r < RE; ++r) {
+        const int e = tid + 256 * r;
+        const int slot = e / S, p = e - slot * S;
+        const long n = n0 - 1 + slot;
+        s_loff[r] = e < E ? p * U + slot : -1;
+        s_ok[r] = e < E && n >= 0 && n < Ncols;
+        const long nn = s_ok[r] ? n : 0;
+        const long b = nn / Lout;
+        const int t = (int)(nn - b * Lout);
+        s_goff[r] = b * Cin * (long)Lin + (long)t * S + p;
+    }
+    // ---- B-read role: per k-pair LDS offset and edge masks for this lane's half
+    int b_off[KPC];
+    unsigned m_first = 0, m_last = 0;  // bit kp: the read reaches into the previous / next column
+#pragma unroll
+    for (int kp = 0; kp < KPC; ++kp) {
+        const int kl = 2 * kp + half;
+        const int ci = kl / KS, kk = kl - ci * KS;
+        const int d = kk - padL;
+        const int q = (d >= 0) ? d / S : -((-d + S - 1) / S);
+        const int p = d - q * S;
+        b_off[kp] = (ci * S + p) * U + 1 + q + gn * WN * 32 + (lane & 31);
+        if (q < 0) m_first |= 1u << kp;
+        if (q > 0) m_last |= 1u << kp;
+    }
+    unsigned zmask[WN];
+#pragma unroll
+    for (int wn = 0; wn < WN; ++wn) {
+        const long n = n0 + (gn * WN + wn) * 32 + (lane & 31);
+        const int t = (int)(n % Lout);
+        zmask[wn] = (t == 0 ? m_first : 0u) | (t == Lout - 1 ? m_last : 0u);
+    }
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -185,71 +231,86 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const float* __restric
         const int cot = co0 + (gm * WM + wm) * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int co = cot + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int co = cot + (r & 3) + 8 * (r >> 2) + 4 * half;
             const float bv = co < Cout ? bias[co] : 0.0f;
 #pragma unroll
             for (int wn = 0; wn < WN; ++wn) acc[wm][wn][r] = bv;
         }
     }
 
-    float sreg[NST];
+    float sreg[CIC][RE];
     auto stage_load = [&](int c) {
 #pragma unroll
-        for (int j = 0; j < NST; ++j) {
-            const int kg = c * KC + srow0 + j * ROWSTEP;
-            const int ci = kg / KS;
-            const int kk = kg - ci * KS;
-            const int i = si0 + kk;
-            float v = 0.0f;
-            if (svalid && kg < K && i >= 0 && i < Lin) {
-                v = sx[(long)ci * Lin + i];
-                if (pre) v = lrelu(v, slope);
+        for (int cl = 0; cl < CIC; ++cl) {
+            const int ci = c * CIC + cl;
+#pragma unroll
+            for (int r = 0; r < RE; ++r) {
+                float v = 0.0f;
+                if (s_ok[r] && ci < Cin) {
+                    v = x[s_goff[r] + (long)ci * Lin];
+                    if (pre) v = lrelu(v, slope);
+                }
+                sreg[cl][r] = v;
             }
-            sreg[j] = v;
         }
     };
     auto stage_write = [&](int buf) {
-        float* dst = xs + buf * KC * NT;
+        float* dst = xs + buf * BUF;
 #pragma unroll
-        for (int j = 0; j < NST; ++j) dst[(srow0 + j * ROWSTEP) * NT + scol] = sreg[j];
+        for (int cl = 0; cl < CIC; ++cl)
+#pragma unroll
+            for (int r = 0; r < RE; ++r)
+                if (s_loff[r] >= 0) dst[cl * S * U + s_loff[r]] = sreg[cl][r];
     };
 
-    // weight fragments for one chunk: 4 quads x WM tiles
-    float4 aw[WM][4];
-    auto load_w = [&](int c) {
+    const long kquads = (long)nchunks * QPC;
+    auto load_w = [&](float4 (&a)[WM][QPC], int c) {
 #pragma unroll
         for (int wm = 0; wm < WM; ++wm) {
             const int cot = blockIdx.y * (GM * WM) + gm * WM + wm;
-            const float4* p = reinterpret_cast<const float4*>(wp) + ((long)cot * kquads + (long)c * 4) * 64 + lane;
+            const float4* p = reinterpret_cast<const float4*>(wp) + ((long)cot * kquads + (long)c * QPC) * 64 + lane;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) aw[wm][q] = p[q * 64];
+            for (int q = 0; q < QPC; ++q) a[wm][q] = p[q * 64];
+        }
+    };
+    auto compute = [&](const float4 (&a)[WM][QPC], int buf) {
+        const float* xb = xs + buf * BUF;
+#pragma unroll
+        for (int kp = 0; kp < KPC; ++kp) {
+            float bfr[WN];
+#pragma unroll
+            for (int wn = 0; wn < WN; ++wn) {
+                const float v = xb[b_off[kp] + wn * 32];
+                bfr[wn] = ((zmask[wn] >> kp) & 1u) ? 0.0f : v;
+            }
+#pragma unroll
+            for (int wm = 0; wm < WM; ++wm) {
+                const float4 q4 = a[wm][kp >> 2];
+                const float av = (kp & 3) == 0 ? q4.x : (kp & 3) == 1 ? q4.y : (kp & 3) == 2 ? q4.z : q4.w;
+#pragma unroll
+                for (int wn = 0; wn < WN; ++wn)
+                    acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bfr[wn], acc[wm][wn], 0, 0, 0);
+            }
         }
     };
 
+    float4 a0[WM][QPC], a1[WM][QPC];
     stage_load(0);
+    load_w(a0, 0);
     stage_write(0);
     __syncthreads();
-
-    for (int c = 0; c < nchunks; ++c) {
-        const bool more = (c + 1) < nchunks;
-        load_w(c);
-        if (more) stage_load(c + 1);
-        const float* xb = xs + (c & 1) * KC * NT + (lane >> 5) * NT + gn * WN * 32 + (lane & 31);
-#pragma unroll
-        for (int kp = 0; kp < 16; ++kp) {
-            float bfr[WN];
-#pragma unroll
-            for (int wn = 0; wn < WN; ++wn) bfr[wn] = xb[kp * 2 * NT + wn * 32];
-#pragma unroll
-            for (int wm = 0; wm < WM; ++wm) {
-                const float4 q4 = aw[wm][kp >> 2];
-                const float a = (kp & 3) == 0 ? q4.x : (kp & 3) == 1 ? q4.y : (kp & 3) == 2 ? q4.z : q4.w;
-#pragma unroll
-                for (int wn = 0; wn < WN; ++wn)
-                    acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bfr[wn], acc[wm][wn], 0, 0, 0);
-            }
-        }
-        if (more) stage_write((c + 1) & 1);
+    for (int c = 0; c < nchunks; c += 2) {
+        // even chunk: compute from a0 / buffer 0 while chunk c+1 streams in
+        const bool more1 = (c + 1) < nchunks;
+        if (more1) { load_w(a1, c + 1); stage_load(c + 1); }
+        compute(a0, 0);
+        if (more1) stage_write(1);
+        __syncthreads();
+        if (!more1) break;
+        const bool more2 = (c + 2) < nchunks;
+        if (more2) { load_w(a0, c + 2); stage_load(c + 2); }
+        compute(a1, 1);
+        if (more2) stage_write(0);
         __syncthreads();
     }
 
@@ -258,15 +319,15 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const float* __restric
     for (int wn = 0; wn < WN; ++wn) {
         const long n = n0 + (gn * WN + wn) * 32 + (lane & 31);
         if (n >= Ncols) continue;
-        const int b = (int)(n / Lout);
-        const int t = (int)(n - (long)b * Lout);
-        float* yb = y + (long)b * Cout * Lout + t;
+        const long b = n / Lout;
+        const int t = (int)(n - b * Lout);
+        float* yb = y + b * Cout * (long)Lout + t;
 #pragma unroll
         for (int wm = 0; wm < WM; ++wm) {
             const int cot = co0 + (gm * WM + wm) * 32;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = cot + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int co = cot + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (co < Cout) yb[(long)co * Lout] = acc[wm][wn][r];
             }
         }
@@ -519,8 +580,18 @@ struct ConvLayer {
     float* w = nullptr;     // original layout
     float* b = nullptr;
     float* wp = nullptr;    // MFMA-packed (encoder non-transposed layers with cin*k >= 32)
-    int K = 0, Kpad = 0, cout_pad = 0;
+    int K = 0, Kpad = 0, cout_pad = 0, nchunks = 0;
 };
+
+// input channels per K chunk of the MFMA conv, by (kernel size, stride)
+static int conv_cic(int k, int s) {
+    if (k == 4 && s == 2) return 8;
+    if (k == 8 && s == 4) return 4;
+    if (k == 10 && s == 5) return 4;
+    if (k == 16 && s == 8) return 2;
+    if (k == 3 && s == 1) return 16;
+    return 0;
+}
 
 struct rca_codec {
     rca_codec_config_t cfg;
@@ -533,6 +604,9 @@ struct rca_codec {
     float *cb = nullptr, *hc = nullptr, *cbp = nullptr;
     DevBuf act[2], zbuf, keys, io_a, io_b;
     int* err_flag = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool last_stream_valid = false;
+    hipEvent_t xev = nullptr;
     // bench profiling (rca_codec_profile): event pairs around profiled launches
     struct Prof { hipEvent_t a, b; int kclass; double flops, bytes; };
     bool profile = false;
@@ -569,7 +643,9 @@ static int upload(const rca_tensor_t* ts, int n, const std::string& name, long n
 // pack W[cout][K] into MFMA A-fragment order, zero padded to cout_pad x Kpad
 static int pack_weights(const float* w_host, ConvLayer& L) {
     L.K = L.cin * L.k;
-    L.Kpad = (L.K + 31) / 32 * 32;
+    const int cic = conv_cic(L.k, L.s);
+    L.nchunks = (L.cin + cic - 1) / cic;
+    L.Kpad = L.nchunks * cic * L.k;
     L.cout_pad = (L.cout + 127) / 128 * 128;  // whole number of the largest workgroup tile
     const long n = (long)(L.cout_pad / 32) * (L.Kpad / 8) * 64 * 4;
     std::vector<float> p((size_t)n, 0.0f);
@@ -615,6 +691,7 @@ extern "C" int rca_codec_destroy(rca_codec_t* h) {
     h->act[0].release(); h->act[1].release(); h->zbuf.release(); h->keys.release(); h->io_a.release(); h->io_b.release();
     for (auto* v : {&h->prof, &h->prof_pool})
         for (auto& p : *v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    if (h->xev) (void)hipEventDestroy(h->xev);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return RCA_OK;
@@ -713,29 +790,26 @@ extern "C" int rca_codec_sync(rca_codec_t* h) {
     return RCA_OK;
 }
 
-template <int KS, int S>
+template <int KS, int S, int CIC, int WM, int WN, int GM, int GN>
+static void launch_conv_cfg(const ConvLayer& L, const float* x, float* y, int Lin, int Lout, long Ncols, float slope, hipStream_t st) {
+    constexpr int NT = GN * WN * 32, MT = GM * WM * 32;
+    constexpr int lds = 2 * CIC * S * ConvLds<S>::stride(NT) * 4;
+    static_assert(lds <= 65536, "LDS budget");
+    dim3 grid(cdiv(Ncols, NT), cdiv(L.cout, MT));
+    conv1d_mfma_kernel<KS, S, CIC, WM, WN, GM, GN><<<grid, 256, lds, st>>>(x, L.wp, L.b, y, L.cin, Lin, L.cout, Lout, Ncols, L.nchunks, L.pre, slope);
+}
+
+template <int KS, int S, int CIC>
 static int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B, int Lin, int Lout, float slope, hipStream_t st) {
     const long Ncols = (long)B * Lout;
-    // tile choice: big tiles when they still fill the chip, otherwise 64x64 tiles (4x the workgroups)
-    const long wg_big = (long)cdiv(Ncols, 128) * cdiv(L.cout, 128);
+    // tile choice: big tiles while they still fill the chip, otherwise 64x64 tiles (4x the workgroups)
     if (L.cout <= 64) {
-        if ((long)cdiv(Ncols, 256) >= 512) {
-            constexpr int NT = 256;
-            dim3 grid(cdiv(Ncols, NT), cdiv(L.cout, 64));
-            conv1d_mfma_kernel<KS, S, 2, 2, 1, 4><<<grid, 256, 2 * 32 * NT * 4, st>>>(x, L.wp, L.b, y, L.cin, Lin, L.cout, Lout, Ncols, L.K, L.Kpad, L.pre, slope);
-        } else {
-            constexpr int NT = 64;
-            dim3 grid(cdiv(Ncols, NT), cdiv(L.cout, 64));
-            conv1d_mfma_kernel<KS, S, 1, 1, 2, 2><<<grid, 256, 2 * 32 * NT * 4, st>>>(x, L.wp, L.b, y, L.cin, Lin, L.cout, Lout, Ncols, L.K, L.Kpad, L.pre, slope);
-        }
-    } else if (wg_big >= 512) {
-        constexpr int NT = 128;
-        dim3 grid(cdiv(Ncols, NT), cdiv(L.cout, 128));
-        conv1d_mfma_kernel<KS, S, 2, 2, 2, 2><<<grid, 256, 2 * 32 * NT * 4, st>>>(x, L.wp, L.b, y, L.cin, Lin, L.cout, Lout, Ncols, L.K, L.Kpad, L.pre, slope);
+        if ((long)cdiv(Ncols, 256) >= 256) launch_conv_cfg<KS, S, CIC, 2, 2, 1, 4>(L, x, y, Lin, Lout, Ncols, slope, st);
+        else launch_conv_cfg<KS, S, CIC, 1, 1, 2, 2>(L, x, y, Lin, Lout, Ncols, slope, st);
+    } else if ((long)cdiv(Ncols, 128) * cdiv(L.cout, 128) >= 256) {
+        launch_conv_cfg<KS, S, CIC, 2, 2, 2, 2>(L, x, y, Lin, Lout, Ncols, slope, st);
     } else {
-        constexpr int NT = 64;
-        dim3 grid(cdiv(Ncols, NT), cdiv(L.cout, 64));
-        conv1d_mfma_kernel<KS, S, 1, 1, 2, 2><<<grid, 256, 2 * 32 * NT * 4, st>>>(x, L.wp, L.b, y, L.cin, Lin, L.cout, Lout, Ncols, L.K, L.Kpad, L.pre, slope);
+        launch_conv_cfg<KS, S, CIC, 1, 1, 2, 2>(L, x, y, Lin, Lout, Ncols, slope, st);
     }
     RCA_LAUNCH_CHECK();
     return RCA_OK;
@@ -754,11 +828,11 @@ static int run_conv(rca_codec* h, const ConvLayer& L, const float* x, float* y, 
     const double cbytes = 4.0 * ((double)B * L.cin * Lin + (double)B * L.cout * Lout + (double)L.cin * L.k * L.cout);
     if (h->variant == 1 && L.wp && !clamp_out) {
         ProfScope ps(h, st, 0, cflops, cbytes);
-        if (L.k == 4 && L.s == 2) return launch_conv_mfma<4, 2>(L, x, y, B, Lin, Lout, slope, st);
-        if (L.k == 8 && L.s == 4) return launch_conv_mfma<8, 4>(L, x, y, B, Lin, Lout, slope, st);
-        if (L.k == 10 && L.s == 5) return launch_conv_mfma<10, 5>(L, x, y, B, Lin, Lout, slope, st);
-        if (L.k == 16 && L.s == 8) return launch_conv_mfma<16, 8>(L, x, y, B, Lin, Lout, slope, st);
-        if (L.k == 3 && L.s == 1) return launch_conv_mfma<3, 1>(L, x, y, B, Lin, Lout, slope, st);
+        if (L.k == 4 && L.s == 2) return launch_conv_mfma<4, 2, 8>(L, x, y, B, Lin, Lout, slope, st);
+        if (L.k == 8 && L.s == 4) return launch_conv_mfma<8, 4, 4>(L, x, y, B, Lin, Lout, slope, st);
+        if (L.k == 10 && L.s == 5) return launch_conv_mfma<10, 5, 4>(L, x, y, B, Lin, Lout, slope, st);
+        if (L.k == 16 && L.s == 8) return launch_conv_mfma<16, 8, 2>(L, x, y, B, Lin, Lout, slope, st);
+        if (L.k == 3 && L.s == 1) return launch_conv_mfma<3, 1, 16>(L, x, y, B, Lin, Lout, slope, st);
     }
     const long total = (long)B * L.cout * Lout;
     ProfScope ps(h, st, 3, cflops, cbytes);
@@ -858,7 +932,20 @@ static int run_quantize(rca_codec* h, const float* ze, int ze_is_rows, int B, in
     return RCA_OK;
 }
 
-static hipStream_t pick_stream(rca_codec* h, void* stream) { return stream ? (hipStream_t)stream : h->stream; }
+// `_dev` entry points run on the caller's stream (NULL = the legacy default stream, as everywhere in
+// HIP).  The handle's workspace is shared by all calls, so when the stream changes between two calls
+// the new stream first waits for the work already queued on the previous one.
+static hipStream_t pick_stream(rca_codec* h, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (h->last_stream_valid && h->last_stream != st) {
+        if (!h->xev) (void)hipEventCreateWithFlags(&h->xev, hipEventDisableTiming);
+        (void)hipEventRecord(h->xev, h->last_stream);
+        (void)hipStreamWaitEvent(st, h->xev, 0);
+    }
+    h->last_stream = st;
+    h->last_stream_valid = true;
+    return st;
+}
 
 extern "C" int rca_codec_encode_dev(rca_codec_t* h, const float* pcm, int32_t B, int32_t T, int64_t* codes, void* stream) {
     if (!h || !pcm || !codes || B < 1 || T < 1) return fail(RCA_ERR_ARG, "encode: bad argument (B=%d T=%d)", B, T);
@@ -897,6 +984,7 @@ extern "C" int rca_codec_encode_tap(rca_codec_t* h, const float* pcm_host, int32
     RCA_HIP(hipMemcpyAsync(h->io_a.p, pcm_host, (size_t)B * T * 4, hipMemcpyHostToDevice, h->stream));
     RowSrc src{h->io_a.as<float>(), B, (long)T, 0, T};
     float* ze; int F;
+    (void)pick_stream(h, h->stream);
     // element-count check
     {
         const int Fx = (T + h->hop - 1) / h->hop;
