@@ -229,6 +229,9 @@ int rca_lm_step(rca_lm_t* h, const int32_t* ids, int32_t n, int32_t* token);
 /* softmax(logits)[token] of the last position, reduced on the device
  * (measure_event_prob, realtime_agent_v2.py:448-452) */
 int rca_lm_token_probs(rca_lm_t* h, const int32_t* token_ids, int32_t n, float* probs_out);
+/* enable / disable hipGraph replay of the steady-state step (eager launches otherwise); tests and
+ * bench compare the two */
+int rca_lm_set_graphs(rca_lm_t* h, int32_t enable);
 /* synchronise the handle's stream (timing) */
 int rca_lm_sync(rca_lm_t* h);
 int rca_codec_sync(rca_codec_t* h);

@@ -11,8 +11,8 @@ LIB_PATH = os.path.join(_DIR, "librca_oracle.so")
 
 
 def build(force: bool = False) -> str:
-    """Compile codec_oracle.c -> librca_oracle.so (gcc, seconds)."""
-    src = os.path.join(_DIR, "codec_oracle.c")
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+    """Compile the C restatements -> librca_oracle.so (gcc, seconds)."""
+    srcs = [os.path.join(_DIR, f) for f in ("codec_oracle.c", "sampler_oracle.c")]
+    if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(LIB_PATH) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _DIR, "-B", "librca_oracle.so"], stdout=subprocess.DEVNULL)
     return LIB_PATH

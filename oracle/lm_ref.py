@@ -1,0 +1,199 @@
+"""Plain PyTorch fp32 restatement of the LM step (TEST INFRASTRUCTURE ONLY).
+
+Follows the arithmetic of the reference's training-time twin, CodecLlamaForCausalLM
+(realtime_codec_agent/codec_llama.py:93-164), i.e. transformers' Llama decoder stack:
+RMSNorm -> q/k/v proj -> RoPE (rotate_half convention, optional llama3 frequency scaling) ->
+causal GQA attention over a KV cache -> o_proj + residual -> RMSNorm -> SwiGLU MLP + residual ->
+final RMSNorm -> lm_head.  After persist_codec_embeddings (codec_llama.py:178-206) the input
+embedding is a plain table lookup, which is the deployed form restated here.
+
+PINNED: tests/golden/lm_tiny.npz holds logits produced by the reference's own classes
+(tests/golden/make_lm_golden.py); test_lm_cpu.py checks this restatement against them.
+
+`kv_dtype=torch.float16` reproduces what the HIP path stores in its cache (llama.cpp's default cache
+type); `kv_dtype=None` keeps K/V in fp32 as HF does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import build
+
+
+def inv_freq(cfg) -> torch.Tensor:
+    dim = cfg.head_dim
+    inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, dim, 2, dtype=torch.int64).to(dtype=torch.float) / dim))
+    if cfg.rope_scaling == "llama3":
+        factor, low, high, old = cfg.rope_factor, cfg.rope_low_freq_factor, cfg.rope_high_freq_factor, cfg.rope_orig_ctx
+        low_wl, high_wl = old / low, old / high
+        wl = 2 * math.pi / inv
+        inv_l = torch.where(wl > low_wl, inv / factor, inv)
+        smooth = (old / wl - low) / (high - low)
+        smoothed = (1 - smooth) * inv_l / factor + smooth * inv_l
+        medium = ~(wl < high_wl) * ~(wl > low_wl)
+        inv = torch.where(medium, smoothed, inv_l)
+    return inv.float()
+
+
+def _rotate_half(x):
+    x1, x2 = x[..., : x.shape[-1] // 2], x[..., x.shape[-1] // 2:]
+    return torch.cat((-x2, x1), dim=-1)
+
+
+class LMRef:
+    def __init__(self, cfg, weights: Dict[str, np.ndarray], kv_dtype: Optional[torch.dtype] = torch.float16):
+        """weights: name -> float32 array, or uint16 array of bf16 bit patterns."""
+        self.cfg = cfg
+        self.kv_dtype = kv_dtype
+        self.w = {}
+        for k, v in weights.items():
+            if v.dtype == np.uint16:
+                v = (v.astype(np.uint32) << 16).view(np.float32)
+            self.w[k] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+        self.inv_freq = inv_freq(cfg)
+        self.reset()
+
+    def reset(self):
+        self.n_tokens = 0
+        self.k: List[Optional[torch.Tensor]] = [None] * self.cfg.n_layers
+        self.v: List[Optional[torch.Tensor]] = [None] * self.cfg.n_layers
+
+    def set_n_tokens(self, n: int):
+        """KV rollback: keep the first n cached positions."""
+        self.n_tokens = n
+        for l in range(self.cfg.n_layers):
+            if self.k[l] is not None:
+                self.k[l] = self.k[l][:, :n]
+                self.v[l] = self.v[l][:, :n]
+
+    def _norm(self, x, w):
+        var = x.pow(2).mean(-1, keepdim=True)
+        return w * (x * torch.rsqrt(var + self.cfg.rms_eps))
+
+    @torch.no_grad()
+    def eval(self, ids) -> torch.Tensor:
+        """Append ids at position n_tokens; returns logits [len(ids), V] (fp32)."""
+        c = self.cfg
+        ids = torch.as_tensor(list(ids), dtype=torch.long)
+        S = ids.shape[0]
+        pos = torch.arange(self.n_tokens, self.n_tokens + S)
+        freqs = pos[:, None].float() * self.inv_freq[None, :]
+        emb = torch.cat((freqs, freqs), dim=-1)
+        cos, sin = emb.cos()[None], emb.sin()[None]  # [1,S,hd]
+        x = self.w["model.embed_tokens.weight"][ids]  # [S,H]
+        G = c.n_heads // c.n_kv_heads
+        for l in range(c.n_layers):
+            p = f"model.layers.{l}."
+            h = self._norm(x, self.w[p + "input_layernorm.weight"])
+            q = (h @ self.w[p + "self_attn.q_proj.weight"].T).view(S, c.n_heads, c.head_dim).transpose(0, 1)
+            k = (h @ self.w[p + "self_attn.k_proj.weight"].T).view(S, c.n_kv_heads, c.head_dim).transpose(0, 1)
+            v = (h @ self.w[p + "self_attn.v_proj.weight"].T).view(S, c.n_kv_heads, c.head_dim).transpose(0, 1)
+            q = q * cos + _rotate_half(q) * sin
+            k = k * cos + _rotate_half(k) * sin
+            if self.kv_dtype is not None:
+                k, v = k.to(self.kv_dtype).float(), v.to(self.kv_dtype).float()
+            if self.k[l] is not None and self.n_tokens > 0:
+                k = torch.cat((self.k[l][:, : self.n_tokens], k), dim=1)
+                v = torch.cat((self.v[l][:, : self.n_tokens], v), dim=1)
+            self.k[l], self.v[l] = k, v
+            kk = k.repeat_interleave(G, dim=0)
+            vv = v.repeat_interleave(G, dim=0)
+            att = (q @ kk.transpose(1, 2)) * (c.head_dim ** -0.5)  # [nh,S,T]
+            T = kk.shape[1]
+            mask = torch.arange(T)[None, :] > (self.n_tokens + torch.arange(S))[:, None]
+            att = att.masked_fill(mask[None], float("-inf")).softmax(-1)
+            o = (att @ vv).transpose(0, 1).reshape(S, c.n_heads * c.head_dim)
+            x = x + o @ self.w[p + "self_attn.o_proj.weight"].T
+            h = self._norm(x, self.w[p + "post_attention_layernorm.weight"])
+            g = h @ self.w[p + "mlp.gate_proj.weight"].T
+            u = h @ self.w[p + "mlp.up_proj.weight"].T
+            x = x + (torch.nn.functional.silu(g) * u) @ self.w[p + "mlp.down_proj.weight"].T
+        x = self._norm(x, self.w["model.norm.weight"])
+        self.n_tokens += S
+        return x @ self.w["lm_head.weight"].T
+
+
+# ------------------------------------------------------------------ random-init weights (bench configs)
+_M64 = (1 << 64) - 1
+
+
+def _splitmix_np(seed: int, ctr: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = (np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + ctr * np.uint64(0xBF58476D1CE4E5B9) + np.uint64(0x94D049BB133111EB))
+        z ^= z >> np.uint64(30)
+        z *= np.uint64(0xBF58476D1CE4E5B9)
+        z ^= z >> np.uint64(27)
+        z *= np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+    return z
+
+
+def random_bf16_tensor(seed: int, tensor_id: int, n: int, init_std: float) -> np.ndarray:
+    """Same values as lm_random_bf16_kernel (rca_lm.hip): Irwin-Hall sum of four 16-bit uniforms of a
+    splitmix64 hash, scaled in float32, rounded to bf16 (RNE).  Returns uint16 bf16 bits."""
+    with np.errstate(over="ignore"):
+        s = np.uint64(seed) ^ (np.uint64(tensor_id) * np.uint64(0xD6E8FEB86659FD93))
+    z = _splitmix_np(int(s), np.arange(n, dtype=np.uint64))
+    m = np.uint64(0xFFFF)
+    total = ((z & m) + ((z >> np.uint64(16)) & m) + ((z >> np.uint64(32)) & m) + ((z >> np.uint64(48)) & m)).astype(np.int64)
+    scale = np.float32(np.float32(init_std) * np.float32(1.7320508) / np.float32(65535.0))
+    f = (total - 131070).astype(np.float32) * scale
+    u = f.view(np.uint32)
+    return ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)).astype(np.uint16)
+
+
+def random_weights(cfg, seed: int, init_std: float = 0.02) -> Dict[str, np.ndarray]:
+    """HF-named state dict equal to what rca_lm_create_random generates (fused qkv / interleaved
+    gate-up tensors are split back into their HF parts)."""
+    H, V, F = cfg.hidden, cfg.vocab_size, cfg.ffn
+    Q, KVD = cfg.n_heads * cfg.head_dim, cfg.n_kv_heads * cfg.head_dim
+    w = {
+        "model.embed_tokens.weight": random_bf16_tensor(seed, 1, V * H, init_std).reshape(V, H),
+        "lm_head.weight": random_bf16_tensor(seed, 2, V * H, init_std).reshape(V, H),
+        "model.norm.weight": np.ones(H, np.float32),
+    }
+    for l in range(cfg.n_layers):
+        p = f"model.layers.{l}."
+        base = 10 * (l + 1)
+        qkv = random_bf16_tensor(seed, base + 3, (Q + 2 * KVD) * H, init_std).reshape(Q + 2 * KVD, H)
+        w[p + "self_attn.q_proj.weight"], w[p + "self_attn.k_proj.weight"], w[p + "self_attn.v_proj.weight"] = qkv[:Q], qkv[Q:Q + KVD], qkv[Q + KVD:]
+        w[p + "self_attn.o_proj.weight"] = random_bf16_tensor(seed, base + 4, H * Q, init_std).reshape(H, Q)
+        gu = random_bf16_tensor(seed, base + 5, 2 * F * H, init_std).reshape(F, 2, H)
+        w[p + "mlp.gate_proj.weight"], w[p + "mlp.up_proj.weight"] = np.ascontiguousarray(gu[:, 0]), np.ascontiguousarray(gu[:, 1])
+        w[p + "mlp.down_proj.weight"] = random_bf16_tensor(seed, base + 6, H * F, init_std).reshape(H, F)
+        w[p + "input_layernorm.weight"] = np.ones(H, np.float32)
+        w[p + "post_attention_layernorm.weight"] = np.ones(H, np.float32)
+    return w
+
+
+# ------------------------------------------------------------------ sampler (C restatement)
+_lib = None
+
+
+def _slib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.oracle_sample.restype = C.c_int
+        _lib.oracle_expf.restype = C.c_float
+        _lib.oracle_expf.argtypes = [C.c_float]
+    return _lib
+
+
+def sample(logits: np.ndarray, top_k: int, top_p: float, min_p: float, temp: float, seed: int, counter: int,
+           logit_bias: Optional[Dict[int, float]] = None) -> int:
+    logits = np.ascontiguousarray(logits, dtype=np.float32)
+    bias = logit_bias or {}
+    ids = (C.c_int32 * max(1, len(bias)))(*bias.keys())
+    vals = (C.c_float * max(1, len(bias)))(*bias.values())
+    return _slib().oracle_sample(logits.ctypes.data_as(C.POINTER(C.c_float)), logits.shape[0], int(top_k), C.c_float(top_p), C.c_float(min_p),
+                                 C.c_float(temp), C.c_uint32(seed & 0xFFFFFFFF), C.c_uint64(counter), len(bias), ids, vals)
+
+
+def expf(x: float) -> float:
+    return float(_slib().oracle_expf(C.c_float(x)))

@@ -1,0 +1,91 @@
+/*
+ * sampler_oracle.c -- CPU restatement (TEST INFRASTRUCTURE ONLY) of the device sampler behind
+ * LlamaForAlternatingCodeChannels.sample (reference: llamacpp_utils.py:39-95 configures llama.cpp's
+ * chain top_k -> top_p -> min_p -> temp -> dist; realtime_agent_config.py:11-20,29 gives top_k=100,
+ * top_p=1, min_p=0, temp=1, seed=42).
+ *
+ * PARITY UNPINNED against llama.cpp's own sampler: llama-cpp-python is absent offline, unpinned
+ * (only commit c37132b is mentioned, llamacpp_utils.py:10) and its RNG (std::mt19937 +
+ * discrete_distribution) cannot be reproduced from the reference; the reference holds no sampled
+ * golden tokens.  This file pins THIS build's sampler definition: exact top-k by (logit desc,
+ * index asc), polynomial exp in fma, counter-based splitmix64 RNG, inverse-CDF draw.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+float oracle_expf(float x) {
+    if (x < -87.0f) return 0.0f;
+    const float n = rintf(x * 1.44269504f);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.3888889e-3f;
+    p = fmaf(p, r, 8.3333333e-3f);
+    p = fmaf(p, r, 4.1666668e-2f);
+    p = fmaf(p, r, 1.6666667e-1f);
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(p, r, 1.0f);
+    p = fmaf(p, r, 1.0f);
+    return ldexpf(p, (int)n);
+}
+
+uint64_t oracle_splitmix(uint64_t seed, uint64_t ctr) {
+    uint64_t z = seed * 0x9E3779B97F4A7C15ull + ctr * 0xBF58476D1CE4E5B9ull + 0x94D049BB133111EBull;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+
+typedef struct { float v; int idx; } cand_t;
+static int cmp_cand(const void* a, const void* b) {
+    const cand_t* x = (const cand_t*)a; const cand_t* y = (const cand_t*)b;
+    if (x->v > y->v) return -1;
+    if (x->v < y->v) return 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+
+/* returns the sampled token for draw number `counter` of the stream started by `seed` */
+int oracle_sample(const float* logits, int V, int top_k, float top_p, float min_p, float temp, uint32_t seed, uint64_t counter,
+                  int n_bias, const int32_t* bias_ids, const float* bias_vals) {
+    cand_t* c = (cand_t*)malloc((size_t)V * sizeof(cand_t));
+    for (int i = 0; i < V; ++i) {
+        float v = logits[i];
+        for (int b = 0; b < n_bias; ++b)
+            if (bias_ids[b] == i) v = v + bias_vals[b];
+        c[i].v = v; c[i].idx = i;
+    }
+    qsort(c, (size_t)V, sizeof(cand_t), cmp_cand);
+    const int greedy = temp <= 0.0f;
+    int k = greedy ? 1 : top_k;
+    if (k <= 0 || k > 256) k = 256;
+    if (k > V) k = V;
+    int cnt = k, pick = 0;
+    if (!greedy && cnt > 1) {
+        const float mx = c[0].v;
+        if (top_p < 1.0f) {
+            float tot = 0.0f;
+            for (int i = 0; i < cnt; ++i) tot += oracle_expf(c[i].v - mx);
+            float cum = 0.0f; int keep = cnt;
+            for (int i = 0; i < cnt; ++i) { cum += oracle_expf(c[i].v - mx); if (cum >= top_p * tot) { keep = i + 1; break; } }
+            cnt = keep;
+        }
+        if (min_p > 0.0f) {
+            int keep = 1;
+            for (int i = 1; i < cnt; ++i) { if (oracle_expf(c[i].v - mx) >= min_p) keep = i + 1; else break; }
+            cnt = keep;
+        }
+        const float inv_t = 1.0f / temp;
+        float tot = 0.0f;
+        for (int i = 0; i < cnt; ++i) tot += oracle_expf((c[i].v - mx) * inv_t);
+        const uint64_t z = oracle_splitmix((uint64_t)seed, counter);
+        const float u = (float)(uint32_t)(z >> 40) * 5.9604644775390625e-08f;
+        const float target = u * tot;
+        float cum = 0.0f;
+        pick = cnt - 1;
+        for (int i = 0; i < cnt; ++i) { cum += oracle_expf((c[i].v - mx) * inv_t); if (cum > target) { pick = i; break; } }
+    }
+    const int tok = c[pick].idx;
+    free(c);
+    return tok;
+}

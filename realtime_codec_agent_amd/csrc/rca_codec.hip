@@ -165,7 +165,7 @@ template <int KS, int S, int CIC, int WM, int WN, int GM, int GN>
 __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           int Cin, int Lin, int Cout, int Lout, long Ncols, int nchunks,
-                                                          int pre, float slope) {
+                                                          int pre, float slope, int abl) {
     constexpr int MT = GM * WM * 32;
     constexpr int NT = GN * WN * 32;
     constexpr int U = ConvLds<S>::stride(NT);
@@ -245,11 +245,10 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const float* __restric
             const int ci = c * CIC + cl;
 #pragma unroll
             for (int r = 0; r < RE; ++r) {
+                // raw load only: the activation is applied in stage_write so that nothing consumes the
+                // loaded value (and forces an s_waitcnt) before the MFMA block of this chunk
                 float v = 0.0f;
-                if (s_ok[r] && ci < Cin) {
-                    v = x[s_goff[r] + (long)ci * Lin];
-                    if (pre) v = lrelu(v, slope);
-                }
+                if (s_ok[r] && ci < Cin && !(abl & 1)) v = x[s_goff[r] + (long)ci * Lin];
                 sreg[cl][r] = v;
             }
         }
@@ -260,7 +259,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const float* __restric
         for (int cl = 0; cl < CIC; ++cl)
 #pragma unroll
             for (int r = 0; r < RE; ++r)
-                if (s_loff[r] >= 0) dst[cl * S * U + s_loff[r]] = sreg[cl][r];
+                if (s_loff[r] >= 0) dst[cl * S * U + s_loff[r]] = pre ? lrelu(sreg[cl][r], slope) : sreg[cl][r];
     };
 
     const long kquads = (long)nchunks * QPC;
@@ -270,7 +269,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const float* __restric
             const int cot = blockIdx.y * (GM * WM) + gm * WM + wm;
             const float4* p = reinterpret_cast<const float4*>(wp) + ((long)cot * kquads + (long)c * QPC) * 64 + lane;
 #pragma unroll
-            for (int q = 0; q < QPC; ++q) a[wm][q] = p[q * 64];
+            for (int q = 0; q < QPC; ++q) a[wm][q] = (abl & 4) ? make_float4(1.f, 2.f, 3.f, 4.f) : p[q * 64];
         }
     };
     auto compute = [&](const float4 (&a)[WM][QPC], int buf) {
@@ -280,7 +279,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const float* __restric
             float bfr[WN];
 #pragma unroll
             for (int wn = 0; wn < WN; ++wn) {
-                const float v = xb[b_off[kp] + wn * 32];
+                const float v = (abl & 2) ? (float)(lane + kp) : xb[b_off[kp] + wn * 32];
                 bfr[wn] = ((zmask[wn] >> kp) & 1u) ? 0.0f : v;
             }
 #pragma unroll
@@ -796,7 +795,8 @@ static void launch_conv_cfg(const ConvLayer& L, const float* x, float* y, int Li
     constexpr int lds = 2 * CIC * S * ConvLds<S>::stride(NT) * 4;
     static_assert(lds <= 65536, "LDS budget");
     dim3 grid(cdiv(Ncols, NT), cdiv(L.cout, MT));
-    conv1d_mfma_kernel<KS, S, CIC, WM, WN, GM, GN><<<grid, 256, lds, st>>>(x, L.wp, L.b, y, L.cin, Lin, L.cout, Lout, Ncols, L.nchunks, L.pre, slope);
+    static const int abl = getenv("RCA_CONV_ABLATE") ? atoi(getenv("RCA_CONV_ABLATE")) : 0;  // timing experiments only
+    conv1d_mfma_kernel<KS, S, CIC, WM, WN, GM, GN><<<grid, 256, lds, st>>>(x, L.wp, L.b, y, L.cin, Lin, L.cout, Lout, Ncols, L.nchunks, L.pre, slope, abl);
 }
 
 template <int KS, int S, int CIC>

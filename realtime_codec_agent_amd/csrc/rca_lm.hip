@@ -1,0 +1,1142 @@
+// rca_lm.hip -- Llama-architecture autoregressive step on gfx950 (MI355X) with a
+// llama_cpp.Llama-like control surface (include/rca.h, rca_lm_*).
+//
+// The deployed reference LM is codec_llama.py after persist_codec_embeddings
+// (codec_llama.py:178-206): a vanilla Llama (RMSNorm, RoPE, GQA attention, SwiGLU, untied
+// lm_head) evaluated by llama.cpp with 1-2 tokens per step (llamacpp_utils.py:145-161;
+// realtime_agent_v2.py:355).  Here:
+//   weights   bf16 in HBM, row-major [N][K], streamed once per step with non-temporal 16-B loads
+//   activations f32; every projection is a wave-per-row dot product with f32 accumulation
+//             (M <= 8 tokens per pass: the step is HBM-bound, ~3 GB of weights per step)
+//   KV cache  fp16 [layer][pos][kv_head][64] (llama.cpp's default cache type)
+//   attention split-KV decode kernel (256 keys per workgroup) + combine
+//   sampler   top-k radix select -> sorted candidates -> top-p/min-p/temperature -> inverse CDF
+//             with a counter-based RNG and a polynomial exp, all on the device
+//   the steady-state step (eval 1-2 tokens + sample) is captured once into a hipGraph; the KV
+//   position, input ids and RNG counter live in device memory so the graph replays unchanged.
+#include <algorithm>
+#include <cmath>
+
+#include "rca_common.h"
+
+using namespace rca;
+
+typedef unsigned short bf16_t;
+typedef _Float16 f16_t;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+#define LM_MAXM 8          // tokens per forward pass
+#define LM_KSLICE 2048     // K handled by one workgroup pass of the GEMV
+#define LM_MAXSPLIT 4      // K splits (ffn 8192 / 2048)
+#define ATT_KEYS 256       // keys per attention workgroup
+#define SAMP_MAXK 256
+
+struct LmDevState {
+    int n_tokens;      // KV position of the first token of the current pass
+    int m;             // tokens in the current pass
+    int ids[LM_MAXM];
+    unsigned long long rng_counter;
+    int out_token;
+    int pad;
+};
+
+struct SamplerDev {
+    int top_k;
+    float top_p, min_p, temp;
+    unsigned long long seed;
+    int n_bias;
+    int bias_ids[8];
+    float bias_vals[8];
+};
+
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------- embed
+__global__ __launch_bounds__(256) void lm_embed_kernel(const LmDevState* __restrict__ stt, const bf16_t* __restrict__ table,
+                                                       float* __restrict__ x, int H, int V) {
+    const int m = blockIdx.x;
+    if (m >= stt->m) return;
+    int id = stt->ids[m];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    const bf16_t* row = table + (long)id * H;
+    for (int h = threadIdx.x; h < H; h += 256) x[(long)m * H + h] = __uint_as_float((unsigned)row[h] << 16);
+}
+
+// --------------------------------------------------------------- residual add + RMSNorm (one WG per token)
+// x[m] += sum_s parts[s][m] (s ascending) ; xn[m] = x[m] * rsqrt(mean(x^2) + eps) * w
+__global__ __launch_bounds__(256) void lm_add_rmsnorm_kernel(const LmDevState* __restrict__ stt, float* __restrict__ x,
+                                                             const float* __restrict__ parts, int nparts, long part_stride,
+                                                             const float* __restrict__ w, float* __restrict__ xn, int H,
+                                                             float eps, int only_last) {
+    int m = blockIdx.x;
+    const int M = stt->m;
+    if (only_last) m = M - 1;
+    if (m >= M) return;
+    float* xr = x + (long)m * H;
+    float ss = 0.0f;
+    for (int h = threadIdx.x; h < H; h += 256) {
+        float v = xr[h];
+        for (int s = 0; s < nparts; ++s) v += parts[s * part_stride + (long)m * H + h];
+        if (nparts) xr[h] = v;
+        ss = __builtin_fmaf(v, v, ss);
+    }
+    __shared__ float red[4];
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float tot = red[0] + red[1] + red[2] + red[3];
+    const float rstd = rsqrtf(tot / (float)H + eps);
+    float* out = xn + (long)(only_last ? 0 : m) * H;
+    for (int h = threadIdx.x; h < H; h += 256) out[h] = (xr[h] * rstd) * w[h];
+}
+
+// ------------------------------------------------------------------------------------ GEMV
+// y[slice][m][n] = sum_{k in slice} W[n][k] * x[m][k].   One wave owns 2 rows at a time and walks
+// its K slice in 16-byte (8 x bf16) lane chunks; x sits in LDS as f32.  EPI 0: store partials,
+// EPI 1: rows (2i, 2i+1) are (gate_i, up_i): store silu(gate) * up into h[m][i].
+template <int M, int EPI>
+__global__ __launch_bounds__(256) void lm_gemv_kernel(const bf16_t* __restrict__ W, const float* __restrict__ x, float* __restrict__ y,
+                                                      int N, int K, int kslice, int rows_per_wg, long y_slice_stride, int ldy,
+                                                      int x_row_offset) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [M][kslice]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sl = blockIdx.y;
+    const int k0 = sl * kslice;
+    const int kl = min(kslice, K - k0);
+    for (int i = threadIdx.x; i < M * kl; i += 256) {
+        const int m = i / kl, k = i - m * kl;
+        xs[m * kslice + k] = x[(long)(m + x_row_offset) * K + k0 + k];
+    }
+    __syncthreads();
+    const int nchunk = kl >> 3;  // 8-element chunks in this slice
+    const int row_beg = blockIdx.x * rows_per_wg;
+    const int row_end = min(N, row_beg + rows_per_wg);
+    for (int r0 = row_beg + wave * 2; r0 < row_end; r0 += 8) {
+        float acc[2][M];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int m = 0; m < M; ++m) acc[rr][m] = 0.0f;
+        const bool has2 = (r0 + 1) < row_end;
+        const u32x4* w0 = reinterpret_cast<const u32x4*>(W + (long)r0 * K + k0);
+        const u32x4* w1 = reinterpret_cast<const u32x4*>(W + (long)(has2 ? r0 + 1 : r0) * K + k0);
+        for (int c = lane; c < nchunk; c += 64) {
+            const u32x4 a = __builtin_nontemporal_load(w0 + c);
+            const u32x4 b = __builtin_nontemporal_load(w1 + c);
+            const float wa[8] = {bf16_lo(a.x), bf16_hi(a.x), bf16_lo(a.y), bf16_hi(a.y), bf16_lo(a.z), bf16_hi(a.z), bf16_lo(a.w), bf16_hi(a.w)};
+            const float wb[8] = {bf16_lo(b.x), bf16_hi(b.x), bf16_lo(b.y), bf16_hi(b.y), bf16_lo(b.z), bf16_hi(b.z), bf16_lo(b.w), bf16_hi(b.w)};
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const float4 x0 = *reinterpret_cast<const float4*>(xs + m * kslice + c * 8);
+                const float4 x1 = *reinterpret_cast<const float4*>(xs + m * kslice + c * 8 + 4);
+                const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc[0][m] = __builtin_fmaf(wa[j], xv[j], acc[0][m]);
+                    acc[1][m] = __builtin_fmaf(wb[j], xv[j], acc[1][m]);
+                }
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int m = 0; m < M; ++m) acc[rr][m] = wave_sum(acc[rr][m]);
+        if (lane == 0) {
+            if (EPI == 1) {
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const float g = acc[0][m], u = acc[1][m];
+                    y[(long)m * ldy + (r0 >> 1)] = (g / (1.0f + __expf(-g))) * u;
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    y[sl * y_slice_stride + (long)m * ldy + r0] = acc[0][m];
+                    if (has2) y[sl * y_slice_stride + (long)m * ldy + r0 + 1] = acc[1][m];
+                }
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------- RoPE + KV-cache write
+// qkv [M][(nh + 2*nkv) * hd] f32.  q rotated in place; k rotated and stored fp16; v stored fp16.
+// HF convention (rotate_half): out[d] = x[d]*cos[d] - x[d+hd/2]*sin[d]; out[d+hd/2] = x[d+hd/2]*cos[d] + x[d]*sin[d].
+__global__ __launch_bounds__(256) void lm_rope_kv_kernel(const LmDevState* __restrict__ stt, float* __restrict__ qkv,
+                                                         const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                         f16_t* __restrict__ kc, f16_t* __restrict__ vc, int nh, int nkv, int hd,
+                                                         int n_ctx) {
+    const int m = blockIdx.x;
+    if (m >= stt->m) return;
+    const int pos = stt->n_tokens + m;
+    if (pos >= n_ctx) return;
+    const int half = hd >> 1;
+    const int ld = (nh + 2 * nkv) * hd;
+    float* row = qkv + (long)m * ld;
+    const float* cs = cos_t + (long)pos * half;
+    const float* sn = sin_t + (long)pos * half;
+    // q and k heads
+    for (int i = threadIdx.x; i < (nh + nkv) * half; i += 256) {
+        const int head = i / half, d = i - head * half;
+        float* hp = row + head * hd;
+        const float x1 = hp[d], x2 = hp[d + half];
+        const float c = cs[d], s = sn[d];
+        const float o1 = x1 * c + (-x2) * s;
+        const float o2 = x2 * c + x1 * s;
+        if (head < nh) {
+            hp[d] = o1;
+            hp[d + half] = o2;
+        } else {
+            f16_t* kp = kc + ((long)pos * nkv + (head - nh)) * hd;
+            kp[d] = (f16_t)o1;
+            kp[d + half] = (f16_t)o2;
+        }
+    }
+    for (int i = threadIdx.x; i < nkv * hd; i += 256) {
+        vc[(long)pos * nkv * hd + i] = (f16_t)row[(nh + nkv) * hd + i];
+    }
+}
+
+// ------------------------------------------------------------------------------ decode attention
+// grid (nkv, n_splits, ceil(M/2)); workgroup = 4 waves, each wave one 64-key block of this split.
+// Rows r = mi*G + hq (two tokens x G query heads of this kv head), R = 2G <= 8.
+// partial layout: part[((pair*nkv + g)*n_splits + sp)*8 + r][66] = {m, l, o[64]}
+template <int G>
+__global__ __launch_bounds__(256) void lm_attn_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ qkv,
+                                                      const f16_t* __restrict__ kc, const f16_t* __restrict__ vc,
+                                                      float* __restrict__ part, int nh, int nkv, int n_splits, float scale) {
+    constexpr int HD = 64;
+    constexpr int R = 2 * G;
+    const int g = blockIdx.x, sp = blockIdx.y, pair = blockIdx.z;
+    const int M = stt->m;
+    const int m0 = pair * 2;
+    if (m0 >= M) return;
+    const int pos0 = stt->n_tokens;
+    const int ntok = min(2, M - m0);
+    const int kmax = pos0 + m0 + ntok;  // keys [0, kmax) are visible to the last token of the pair
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* pout = part + ((long)(pair * nkv + g) * n_splits + sp) * 8 * 66;
+    const int kbase = sp * ATT_KEYS;
+    if (kbase >= kmax) {  // nothing visible in this split
+        if (threadIdx.x < R) { pout[threadIdx.x * 66] = -INFINITY; pout[threadIdx.x * 66 + 1] = 0.0f; }
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) float qs[R][HD];
+    __shared__ float ps[4][R][64];
+    __shared__ float wm[4][R], wl[4][R];
+    __shared__ float wo[4][R][HD];
+    const int ld = (nh + 2 * nkv) * HD;
+    for (int i = threadIdx.x; i < R * HD; i += 256) {
+        const int r = i / HD, d = i - r * HD;
+        const int mi = r / G, hq = r - mi * G;
+        qs[r][d] = (mi < ntok) ? qkv[(long)(m0 + mi) * ld + (g * G + hq) * HD + d] : 0.0f;
+    }
+    __syncthreads();
+    // ---- phase A: lane <-> key
+    const int key = kbase + wave * 64 + lane;
+    float s[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) s[r] = 0.0f;
+    if (key < kmax) {
+        const uint4* kp = reinterpret_cast<const uint4*>(kc + ((long)key * nkv + g) * HD);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint4 u = kp[c];
+            const unsigned uw[4] = {u.x, u.y, u.z, u.w};
+            float kv[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f16x2 h2 = __builtin_bit_cast(f16x2, uw[j]);
+                kv[2 * j] = (float)h2.x;
+                kv[2 * j + 1] = (float)h2.y;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float4 q0 = *reinterpret_cast<const float4*>(&qs[r][c * 8]);
+                const float4 q1 = *reinterpret_cast<const float4*>(&qs[r][c * 8 + 4]);
+                float a = s[r];
+                a = __builtin_fmaf(q0.x, kv[0], a); a = __builtin_fmaf(q0.y, kv[1], a);
+                a = __builtin_fmaf(q0.z, kv[2], a); a = __builtin_fmaf(q0.w, kv[3], a);
+                a = __builtin_fmaf(q1.x, kv[4], a); a = __builtin_fmaf(q1.y, kv[5], a);
+                a = __builtin_fmaf(q1.z, kv[6], a); a = __builtin_fmaf(q1.w, kv[7], a);
+                s[r] = a;
+            }
+        }
+    }
+    float mrow[R], lrow[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int mi = r / G;
+        const bool vis = (mi < ntok) && (key <= pos0 + m0 + mi);
+        const float sv = vis ? s[r] * scale : -INFINITY;
+        const float mx = wave_max(sv);
+        const float p = (mx == -INFINITY) ? 0.0f : __expf(sv - mx);
+        mrow[r] = mx;
+        lrow[r] = wave_sum(p);
+        ps[wave][r][lane] = p;
+    }
+    __syncthreads();
+    // ---- phase B: lane <-> (key group kq of 8, dim chunk dq of 8)
+    const int kq = lane >> 3, dq = lane & 7;
+    float o[R][8];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[r][j] = 0.0f;
+    const int kwb = kbase + wave * 64;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int jj = it * 8 + kq;
+        const int kk = kwb + jj;
+        if (kk < kmax) {
+            const uint4 u = *reinterpret_cast<const uint4*>(vc + ((long)kk * nkv + g) * HD + dq * 8);
+            const unsigned uw[4] = {u.x, u.y, u.z, u.w};
+            float vv[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f16x2 h2 = __builtin_bit_cast(f16x2, uw[j]);
+                vv[2 * j] = (float)h2.x;
+                vv[2 * j + 1] = (float)h2.y;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float p = ps[wave][r][jj];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[r][j] = __builtin_fmaf(p, vv[j], o[r][j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = o[r][j];
+            v += __shfl_xor(v, 8);
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            o[r][j] = v;
+        }
+    if (kq == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wo[wave][r][dq * 8 + j] = o[r][j];
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { wm[wave][r] = mrow[r]; wl[wave][r] = lrow[r]; }
+    }
+    __syncthreads();
+    // ---- merge the 4 waves, write the split partial
+    for (int i = threadIdx.x; i < R * HD; i += 256) {
+        const int r = i / HD, d = i - r * HD;
+        float mx = fmaxf(fmaxf(wm[0][r], wm[1][r]), fmaxf(wm[2][r], wm[3][r]));
+        float L = 0.0f, O = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float f = (wm[w][r] == -INFINITY) ? 0.0f : __expf(wm[w][r] - mx);
+            L = __builtin_fmaf(wl[w][r], f, L);
+            O = __builtin_fmaf(wo[w][r][d], f, O);
+        }
+        pout[r * 66 + 2 + d] = O;
+        if (d == 0) { pout[r * 66] = mx; pout[r * 66 + 1] = L; }
+    }
+}
+
+// attn[m][head*64 + d] = sum_sp o * exp(m_sp - mx) / sum_sp l * exp(m_sp - mx); one wave per (m, head)
+template <int G>
+__global__ __launch_bounds__(64) void lm_attn_combine_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ part,
+                                                             float* __restrict__ attn, int nh, int nkv, int n_splits) {
+    const int m = blockIdx.x / nh, head = blockIdx.x % nh;
+    if (m >= stt->m) return;
+    const int g = head / G, hq = head % G;
+    const int pair = m >> 1, mi = m & 1;
+    const int r = mi * G + hq;
+    const int d = threadIdx.x;
+    const int nsp = min(n_splits, (stt->n_tokens + m) / ATT_KEYS + 1);
+    const float* base = part + ((long)(pair * nkv + g) * n_splits) * 8 * 66 + r * 66;
+    float mx = -INFINITY;
+    for (int sp = 0; sp < nsp; ++sp) mx = fmaxf(mx, base[(long)sp * 8 * 66]);
+    float L = 0.0f, O = 0.0f;
+    for (int sp = 0; sp < nsp; ++sp) {
+        const float* p = base + (long)sp * 8 * 66;
+        const float f = (p[0] == -INFINITY) ? 0.0f : __expf(p[0] - mx);
+        L = __builtin_fmaf(p[1], f, L);
+        O = __builtin_fmaf(p[2 + d], f, O);
+    }
+    attn[(long)m * nh * 64 + head * 64 + d] = O / L;
+}
+
+// advance the device-side KV position after a pass
+__global__ void lm_advance_kernel(LmDevState* stt) { stt->n_tokens += stt->m; }
+// steady-state step: next pass's first id is the token just sampled (realtime_agent_v2.py:355-363)
+__global__ void lm_copy_logits_row_kernel(const float* __restrict__ src, float* __restrict__ dst, int V) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// --------------------------------------------------------------------------------- sampler
+// Deterministic exp for x <= 0 (bit-identical to oracle/sampler_oracle.c): Cody-Waite reduction,
+// degree-6 Horner in fma, exact ldexp.
+__device__ __forceinline__ float rca_expf(float x) {
+    if (x < -87.0f) return 0.0f;
+    const float n = rintf(x * 1.44269504f);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.3888889e-3f;
+    p = __builtin_fmaf(p, r, 8.3333333e-3f);
+    p = __builtin_fmaf(p, r, 4.1666668e-2f);
+    p = __builtin_fmaf(p, r, 1.6666667e-1f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    return ldexpf(p, (int)n);
+}
+__device__ __forceinline__ unsigned long long splitmix(unsigned long long seed, unsigned long long ctr) {
+    unsigned long long z = seed * 0x9E3779B97F4A7C15ull + ctr * 0xBF58476D1CE4E5B9ull + 0x94D049BB133111EBull;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+__device__ __forceinline__ unsigned long long sample_key(float v, unsigned idx) {
+    unsigned u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+}
+
+// One workgroup of 1024 threads: exact top-k by 8-bit radix select over 64-bit (value, index) keys,
+// bitonic sort of the k survivors, then the llama.cpp chain order top_k -> top_p -> min_p -> temp ->
+// softmax -> inverse-CDF draw (llamacpp_utils.py:39-95; realtime_agent_config.py:11-20,29).
+__global__ __launch_bounds__(1024) void lm_sample_kernel(const float* __restrict__ logits, int V, const SamplerDev* __restrict__ sp,
+                                                         LmDevState* __restrict__ stt, int feed_back) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long sel_prefix;
+    __shared__ int sel_shift;      // bits already fixed (from the top)
+    __shared__ unsigned need;      // how many more keys to take inside the current prefix bucket
+    __shared__ unsigned long long cand[SAMP_MAXK];
+    __shared__ unsigned ncand;
+    __shared__ float cval[SAMP_MAXK];
+    const int tid = threadIdx.x;
+    int k = sp->top_k;
+    const bool greedy = sp->temp <= 0.0f;
+    if (greedy) k = 1;
+    if (k <= 0 || k > SAMP_MAXK) k = SAMP_MAXK;
+    if (k > V) k = V;
+    const int nb = sp->n_bias;
+    auto value_of = [&](int i) {
+        float v = logits[i];
+        for (int b = 0; b < nb; ++b)
+            if (sp->bias_ids[b] == i) v = v + sp->bias_vals[b];
+        return v;
+    };
+    if (tid == 0) { sel_prefix = 0ull; sel_shift = 0; need = (unsigned)k; ncand = 0; }
+    __syncthreads();
+    // radix select: after the loop, keys >= threshold are exactly the k largest
+    for (int pass = 0; pass < 8; ++pass) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const int shift = 56 - 8 * pass;
+        const unsigned long long prefix = sel_prefix;
+        const int fixed = sel_shift;
+        for (int i = tid; i < V; i += 1024) {
+            const unsigned long long key = sample_key(value_of(i), (unsigned)i);
+            const bool match = fixed == 0 ? true : ((key >> (64 - fixed)) == (prefix >> (64 - fixed)));
+            if (match) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned acc = 0;
+            int d = 255;
+            for (; d > 0; --d) {
+                if (acc + hist[d] >= need) break;
+                acc += hist[d];
+            }
+            need -= acc;  // keys in higher digits are all taken
+            sel_prefix = prefix | ((unsigned long long)d << shift);
+            sel_shift = fixed + 8;
+            if (hist[d] == need) need = 0xFFFFFFFFu;  // whole bucket taken: threshold fixed, stop refining
+        }
+        __syncthreads();
+        if (need == 0xFFFFFFFFu) break;
+    }
+    const int fixed = sel_shift;
+    const unsigned long long thr = fixed >= 64 ? sel_prefix : (sel_prefix >> (64 - fixed)) << (64 - fixed);
+    for (int i = tid; i < V; i += 1024) {
+        const float v = value_of(i);
+        const unsigned long long key = sample_key(v, (unsigned)i);
+        if (key >= thr) {
+            const unsigned slot = atomicAdd(&ncand, 1u);
+            if (slot < SAMP_MAXK) cand[slot] = key;
+        }
+    }
+    __syncthreads();
+    const int n = min((int)ncand, SAMP_MAXK);
+    // bitonic sort (descending) of 256 slots, padding = 0
+    if (tid < SAMP_MAXK && tid >= n) cand[tid] = 0ull;
+    __syncthreads();
+    for (int size = 2; size <= SAMP_MAXK; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (tid < SAMP_MAXK) {
+                const int j = tid ^ stride;
+                if (j > tid) {
+                    const unsigned long long a = cand[tid], b = cand[j];
+                    const bool desc = (tid & size) == 0;
+                    if (desc ? (a < b) : (a > b)) { cand[tid] = b; cand[j] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid < n) {
+        const unsigned idx = 0xFFFFFFFFu - (unsigned)(cand[tid] & 0xFFFFFFFFull);
+        cval[tid] = value_of((int)idx);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int cnt = min(n, k);
+        int pick = 0;
+        if (!greedy && cnt > 1) {
+            const float mx = cval[0];
+            if (sp->top_p < 1.0f) {  // smallest prefix whose probability mass reaches top_p
+                float tot = 0.0f;
+                for (int i = 0; i < cnt; ++i) tot += rca_expf(cval[i] - mx);
+                float cum = 0.0f;
+                int keep = cnt;
+                for (int i = 0; i < cnt; ++i) {
+                    cum += rca_expf(cval[i] - mx);
+                    if (cum >= sp->top_p * tot) { keep = i + 1; break; }
+                }
+                cnt = keep;
+            }
+            if (sp->min_p > 0.0f) {  // keep p_i >= min_p * p_max
+                int keep = 1;
+                for (int i = 1; i < cnt; ++i)
+                    if (rca_expf(cval[i] - mx) >= sp->min_p) keep = i + 1; else break;
+                cnt = keep;
+            }
+            const float inv_t = 1.0f / sp->temp;
+            float tot = 0.0f;
+            for (int i = 0; i < cnt; ++i) tot += rca_expf((cval[i] - mx) * inv_t);
+            const unsigned long long z = splitmix(sp->seed, stt->rng_counter);
+            const float u = (float)(unsigned)(z >> 40) * 5.9604644775390625e-08f;  // 2^-24
+            const float target = u * tot;
+            float cum = 0.0f;
+            pick = cnt - 1;
+            for (int i = 0; i < cnt; ++i) {
+                cum += rca_expf((cval[i] - mx) * inv_t);
+                if (cum > target) { pick = i; break; }
+            }
+        }
+        stt->rng_counter += 1ull;
+        const int tok = (int)(0xFFFFFFFFu - (unsigned)(cand[pick] & 0xFFFFFFFFull));
+        stt->out_token = tok;
+        if (feed_back) stt->ids[0] = tok;
+    }
+}
+
+// probs[i] = softmax(logits)[ids[i]] : one workgroup, two sweeps (max, sum)
+__global__ __launch_bounds__(1024) void lm_token_probs_kernel(const float* __restrict__ logits, int V, const int* __restrict__ ids,
+                                                              int n, float* __restrict__ probs) {
+    __shared__ float red[16];
+    __shared__ float smax, ssum;
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < V; i += 1024) mx = fmaxf(mx, logits[i]);
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) { float m = red[0]; for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]); smax = m; }
+    __syncthreads();
+    mx = smax;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < V; i += 1024) s += __expf(logits[i] - mx);
+    s = wave_sum(s);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { float t = 0; for (int w = 0; w < 16; ++w) t += red[w]; ssum = t; }
+    __syncthreads();
+    if (threadIdx.x < n) {
+        const int id = ids[threadIdx.x];
+        probs[threadIdx.x] = (id >= 0 && id < V) ? __expf(logits[id] - mx) / ssum : 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------- random init (bench)
+// value(tensor_id, i) = std * 1.7320508 * (sum of four 16-bit uniforms - 131070) / 65535 ~ N(0, std^2)
+// (Irwin-Hall, integer arithmetic only, reproduced by oracle/lm_ref.py), rounded to bf16 (RNE).
+__device__ __forceinline__ bf16_t f32_to_bf16_rne(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__global__ __launch_bounds__(256) void lm_random_bf16_kernel(bf16_t* __restrict__ out, long n, unsigned long long seed,
+                                                             unsigned long long tensor_id, float scale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const unsigned long long z = splitmix(seed ^ (tensor_id * 0xD6E8FEB86659FD93ull), (unsigned long long)i);
+        const int sum = (int)(z & 0xFFFF) + (int)((z >> 16) & 0xFFFF) + (int)((z >> 32) & 0xFFFF) + (int)((z >> 48) & 0xFFFF);
+        out[i] = f32_to_bf16_rne((float)(sum - 131070) * scale);
+    }
+}
+__global__ __launch_bounds__(256) void lm_fill_f32_kernel(float* __restrict__ out, long n, float v) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = v;
+}
+__global__ __launch_bounds__(256) void lm_rope_table_kernel(const float* __restrict__ inv_freq, float* __restrict__ cos_t,
+                                                            float* __restrict__ sin_t, int n_ctx, int half) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)n_ctx * half) return;
+    const int pos = (int)(i / half), d = (int)(i - (long)pos * half);
+    const float ang = (float)pos * inv_freq[d];
+    cos_t[i] = cosf(ang);
+    sin_t[i] = sinf(ang);
+}
+// interleave gate/up rows: dst row 2i = gate_i, 2i+1 = up_i
+__global__ __launch_bounds__(256) void lm_interleave_rows_kernel(const bf16_t* __restrict__ gate, const bf16_t* __restrict__ up,
+                                                                 bf16_t* __restrict__ dst, int F, int H) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)2 * F * H) return;
+    const long row = i / H;
+    const int h = (int)(i - row * H);
+    const long src = (row >> 1) * H + h;
+    dst[i] = (row & 1) ? up[src] : gate[src];
+}
+__global__ __launch_bounds__(256) void lm_f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = f32_to_bf16_rne(in[i]);
+}
+
+// =============================================================================================
+struct LmLayer {
+    bf16_t *wqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wdown = nullptr;
+    float *attn_norm = nullptr, *ffn_norm = nullptr;
+};
+
+struct rca_lm {
+    rca_lm_config_t cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bf16_t *embed = nullptr, *head = nullptr;
+    float* final_norm = nullptr;
+    std::vector<LmLayer> layers;
+    float *cos_t = nullptr, *sin_t = nullptr;
+    f16_t *kc = nullptr, *vc = nullptr;  // [L][n_ctx_pad][nkv][hd]
+    long kv_layer_stride = 0;
+    int n_ctx_pad = 0, n_splits = 0;
+    // activations
+    float *x = nullptr, *xn = nullptr, *qkv = nullptr, *attn = nullptr, *part_o = nullptr, *hbuf = nullptr, *part_d = nullptr,
+          *att_part = nullptr, *logits = nullptr, *probs_dev = nullptr;
+    int* probe_ids_dev = nullptr;
+    long logits_rows_cap = 0;   // rows allocated in `logits` (1, or more when logits_all)
+    int logits_rows = 0;        // rows valid from the last eval
+    LmDevState* stt = nullptr;  // device
+    SamplerDev* samp = nullptr; // device
+    LmDevState* h_stt = nullptr;   // pinned host staging (ids, n_tokens, m in; out_token back)
+    int n_tokens = 0;           // host mirror (llama_cpp.Llama.n_tokens)
+    bool sampler_set = false;
+    int ksplit_down = 1, kslice_down = 0;
+    // captured steady-state steps (n = 1, 2)
+    hipGraphExec_t graph[3] = {nullptr, nullptr, nullptr};
+    bool graphs_enabled = true;
+};
+
+static int lm_alloc(void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return fail(RCA_ERR_HIP, "hipMalloc(%zu) -> %s", bytes, hipGetErrorString(e));
+    return RCA_OK;
+}
+
+extern "C" int rca_lm_destroy(rca_lm_t* h) {
+    if (!h) return RCA_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (int i = 0; i < 3; ++i)
+        if (h->graph[i]) (void)hipGraphExecDestroy(h->graph[i]);
+    for (auto& L : h->layers)
+        for (void* p : {(void*)L.wqkv, (void*)L.wo, (void*)L.wgu, (void*)L.wdown, (void*)L.attn_norm, (void*)L.ffn_norm})
+            if (p) (void)hipFree(p);
+    for (void* p : {(void*)h->embed, (void*)h->head, (void*)h->final_norm, (void*)h->cos_t, (void*)h->sin_t, (void*)h->kc, (void*)h->vc,
+                    (void*)h->x, (void*)h->xn, (void*)h->qkv, (void*)h->attn, (void*)h->part_o, (void*)h->hbuf, (void*)h->part_d,
+                    (void*)h->att_part, (void*)h->logits, (void*)h->probs_dev, (void*)h->probe_ids_dev, (void*)h->stt, (void*)h->samp})
+        if (p) (void)hipFree(p);
+    if (h->h_stt) (void)hipHostFree(h->h_stt);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return RCA_OK;
+}
+
+static int lm_check_cfg(const rca_lm_config_t* c) {
+    if (!c) return fail(RCA_ERR_ARG, "null config");
+    if (c->head_dim != 64) return fail(RCA_ERR_ARG, "head_dim must be 64 (got %d)", c->head_dim);
+    if (c->n_kv_heads < 1 || c->n_heads % c->n_kv_heads) return fail(RCA_ERR_ARG, "n_heads must be a multiple of n_kv_heads");
+    const int G = c->n_heads / c->n_kv_heads;
+    if (G != 1 && G != 2 && G != 4) return fail(RCA_ERR_ARG, "query group size %d unsupported (1, 2, 4)", G);
+    if (c->hidden % 8 || c->ffn % 8 || (c->n_heads * c->head_dim) % 8) return fail(RCA_ERR_ARG, "hidden/ffn must be multiples of 8");
+    if (c->hidden > LM_KSLICE || c->n_heads * c->head_dim > LM_KSLICE) return fail(RCA_ERR_ARG, "hidden > %d unsupported", LM_KSLICE);
+    if (c->ffn > LM_KSLICE * LM_MAXSPLIT) return fail(RCA_ERR_ARG, "ffn > %d unsupported", LM_KSLICE * LM_MAXSPLIT);
+    if (c->ffn > LM_KSLICE && c->ffn % LM_KSLICE) return fail(RCA_ERR_ARG, "ffn above %d must be a multiple of it", LM_KSLICE);
+    if (c->vocab_size < 2 || c->n_layers < 1 || c->n_ctx < 2) return fail(RCA_ERR_ARG, "bad sizes");
+    return RCA_OK;
+}
+
+// uploads a tensor as bf16 (converting from f32 on the device when needed)
+static int lm_upload_bf16(rca_lm* h, const rca_tensor_t* ts, int nt, const std::string& name, long numel, bf16_t** out) {
+    const rca_tensor_t* t = find_tensor(ts, nt, name);
+    if (!t) return fail(RCA_ERR_MISSING, "tensor '%s' missing", name.c_str());
+    if (t->numel != numel) return fail(RCA_ERR_ARG, "tensor '%s': numel %ld, expected %ld", name.c_str(), (long)t->numel, numel);
+    int rc;
+    if ((rc = lm_alloc((void**)out, (size_t)numel * 2)) != RCA_OK) return rc;
+    if (t->dtype == RCA_BF16) {
+        RCA_HIP(hipMemcpy(*out, t->data, (size_t)numel * 2, hipMemcpyHostToDevice));
+    } else {
+        float* tmp = nullptr;
+        if ((rc = lm_alloc((void**)&tmp, (size_t)numel * 4)) != RCA_OK) return rc;
+        hipError_t e = hipMemcpy(tmp, t->data, (size_t)numel * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            lm_f32_to_bf16_kernel<<<2048, 256, 0, h->stream>>>(tmp, *out, numel);
+            e = hipStreamSynchronize(h->stream);
+        }
+        (void)hipFree(tmp);
+        if (e != hipSuccess) return fail(RCA_ERR_HIP, "upload '%s': %s", name.c_str(), hipGetErrorString(e));
+    }
+    return RCA_OK;
+}
+static int lm_upload_f32(const rca_tensor_t* ts, int nt, const std::string& name, long numel, float** out) {
+    const rca_tensor_t* t = find_tensor(ts, nt, name);
+    if (!t) return fail(RCA_ERR_MISSING, "tensor '%s' missing", name.c_str());
+    if (t->numel != numel || t->dtype != RCA_F32) return fail(RCA_ERR_ARG, "tensor '%s': want %ld f32 values", name.c_str(), numel);
+    int rc;
+    if ((rc = lm_alloc((void**)out, (size_t)numel * 4)) != RCA_OK) return rc;
+    RCA_HIP(hipMemcpy(*out, t->data, (size_t)numel * 4, hipMemcpyHostToDevice));
+    return RCA_OK;
+}
+
+static int lm_common_init(rca_lm* h, const rca_tensor_t* ts, int nt) {
+    const rca_lm_config_t& c = h->cfg;
+    int rc;
+    const int half = c.head_dim / 2;
+    h->n_ctx_pad = (c.n_ctx + ATT_KEYS - 1) / ATT_KEYS * ATT_KEYS;
+    h->n_splits = h->n_ctx_pad / ATT_KEYS;
+    // RoPE tables from inv_freq (supplied by the host layer exactly as HF computes it, or derived here)
+    std::vector<float> inv(half);
+    const rca_tensor_t* tinv = find_tensor(ts, nt, "rope.inv_freq");
+    if (tinv) {
+        if (tinv->numel != half || tinv->dtype != RCA_F32) return fail(RCA_ERR_ARG, "rope.inv_freq must hold %d f32", half);
+        memcpy(inv.data(), tinv->data, half * sizeof(float));
+    } else {
+        for (int i = 0; i < half; ++i) {
+            double f = 1.0 / pow((double)c.rope_theta, (double)(2 * i) / (double)c.head_dim);
+            if (c.rope_scaling == 1) {
+                const double low_wl = (double)c.rope_orig_ctx / c.rope_low_freq_factor;
+                const double high_wl = (double)c.rope_orig_ctx / c.rope_high_freq_factor;
+                const double wl = 2.0 * M_PI / f;
+                if (wl > low_wl) f = f / c.rope_factor;
+                else if (wl >= high_wl) {
+                    const double smooth = ((double)c.rope_orig_ctx / wl - c.rope_low_freq_factor) / (c.rope_high_freq_factor - c.rope_low_freq_factor);
+                    f = (1.0 - smooth) * f / c.rope_factor + smooth * f;
+                }
+            }
+            inv[i] = (float)f;
+        }
+    }
+    float* inv_dev = nullptr;
+    if ((rc = lm_alloc((void**)&inv_dev, half * 4)) != RCA_OK) return rc;
+    RCA_HIP(hipMemcpy(inv_dev, inv.data(), half * 4, hipMemcpyHostToDevice));
+    if ((rc = lm_alloc((void**)&h->cos_t, (size_t)h->n_ctx_pad * half * 4)) != RCA_OK) return rc;
+    if ((rc = lm_alloc((void**)&h->sin_t, (size_t)h->n_ctx_pad * half * 4)) != RCA_OK) return rc;
+    lm_rope_table_kernel<<<cdiv((long)h->n_ctx_pad * half, 256), 256, 0, h->stream>>>(inv_dev, h->cos_t, h->sin_t, h->n_ctx_pad, half);
+    RCA_HIP(hipStreamSynchronize(h->stream));
+    (void)hipFree(inv_dev);
+    // KV cache
+    h->kv_layer_stride = (long)h->n_ctx_pad * c.n_kv_heads * c.head_dim;
+    const size_t kvb = (size_t)c.n_layers * h->kv_layer_stride * 2;
+    if ((rc = lm_alloc((void**)&h->kc, kvb)) != RCA_OK) return rc;
+    if ((rc = lm_alloc((void**)&h->vc, kvb)) != RCA_OK) return rc;
+    RCA_HIP(hipMemsetAsync(h->kc, 0, kvb, h->stream));
+    RCA_HIP(hipMemsetAsync(h->vc, 0, kvb, h->stream));
+    // activations
+    const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim;
+    h->ksplit_down = (c.ffn + LM_KSLICE - 1) / LM_KSLICE;
+    h->kslice_down = c.ffn <= LM_KSLICE ? c.ffn : LM_KSLICE;
+    if ((rc = lm_alloc((void**)&h->x, (size_t)LM_MAXM * H * 4)) != RCA_OK) return rc;
+    if ((rc = lm_alloc((void**)&h->xn, (size_t)LM_MAXM * H * 4)) != RCA_OK) return rc;
+    if ((rc = lm_alloc((void**)&h->qkv, (size_t)LM_MAXM * QKV * 4)) != RCA_OK) return rc;
+    if ((rc = lm_alloc((void**)&h->attn, (size_t)LM_MAXM * AO * 4)) != RCA_OK) return rc;
+    if ((rc = lm_alloc((void**)&h->part_o, (size_t)LM_MAXM * H * 4)) != RCA_OK) return rc;
+    if ((rc = lm_alloc((void**)&h->hbuf, (size_t)LM_MAXM * c.ffn * 4)) != RCA_OK) return rc;
+    if ((rc = lm_alloc((void**)&h->part_d, (size_t)LM_MAXSPLIT * LM_MAXM * H * 4)) != RCA_OK) return rc;
+    if ((rc = lm_alloc((void**)&h->att_part, (size_t)(LM_MAXM / 2) * c.n_kv_heads * h->n_splits * 8 * 66 * 4)) != RCA_OK) return rc;
+    h->logits_rows_cap = c.logits_all ? 64 : 1;
+    if ((rc = lm_alloc((void**)&h->logits, (size_t)h->logits_rows_cap * c.vocab_size * 4)) != RCA_OK) return rc;
+    if ((rc = lm_alloc((void**)&h->probs_dev, 64 * 4)) != RCA_OK) return rc;
+    if ((rc = lm_alloc((void**)&h->probe_ids_dev, 64 * 4)) != RCA_OK) return rc;
+    if ((rc = lm_alloc((void**)&h->stt, sizeof(LmDevState))) != RCA_OK) return rc;
+    if ((rc = lm_alloc((void**)&h->samp, sizeof(SamplerDev))) != RCA_OK) return rc;
+    RCA_HIP(hipMemsetAsync(h->stt, 0, sizeof(LmDevState), h->stream));
+    RCA_HIP(hipMemsetAsync(h->samp, 0, sizeof(SamplerDev), h->stream));
+    RCA_HIP(hipHostMalloc((void**)&h->h_stt, sizeof(LmDevState), hipHostMallocDefault));
+    memset(h->h_stt, 0, sizeof(LmDevState));
+    RCA_HIP(hipStreamSynchronize(h->stream));
+    return RCA_OK;
+}
+
+static int lm_new(const rca_lm_config_t* cfg, int device, rca_lm** out) {
+    int rc;
+    if ((rc = lm_check_cfg(cfg)) != RCA_OK) return rc;
+    RCA_HIP(hipSetDevice(device));
+    rca_lm* h = new rca_lm();
+    h->cfg = *cfg;
+    h->device = device;
+    h->layers.resize(cfg->n_layers);
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return fail(RCA_ERR_HIP, "stream create");
+    }
+    *out = h;
+    return RCA_OK;
+}
+
+extern "C" int rca_lm_create(const rca_lm_config_t* cfg, const rca_tensor_t* ts, int32_t nt, int32_t device, rca_lm_t** out) {
+    if (!ts || !out) return fail(RCA_ERR_ARG, "null argument");
+    rca_lm* h = nullptr;
+    int rc;
+    if ((rc = lm_new(cfg, device, &h)) != RCA_OK) return rc;
+    auto bail = [&](int code) { rca_lm_destroy(h); return code; };
+    const rca_lm_config_t& c = h->cfg;
+    const long H = c.hidden, V = c.vocab_size, F = c.ffn, Q = (long)c.n_heads * c.head_dim, KVD = (long)c.n_kv_heads * c.head_dim;
+    if ((rc = lm_upload_bf16(h, ts, nt, "model.embed_tokens.weight", V * H, &h->embed)) != RCA_OK) return bail(rc);
+    if ((rc = lm_upload_bf16(h, ts, nt, "lm_head.weight", V * H, &h->head)) != RCA_OK) return bail(rc);
+    if ((rc = lm_upload_f32(ts, nt, "model.norm.weight", H, &h->final_norm)) != RCA_OK) return bail(rc);
+    for (int l = 0; l < c.n_layers; ++l) {
+        const std::string p = "model.layers." + std::to_string(l) + ".";
+        LmLayer& L = h->layers[l];
+        bf16_t *q = nullptr, *k = nullptr, *v = nullptr, *g = nullptr, *u = nullptr;
+        auto free5 = [&]() { for (bf16_t* t : {q, k, v, g, u}) if (t) (void)hipFree(t); };
+        if ((rc = lm_upload_bf16(h, ts, nt, p + "self_attn.q_proj.weight", Q * H, &q)) != RCA_OK ||
+            (rc = lm_upload_bf16(h, ts, nt, p + "self_attn.k_proj.weight", KVD * H, &k)) != RCA_OK ||
+            (rc = lm_upload_bf16(h, ts, nt, p + "self_attn.v_proj.weight", KVD * H, &v)) != RCA_OK ||
+            (rc = lm_upload_bf16(h, ts, nt, p + "mlp.gate_proj.weight", F * H, &g)) != RCA_OK ||
+            (rc = lm_upload_bf16(h, ts, nt, p + "mlp.up_proj.weight", F * H, &u)) != RCA_OK) { free5(); return bail(rc); }
+        // fused layouts: [q; k; v] rows, and gate/up rows interleaved for the SwiGLU epilogue
+        if ((rc = lm_alloc((void**)&L.wqkv, (size_t)(Q + 2 * KVD) * H * 2)) != RCA_OK || (rc = lm_alloc((void**)&L.wgu, (size_t)2 * F * H * 2)) != RCA_OK) { free5(); return bail(rc); }
+        (void)hipMemcpyAsync(L.wqkv, q, Q * H * 2, hipMemcpyDeviceToDevice, h->stream);
+        (void)hipMemcpyAsync(L.wqkv + Q * H, k, KVD * H * 2, hipMemcpyDeviceToDevice, h->stream);
+        (void)hipMemcpyAsync(L.wqkv + (Q + KVD) * H, v, KVD * H * 2, hipMemcpyDeviceToDevice, h->stream);
+        lm_interleave_rows_kernel<<<cdiv(2 * F * H, 256), 256, 0, h->stream>>>(g, u, L.wgu, (int)F, (int)H);
+        hipError_t e = hipStreamSynchronize(h->stream);
+        free5();
+        if (e != hipSuccess) return bail(fail(RCA_ERR_HIP, "layer %d pack: %s", l, hipGetErrorString(e)));
+        if ((rc = lm_upload_bf16(h, ts, nt, p + "self_attn.o_proj.weight", H * Q, &L.wo)) != RCA_OK) return bail(rc);
+        if ((rc = lm_upload_bf16(h, ts, nt, p + "mlp.down_proj.weight", H * F, &L.wdown)) != RCA_OK) return bail(rc);
+        if ((rc = lm_upload_f32(ts, nt, p + "input_layernorm.weight", H, &L.attn_norm)) != RCA_OK) return bail(rc);
+        if ((rc = lm_upload_f32(ts, nt, p + "post_attention_layernorm.weight", H, &L.ffn_norm)) != RCA_OK) return bail(rc);
+    }
+    if ((rc = lm_common_init(h, ts, nt)) != RCA_OK) return bail(rc);
+    *out = h;
+    return RCA_OK;
+}
+
+extern "C" int rca_lm_create_random(const rca_lm_config_t* cfg, uint64_t seed, float init_std, int32_t device, rca_lm_t** out) {
+    if (!out) return fail(RCA_ERR_ARG, "null argument");
+    rca_lm* h = nullptr;
+    int rc;
+    if ((rc = lm_new(cfg, device, &h)) != RCA_OK) return rc;
+    auto bail = [&](int code) { rca_lm_destroy(h); return code; };
+    const rca_lm_config_t& c = h->cfg;
+    const long H = c.hidden, V = c.vocab_size, F = c.ffn, Q = (long)c.n_heads * c.head_dim, KVD = (long)c.n_kv_heads * c.head_dim;
+    const float scale = init_std * 1.7320508f / 65535.0f;
+    unsigned long long tid = 1;
+    auto rnd = [&](bf16_t** p, long n) -> int {
+        int r = lm_alloc((void**)p, (size_t)n * 2);
+        if (r != RCA_OK) return r;
+        lm_random_bf16_kernel<<<4096, 256, 0, h->stream>>>(*p, n, seed, tid++, scale);
+        return RCA_OK;
+    };
+    auto ones = [&](float** p, long n) -> int {
+        int r = lm_alloc((void**)p, (size_t)n * 4);
+        if (r != RCA_OK) return r;
+        lm_fill_f32_kernel<<<cdiv(n, 256), 256, 0, h->stream>>>(*p, n, 1.0f);
+        return RCA_OK;
+    };
+    // tensor ids: 1 embed, 2 head, then per layer 10*l + {3 qkv, 4 o, 5 gate/up(interleaved), 6 down}
+    if ((rc = rnd(&h->embed, V * H)) != RCA_OK || (rc = rnd(&h->head, V * H)) != RCA_OK || (rc = ones(&h->final_norm, H)) != RCA_OK) return bail(rc);
+    for (int l = 0; l < c.n_layers; ++l) {
+        LmLayer& L = h->layers[l];
+        tid = 10ull * (l + 1) + 3;
+        if ((rc = rnd(&L.wqkv, (Q + 2 * KVD) * H)) != RCA_OK || (rc = rnd(&L.wo, H * Q)) != RCA_OK || (rc = rnd(&L.wgu, 2 * F * H)) != RCA_OK ||
+            (rc = rnd(&L.wdown, H * F)) != RCA_OK || (rc = ones(&L.attn_norm, H)) != RCA_OK || (rc = ones(&L.ffn_norm, H)) != RCA_OK)
+            return bail(rc);
+    }
+    RCA_HIP(hipStreamSynchronize(h->stream));
+    if ((rc = lm_common_init(h, nullptr, 0)) != RCA_OK) return bail(rc);
+    *out = h;
+    return RCA_OK;
+}
+
+// ------------------------------------------------------------------------- forward pass (M tokens)
+template <int M>
+static void launch_gemv(rca_lm* h, const bf16_t* W, const float* x, float* y, int N, int K, int kslice, int nsl, long y_slice_stride,
+                        int ldy, int epi, int x_row_offset, hipStream_t st) {
+    // rows per workgroup: enough workgroups to fill 256 CUs several times over, multiples of 8
+    int rpw = 8;
+    while ((long)cdiv(N, rpw) * nsl > 4096 && rpw < 64) rpw *= 2;
+    dim3 grid(cdiv(N, rpw), nsl);
+    const size_t lds = (size_t)M * kslice * 4;
+    if (epi == 1) lm_gemv_kernel<M, 1><<<grid, 256, lds, st>>>(W, x, y, N, K, kslice, rpw, y_slice_stride, ldy, x_row_offset);
+    else lm_gemv_kernel<M, 0><<<grid, 256, lds, st>>>(W, x, y, N, K, kslice, rpw, y_slice_stride, ldy, x_row_offset);
+}
+static void gemv(rca_lm* h, int M, const bf16_t* W, const float* x, float* y, int N, int K, int kslice, int nsl, long yss, int ldy, int epi,
+                 int xro, hipStream_t st) {
+    switch (M) {
+        case 1: launch_gemv<1>(h, W, x, y, N, K, kslice, nsl, yss, ldy, epi, xro, st); break;
+        case 2: launch_gemv<2>(h, W, x, y, N, K, kslice, nsl, yss, ldy, epi, xro, st); break;
+        case 3: case 4: launch_gemv<4>(h, W, x, y, N, K, kslice, nsl, yss, ldy, epi, xro, st); break;
+        default: launch_gemv<8>(h, W, x, y, N, K, kslice, nsl, yss, ldy, epi, xro, st); break;
+    }
+}
+
+// Enqueue one pass over the M tokens whose ids / position are already in h->stt (device).
+// want_logits: 0 none, 1 last token only, 2 every token (logits_all).
+static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st) {
+    const rca_lm_config_t& c = h->cfg;
+    const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim, F = c.ffn;
+    const int G = c.n_heads / c.n_kv_heads;
+    const int Mt = M <= 2 ? M : (M <= 4 ? 4 : 8);  // template width (extra rows compute on stale-but-finite data, never stored to state)
+    const float scale = 1.0f / sqrtf((float)c.head_dim);
+    lm_embed_kernel<<<M, 256, 0, st>>>(h->stt, h->embed, h->x, H, c.vocab_size);
+    for (int l = 0; l < c.n_layers; ++l) {
+        const LmLayer& L = h->layers[l];
+        // residual add of the previous layer's down-projection partials is folded into this norm
+        lm_add_rmsnorm_kernel<<<M, 256, 0, st>>>(h->stt, h->x, h->part_d, l == 0 ? 0 : h->ksplit_down, (long)LM_MAXM * H, L.attn_norm, h->xn, H, c.rms_eps, 0);
+        gemv(h, Mt, L.wqkv, h->xn, h->qkv, QKV, H, H, 1, 0, QKV, 0, 0, st);
+        f16_t* kc = h->kc + (long)l * h->kv_layer_stride;
+        f16_t* vc = h->vc + (long)l * h->kv_layer_stride;
+        lm_rope_kv_kernel<<<M, 256, 0, st>>>(h->stt, h->qkv, h->cos_t, h->sin_t, kc, vc, c.n_heads, c.n_kv_heads, c.head_dim, c.n_ctx);
+        dim3 ag(c.n_kv_heads, h->n_splits, (M + 1) / 2);
+        if (G == 4) {
+            lm_attn_kernel<4><<<ag, 256, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale);
+            lm_attn_combine_kernel<4><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
+        } else if (G == 2) {
+            lm_attn_kernel<2><<<ag, 256, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale);
+            lm_attn_combine_kernel<2><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
+        } else {
+            lm_attn_kernel<1><<<ag, 256, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale);
+            lm_attn_combine_kernel<1><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
+        }
+        gemv(h, Mt, L.wo, h->attn, h->part_o, H, AO, AO, 1, 0, H, 0, 0, st);
+        lm_add_rmsnorm_kernel<<<M, 256, 0, st>>>(h->stt, h->x, h->part_o, 1, (long)LM_MAXM * H, L.ffn_norm, h->xn, H, c.rms_eps, 0);
+        gemv(h, Mt, L.wgu, h->xn, h->hbuf, 2 * F, H, H, 1, 0, F, 1, 0, st);
+        gemv(h, Mt, L.wdown, h->hbuf, h->part_d, H, F, h->kslice_down, h->ksplit_down, (long)LM_MAXM * H, H, 0, 0, st);
+    }
+    if (want_logits == 1) {
+        lm_add_rmsnorm_kernel<<<1, 256, 0, st>>>(h->stt, h->x, h->part_d, h->ksplit_down, (long)LM_MAXM * H, h->final_norm, h->xn, H, c.rms_eps, 1);
+        gemv(h, 1, h->head, h->xn, h->logits, c.vocab_size, H, H, 1, 0, c.vocab_size, 0, 0, st);
+    } else if (want_logits == 2) {
+        lm_add_rmsnorm_kernel<<<M, 256, 0, st>>>(h->stt, h->x, h->part_d, h->ksplit_down, (long)LM_MAXM * H, h->final_norm, h->xn, H, c.rms_eps, 0);
+        gemv(h, Mt, h->head, h->xn, h->logits, c.vocab_size, H, H, 1, 0, c.vocab_size, 0, 0, st);
+    }
+    lm_advance_kernel<<<1, 1, 0, st>>>(h->stt);
+    RCA_LAUNCH_CHECK();
+    return RCA_OK;
+}
+
+static int lm_push_state(rca_lm* h, const int32_t* ids, int m, hipStream_t st) {
+    h->h_stt->n_tokens = h->n_tokens;
+    h->h_stt->m = m;
+    for (int i = 0; i < m; ++i) h->h_stt->ids[i] = ids[i];
+    // n_tokens, m, ids only (first 8 + 4*LM_MAXM bytes); rng counter / out_token stay device-owned
+    RCA_HIP(hipMemcpyAsync(h->stt, h->h_stt, 8 + 4 * LM_MAXM, hipMemcpyHostToDevice, st));
+    return RCA_OK;
+}
+
+extern "C" int rca_lm_reset(rca_lm_t* h) {
+    if (!h) return fail(RCA_ERR_ARG, "null");
+    h->n_tokens = 0;
+    h->logits_rows = 0;
+    return RCA_OK;
+}
+extern "C" int rca_lm_get_n_tokens(const rca_lm_t* h, int32_t* n) {
+    if (!h || !n) return fail(RCA_ERR_ARG, "null");
+    *n = h->n_tokens;
+    return RCA_OK;
+}
+extern "C" int rca_lm_set_n_tokens(rca_lm_t* h, int32_t n) {
+    if (!h) return fail(RCA_ERR_ARG, "null");
+    if (n < 0 || n > h->cfg.n_ctx) return fail(RCA_ERR_ARG, "n_tokens %d outside [0, %d]", n, h->cfg.n_ctx);
+    h->n_tokens = n;
+    return RCA_OK;
+}
+extern "C" int rca_lm_sync(rca_lm_t* h) {
+    if (!h) return fail(RCA_ERR_ARG, "null");
+    RCA_HIP(hipSetDevice(h->device));
+    RCA_HIP(hipStreamSynchronize(h->stream));
+    return RCA_OK;
+}
+
+extern "C" int rca_lm_eval(rca_lm_t* h, const int32_t* ids, int32_t n) {
+    if (!h || (!ids && n > 0) || n < 0) return fail(RCA_ERR_ARG, "eval: bad argument");
+    if (n == 0) return RCA_OK;
+    if (h->n_tokens + n > h->cfg.n_ctx) return fail(RCA_ERR_STATE, "context overflow: %d + %d > n_ctx %d", h->n_tokens, n, h->cfg.n_ctx);
+    RCA_HIP(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    int rc;
+    const bool all = h->cfg.logits_all != 0;
+    if (all && n > h->logits_rows_cap) {
+        RCA_HIP(hipStreamSynchronize(st));
+        (void)hipFree(h->logits);
+        h->logits = nullptr;
+        h->logits_rows_cap = n;
+        if ((rc = lm_alloc((void**)&h->logits, (size_t)n * h->cfg.vocab_size * 4)) != RCA_OK) return rc;
+    }
+    float* logits_base = h->logits;
+    for (int off = 0; off < n; off += LM_MAXM) {
+        const int m = std::min(LM_MAXM, n - off);
+        const bool last = off + m >= n;
+        if ((rc = lm_push_state(h, ids + off, m, st)) != RCA_OK) return rc;
+        if (all) h->logits = logits_base + (long)off * h->cfg.vocab_size;
+        rc = lm_enqueue_pass(h, m, all ? 2 : (last ? 1 : 0), st);
+        h->logits = logits_base;
+        if (rc != RCA_OK) return rc;
+        h->n_tokens += m;
+        // the pinned staging block is reused by the next chunk: wait until this one's copy has been consumed
+        if (!last) RCA_HIP(hipStreamSynchronize(st));
+    }
+    h->logits_rows = all ? n : 1;
+    RCA_HIP(hipStreamSynchronize(st));
+    return RCA_OK;
+}
+
+extern "C" int rca_lm_logits_dev(rca_lm_t* h, const float** out) {
+    if (!h || !out) return fail(RCA_ERR_ARG, "null");
+    if (h->logits_rows < 1) return fail(RCA_ERR_STATE, "no logits: call eval first");
+    *out = h->logits + (long)(h->logits_rows - 1) * h->cfg.vocab_size;
+    return RCA_OK;
+}
+extern "C" int rca_lm_get_logits(rca_lm_t* h, float* out_host) {
+    if (!h || !out_host) return fail(RCA_ERR_ARG, "null");
+    const float* src;
+    int rc;
+    if ((rc = rca_lm_logits_dev(h, &src)) != RCA_OK) return rc;
+    RCA_HIP(hipSetDevice(h->device));
+    RCA_HIP(hipMemcpyAsync(out_host, src, (size_t)h->cfg.vocab_size * 4, hipMemcpyDeviceToHost, h->stream));
+    RCA_HIP(hipStreamSynchronize(h->stream));
+    return RCA_OK;
+}
+extern "C" int rca_lm_get_logits_row(rca_lm_t* h, int32_t row, float* out_host) {
+    if (!h || !out_host) return fail(RCA_ERR_ARG, "null");
+    if (row < 0 || row >= h->logits_rows) return fail(RCA_ERR_ARG, "row %d outside the %d rows of the last eval", row, h->logits_rows);
+    RCA_HIP(hipSetDevice(h->device));
+    RCA_HIP(hipMemcpyAsync(out_host, h->logits + (long)row * h->cfg.vocab_size, (size_t)h->cfg.vocab_size * 4, hipMemcpyDeviceToHost, h->stream));
+    RCA_HIP(hipStreamSynchronize(h->stream));
+    return RCA_OK;
+}
+
+extern "C" int rca_lm_sampler_init(rca_lm_t* h, const rca_sampler_params_t* p) {
+    if (!h || !p) return fail(RCA_ERR_ARG, "null");
+    if (p->n_bias < 0 || p->n_bias > 8) return fail(RCA_ERR_ARG, "at most 8 logit-bias entries");
+    RCA_HIP(hipSetDevice(h->device));
+    SamplerDev s;
+    memset(&s, 0, sizeof(s));
+    s.top_k = p->top_k; s.top_p = p->top_p; s.min_p = p->min_p; s.temp = p->temp; s.seed = p->seed; s.n_bias = p->n_bias;
+    for (int i = 0; i < p->n_bias; ++i) { s.bias_ids[i] = p->bias_ids[i]; s.bias_vals[i] = p->bias_vals[i]; }
+    RCA_HIP(hipStreamSynchronize(h->stream));
+    RCA_HIP(hipMemcpy(h->samp, &s, sizeof(s), hipMemcpyHostToDevice));
+    // set_seed restarts the stream of draws (llamacpp_utils.py:58)
+    const unsigned long long zero = 0;
+    RCA_HIP(hipMemcpy(&h->stt->rng_counter, &zero, 8, hipMemcpyHostToDevice));
+    h->sampler_set = true;
+    return RCA_OK;
+}
+
+static int lm_fetch_token(rca_lm* h, int32_t* token, hipStream_t st) {
+    RCA_HIP(hipMemcpyAsync(&h->h_stt->out_token, &h->stt->out_token, 4, hipMemcpyDeviceToHost, st));
+    RCA_HIP(hipStreamSynchronize(st));
+    *token = h->h_stt->out_token;
+    return RCA_OK;
+}
+
+extern "C" int rca_lm_sample(rca_lm_t* h, int32_t* token) {
+    if (!h || !token) return fail(RCA_ERR_ARG, "null");
+    if (!h->sampler_set) return fail(RCA_ERR_STATE, "sampler not initialised");
+    if (h->logits_rows < 1) return fail(RCA_ERR_STATE, "no logits: call eval first");
+    RCA_HIP(hipSetDevice(h->device));
+    const float* lg = h->logits + (long)(h->logits_rows - 1) * h->cfg.vocab_size;
+    lm_sample_kernel<<<1, 1024, 0, h->stream>>>(lg, h->cfg.vocab_size, h->samp, h->stt, 0);
+    RCA_LAUNCH_CHECK();
+    return lm_fetch_token(h, token, h->stream);
+}
+
+// eval(ids[0..n)) + sample with no host round trip in between.  For n <= 2 and a plain (not
+// logits_all) handle the whole step is one hipGraph replay.
+extern "C" int rca_lm_step(rca_lm_t* h, const int32_t* ids, int32_t n, int32_t* token) {
+    if (!h || !ids || !token || n < 1) return fail(RCA_ERR_ARG, "step: bad argument");
+    if (!h->sampler_set) return fail(RCA_ERR_STATE, "sampler not initialised");
+    if (h->n_tokens + n > h->cfg.n_ctx) return fail(RCA_ERR_STATE, "context overflow: %d + %d > n_ctx %d", h->n_tokens, n, h->cfg.n_ctx);
+    RCA_HIP(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    int rc;
+    if (n > 2 || h->cfg.logits_all || !h->graphs_enabled) {
+        if ((rc = rca_lm_eval(h, ids, n)) != RCA_OK) return rc;
+        return rca_lm_sample(h, token);
+    }
+    // stage inputs in pinned memory; the graph's first node copies them to the device
+    h->h_stt->n_tokens = h->n_tokens;
+    h->h_stt->m = n;
+    for (int i = 0; i < n; ++i) h->h_stt->ids[i] = ids[i];
+    if (!h->graph[n]) {
+        hipGraph_t g = nullptr;
+        RCA_HIP(hipStreamSynchronize(st));
+        RCA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        hipError_t e = hipMemcpyAsync(h->stt, h->h_stt, 8 + 4 * LM_MAXM, hipMemcpyHostToDevice, st);
+        rc = e == hipSuccess ? lm_enqueue_pass(h, n, 1, st) : fail(RCA_ERR_HIP, "capture memcpy: %s", hipGetErrorString(e));
+        if (rc == RCA_OK) {
+            lm_sample_kernel<<<1, 1024, 0, st>>>(h->logits, h->cfg.vocab_size, h->samp, h->stt, 0);
+            e = hipMemcpyAsync(&h->h_stt->out_token, &h->stt->out_token, 4, hipMemcpyDeviceToHost, st);
+            if (e != hipSuccess) rc = fail(RCA_ERR_HIP, "capture d2h: %s", hipGetErrorString(e));
+        }
+        hipError_t e2 = hipStreamEndCapture(st, &g);
+        if (rc != RCA_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (e2 != hipSuccess) return fail(RCA_ERR_HIP, "end capture: %s", hipGetErrorString(e2));
+        e2 = hipGraphInstantiate(&h->graph[n], g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e2 != hipSuccess) { h->graph[n] = nullptr; return fail(RCA_ERR_HIP, "graph instantiate: %s", hipGetErrorString(e2)); }
+    }
+    RCA_HIP(hipGraphLaunch(h->graph[n], st));
+    RCA_HIP(hipStreamSynchronize(st));
+    h->n_tokens += n;
+    h->logits_rows = 1;
+    *token = h->h_stt->out_token;
+    return RCA_OK;
+}
+
+extern "C" int rca_lm_token_probs(rca_lm_t* h, const int32_t* token_ids, int32_t n, float* probs_out) {
+    if (!h || !token_ids || !probs_out || n < 1 || n > 64) return fail(RCA_ERR_ARG, "token_probs: 1..64 ids");
+    if (h->logits_rows < 1) return fail(RCA_ERR_STATE, "no logits: call eval first");
+    RCA_HIP(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    RCA_HIP(hipMemcpyAsync(h->probe_ids_dev, token_ids, n * 4, hipMemcpyHostToDevice, st));
+    const float* lg = h->logits + (long)(h->logits_rows - 1) * h->cfg.vocab_size;
+    lm_token_probs_kernel<<<1, 1024, 0, st>>>(lg, h->cfg.vocab_size, h->probe_ids_dev, n, h->probs_dev);
+    RCA_LAUNCH_CHECK();
+    RCA_HIP(hipMemcpyAsync(probs_out, h->probs_dev, n * 4, hipMemcpyDeviceToHost, st));
+    RCA_HIP(hipStreamSynchronize(st));
+    return RCA_OK;
+}
+
+// test / bench knob: disable graph replay (eager launches) to compare
+extern "C" int rca_lm_set_graphs(rca_lm_t* h, int32_t enable) {
+    if (!h) return fail(RCA_ERR_ARG, "null");
+    h->graphs_enabled = enable != 0;
+    return RCA_OK;
+}

@@ -1,0 +1,427 @@
+"""LlamaForAlternatingCodeChannels -- the LM step object of the duplex loop.
+
+Same control surface as the reference subclass of llama_cpp.Llama
+(realtime_codec_agent/utils/llamacpp_utils.py:26-181) for every member the agent uses
+(SURVEY.md 8b-3): reset, eval, generate(tokens, reset=False), sample, read/WRITE n_tokens,
+init_sampler_for_generate, set_seed, get_logprobs, logits_to_logprobs, _ctx.get_logits(),
+_n_vocab, _scores, model_path, n_ctx().  The forward pass, KV cache and sampler live behind the
+C ABI (include/rca.h, rca_lm_*) as HIP kernels; there is no CPU fallback.
+
+The model is a vanilla Llama (codec_llama.py after persist_codec_embeddings, codec_llama.py:178-206).
+`model_path` may name a directory holding config.json + *.safetensors, an .npz written by
+`save_npz`, or the literal "random:<name>" for seeded random-init weights generated on the device
+(bench configs 3/4: no checkpoint exists offline).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import math
+import os
+from dataclasses import asdict, dataclass
+from typing import Dict, Generator, List, Optional, Sequence
+
+import numpy as np
+
+from . import _native as N
+
+
+@dataclass
+class LMConfig:
+    vocab_size: int = 259344
+    hidden: int = 2048
+    n_layers: int = 16
+    n_heads: int = 32
+    n_kv_heads: int = 8
+    head_dim: int = 64
+    ffn: int = 8192
+    rms_eps: float = 1e-5
+    rope_theta: float = 500000.0
+    rope_scaling: Optional[str] = "llama3"  # None | "llama3"
+    rope_factor: float = 32.0
+    rope_low_freq_factor: float = 1.0
+    rope_high_freq_factor: float = 4.0
+    rope_orig_ctx: int = 8192
+
+    @staticmethod
+    def llama_3_2_1b(vocab_size: int = 259344) -> "LMConfig":
+        """Llama-3.2-1B dims with the codec vocabulary."""
+        return LMConfig(vocab_size=vocab_size)
+
+    @staticmethod
+    def from_hf(d: dict) -> "LMConfig":
+        rp = d.get("rope_parameters") or d.get("rope_scaling") or {}
+        theta = rp.get("rope_theta", d.get("rope_theta", 10000.0))
+        rtype = rp.get("rope_type", rp.get("type", "default"))
+        nh = d["num_attention_heads"]
+        return LMConfig(
+            vocab_size=d["vocab_size"], hidden=d["hidden_size"], n_layers=d["num_hidden_layers"], n_heads=nh,
+            n_kv_heads=d.get("num_key_value_heads", nh), head_dim=d.get("head_dim") or d["hidden_size"] // nh,
+            ffn=d["intermediate_size"], rms_eps=d.get("rms_norm_eps", 1e-5), rope_theta=float(theta),
+            rope_scaling="llama3" if rtype == "llama3" else None, rope_factor=float(rp.get("factor", 32.0)),
+            rope_low_freq_factor=float(rp.get("low_freq_factor", 1.0)), rope_high_freq_factor=float(rp.get("high_freq_factor", 4.0)),
+            rope_orig_ctx=int(rp.get("original_max_position_embeddings", 8192)),
+        )
+
+    def n_params(self) -> int:
+        per_layer = self.hidden * (self.n_heads + 2 * self.n_kv_heads) * self.head_dim + self.n_heads * self.head_dim * self.hidden \
+            + 3 * self.hidden * self.ffn
+        return self.n_layers * per_layer + 2 * self.vocab_size * self.hidden
+
+    def weight_bytes_per_step(self) -> int:
+        """bf16 bytes streamed by one decode step: all layer weights + lm_head (embedding rows are gathered)."""
+        return 2 * (self.n_params() - self.vocab_size * self.hidden)
+
+
+def rope_inv_freq(cfg: LMConfig) -> np.ndarray:
+    """inv_freq exactly as transformers computes it in float32 (default and llama3 scaling)."""
+    import torch
+    dim = cfg.head_dim
+    inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, dim, 2, dtype=torch.int64).to(dtype=torch.float) / dim))
+    if cfg.rope_scaling == "llama3":
+        factor, low, high, old = cfg.rope_factor, cfg.rope_low_freq_factor, cfg.rope_high_freq_factor, cfg.rope_orig_ctx
+        low_wl, high_wl = old / low, old / high
+        wl = 2 * math.pi / inv
+        inv_l = torch.where(wl > low_wl, inv / factor, inv)
+        smooth = (old / wl - low) / (high - low)
+        smoothed = (1 - smooth) * inv_l / factor + smooth * inv_l
+        medium = ~(wl < high_wl) * ~(wl > low_wl)
+        inv = torch.where(medium, smoothed, inv_l)
+    return inv.numpy().astype(np.float32)
+
+
+def f32_to_bf16_bits(a: np.ndarray) -> np.ndarray:
+    """float32 -> bf16 bit pattern (round to nearest even) as uint16."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def bf16_bits_to_f32(b: np.ndarray) -> np.ndarray:
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def lm_tensor_names(cfg: LMConfig) -> List[str]:
+    names = ["model.embed_tokens.weight", "model.norm.weight", "lm_head.weight"]
+    for l in range(cfg.n_layers):
+        p = f"model.layers.{l}."
+        names += [p + s for s in ("self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
+                                  "self_attn.o_proj.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight",
+                                  "input_layernorm.weight", "post_attention_layernorm.weight")]
+    return names
+
+
+def save_npz(path: str, cfg: LMConfig, weights: Dict[str, np.ndarray]) -> None:
+    np.savez(path, __config__=np.array(json.dumps(asdict(cfg))), **{k: v for k, v in weights.items()})
+
+
+def load_weights(model_path: str):
+    """-> (LMConfig, {name: ndarray}) from an .npz (save_npz) or an HF directory with safetensors."""
+    if model_path.endswith(".npz"):
+        z = np.load(model_path)
+        cfg = LMConfig(**json.loads(str(z["__config__"])))
+        return cfg, {k: z[k] for k in z.files if k != "__config__"}
+    d = model_path if os.path.isdir(model_path) else os.path.dirname(model_path)
+    with open(os.path.join(d, "config.json")) as f:
+        cfg = LMConfig.from_hf(json.load(f))
+    from safetensors import safe_open
+    import torch
+    weights = {}
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith(".safetensors"):
+            with safe_open(os.path.join(d, fn), framework="pt") as sf:
+                for k in sf.keys():
+                    t = sf.get_tensor(k)
+                    if t.dtype == torch.bfloat16:
+                        weights[k] = t.view(torch.int16).numpy().view(np.uint16)
+                    else:
+                        weights[k] = t.float().numpy()
+    if "lm_head.weight" not in weights:  # tied checkpoints
+        weights["lm_head.weight"] = weights["model.embed_tokens.weight"]
+    return cfg, weights
+
+
+class _Ctx:
+    """llm._ctx.get_logits(): a C float* over the last logits (realtime_agent_v2.py:449,461)."""
+
+    def __init__(self, llm: "LlamaForAlternatingCodeChannels"):
+        self._llm = llm
+
+    def get_logits(self):
+        buf = self._llm._fetch_logits()
+        return buf.ctypes.data_as(C.POINTER(C.c_float))
+
+    def kv_cache_seq_rm(self, seq_id: int, p0: int, p1: int) -> None:
+        # stale slots are simply overwritten by the next eval
+        return None
+
+
+class LlamaForAlternatingCodeChannels:
+    def __init__(
+        self,
+        model_path: Optional[str] = None,
+        n_ctx: int = 16384,
+        n_gpu_layers: int = -1,
+        verbose: bool = False,
+        flash_attn: bool = True,
+        logits_all: bool = False,
+        seed: int = 0xFFFFFFFF,
+        *,
+        config: Optional[LMConfig] = None,
+        weights: Optional[Dict[str, np.ndarray]] = None,
+        device: Optional[int] = None,
+        random_seed: int = 0,
+        init_std: float = 0.02,
+        **_ignored,
+    ):
+        self._lib = N.lib()
+        self.model_path = model_path
+        self.verbose = verbose
+        self.draft_model = None
+        self._logits_all = bool(logits_all)
+        if device is None:
+            import torch
+            if not torch.cuda.is_available():
+                raise N.RcaError("LlamaForAlternatingCodeChannels needs a GPU; there is no CPU fallback")
+            device = torch.cuda.current_device()
+        self._device = device
+        random_init = weights is None and (model_path is None or str(model_path).startswith("random:"))
+        if weights is None and not random_init:
+            config, weights = load_weights(model_path)
+        if config is None:
+            config = LMConfig.llama_3_2_1b()
+        self.config = config
+        self._n_vocab = config.vocab_size
+        self._n_ctx = int(n_ctx)
+        c = N.LMConfigC(
+            vocab_size=config.vocab_size, hidden=config.hidden, n_layers=config.n_layers, n_heads=config.n_heads,
+            n_kv_heads=config.n_kv_heads, head_dim=config.head_dim, ffn=config.ffn, n_ctx=self._n_ctx, rms_eps=config.rms_eps,
+            rope_theta=config.rope_theta, rope_scaling=1 if config.rope_scaling == "llama3" else 0, rope_factor=config.rope_factor,
+            rope_low_freq_factor=config.rope_low_freq_factor, rope_high_freq_factor=config.rope_high_freq_factor,
+            rope_orig_ctx=config.rope_orig_ctx, logits_all=1 if logits_all else 0,
+        )
+        self._h = C.c_void_p()
+        if random_init:
+            N.check(self._lib.rca_lm_create_random(C.byref(c), C.c_uint64(random_seed), C.c_float(init_std), device, C.byref(self._h)),
+                    "rca_lm_create_random")
+        else:
+            w = dict(weights)
+            w["rope.inv_freq"] = rope_inv_freq(config)
+            tensors, keep = N.make_tensors(w)
+            N.check(self._lib.rca_lm_create(C.byref(c), tensors, len(w), device, C.byref(self._h)), "rca_lm_create")
+            del keep
+        self._ctx = _Ctx(self)
+        self._input_ids = np.zeros(self._n_ctx, dtype=np.intc)
+        self.input_ids = self._input_ids
+        self._logits_host = np.zeros(self._n_vocab, dtype=np.float32)
+        self._logits_valid = False
+        self._sampler = None
+        self._seed = seed
+        self._sampler_params = None
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.rca_lm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ llama_cpp.Llama surface
+    def n_ctx(self) -> int:
+        return self._n_ctx
+
+    def n_vocab(self) -> int:
+        return self._n_vocab
+
+    @property
+    def n_tokens(self) -> int:
+        n = C.c_int32()
+        N.check(self._lib.rca_lm_get_n_tokens(self._h, C.byref(n)), "rca_lm_get_n_tokens")
+        return n.value
+
+    @n_tokens.setter
+    def n_tokens(self, value: int) -> None:
+        # the agent rolls the KV cache back by assigning n_tokens (realtime_agent_v2.py:208,219,261,465,730)
+        N.check(self._lib.rca_lm_set_n_tokens(self._h, int(value)), "rca_lm_set_n_tokens")
+
+    def reset(self) -> None:
+        N.check(self._lib.rca_lm_reset(self._h), "rca_lm_reset")
+        self._logits_valid = False
+
+    def set_seed(self, seed: int) -> None:
+        self._seed = seed & 0xFFFFFFFF
+
+    def eval(self, tokens: Sequence[int]) -> None:
+        tokens = list(tokens)
+        if not tokens:
+            return
+        n0 = self.n_tokens
+        arr = (C.c_int32 * len(tokens))(*tokens)
+        N.check(self._lib.rca_lm_eval(self._h, arr, len(tokens)), "rca_lm_eval")
+        self._input_ids[n0:n0 + len(tokens)] = tokens
+        self._logits_valid = False
+
+    def _fetch_logits(self) -> np.ndarray:
+        if not self._logits_valid:
+            N.check(self._lib.rca_lm_get_logits(self._h, C.c_void_p(self._logits_host.ctypes.data)), "rca_lm_get_logits")
+            self._logits_valid = True
+        return self._logits_host
+
+    @property
+    def _scores(self) -> np.ndarray:
+        """Rows of logits of the last eval call (all of them for logits_all handles, else the last)."""
+        rows = []
+        r = 0
+        while True:
+            buf = np.empty(self._n_vocab, np.float32)
+            rc = self._lib.rca_lm_get_logits_row(self._h, r, C.c_void_p(buf.ctypes.data))
+            if rc != 0:
+                break
+            rows.append(buf)
+            r += 1
+        return np.stack(rows) if rows else np.zeros((0, self._n_vocab), np.float32)
+
+    @property
+    def scores(self) -> np.ndarray:
+        return self._scores
+
+    @staticmethod
+    def logits_to_logprobs(logits: np.ndarray, axis: int = -1) -> np.ndarray:
+        logits = np.asarray(logits, dtype=np.float32)
+        mx = np.max(logits, axis=axis, keepdims=True)
+        shifted = logits - mx
+        return shifted - np.log(np.sum(np.exp(shifted), axis=axis, keepdims=True))
+
+    def get_logprobs(self, ctx_input_ids, input_ids):
+        """llamacpp_utils.py:30-37: log p(input_ids[i] | ctx, input_ids[:i]) on a logits_all handle."""
+        if not self._logits_all:
+            raise N.RcaError("get_logprobs needs a handle created with logits_all=True")
+        self.reset()
+        self.eval(ctx_input_ids)
+        last_ctx = self._scores[-1]
+        self.eval(input_ids)
+        logits = np.concatenate([last_ctx[None, :], self._scores], axis=0)[-len(input_ids) - 1:-1]
+        logprobs = self.logits_to_logprobs(logits)
+        return logprobs[range(len(input_ids)), list(input_ids)]
+
+    def init_sampler_for_generate(
+        self,
+        top_k: int = 40,
+        top_p: float = 0.95,
+        min_p: float = 0.05,
+        typical_p: float = 1.0,
+        temp: float = 0.80,
+        repeat_penalty: float = 1.0,
+        frequency_penalty: float = 0.0,
+        presence_penalty: float = 0.0,
+        tfs_z: float = 1.0,
+        mirostat_mode: int = 0,
+        mirostat_tau: float = 5.0,
+        mirostat_eta: float = 0.1,
+        penalize_nl: bool = True,
+        logits_processor=None,
+        grammar=None,
+        seed: Optional[int] = None,
+        logit_bias: Optional[Dict[int, float]] = None,
+    ) -> None:
+        """llamacpp_utils.py:39-77.  Supported chain: logit bias -> top_k -> top_p -> min_p -> temp -> dist
+        (the only members the agent configures, realtime_agent_v2.py:172-185); penalties must be neutral."""
+        if repeat_penalty != 1.0 or frequency_penalty != 0.0 or presence_penalty != 0.0 or typical_p != 1.0 or mirostat_mode != 0 or grammar is not None:
+            raise NotImplementedError("only the sampler members the duplex agent uses are implemented")
+        self.set_seed(seed if seed is not None else -1)
+        bias = dict(logit_bias or {})
+        if logits_processor is not None:
+            lb = getattr(logits_processor, "logit_bias_map", None)
+            if lb is None:
+                raise NotImplementedError("logits_processor must come from get_logits_bias_processor")
+            bias.update(lb)
+        ids = (C.c_int32 * max(1, len(bias)))(*bias.keys())
+        vals = (C.c_float * max(1, len(bias)))(*bias.values())
+        p = N.SamplerParamsC(top_k=int(top_k), top_p=float(top_p), min_p=float(min_p), temp=float(temp), seed=self._seed,
+                             n_bias=len(bias), bias_ids=ids, bias_vals=vals)
+        N.check(self._lib.rca_lm_sampler_init(self._h, C.byref(p)), "rca_lm_sampler_init")
+        self._sampler = True
+        self._sampler_params = dict(top_k=top_k, top_p=top_p, min_p=min_p, temp=temp, seed=self._seed, logit_bias=bias)
+
+    def sample(self, idx: Optional[int] = None) -> int:
+        assert self.n_tokens > 0
+        assert self._sampler is not None
+        tok = C.c_int32()
+        N.check(self._lib.rca_lm_sample(self._h, C.byref(tok)), "rca_lm_sample")
+        return tok.value
+
+    def step(self, tokens: Sequence[int]) -> int:
+        """eval(tokens) + sample() in one C-ABI call (hipGraph replay for 1-2 tokens)."""
+        tokens = list(tokens)
+        n0 = self.n_tokens
+        arr = (C.c_int32 * len(tokens))(*tokens)
+        tok = C.c_int32()
+        N.check(self._lib.rca_lm_step(self._h, arr, len(tokens), C.byref(tok)), "rca_lm_step")
+        self._input_ids[n0:n0 + len(tokens)] = tokens
+        self._logits_valid = False
+        return tok.value
+
+    def generate(self, tokens: Sequence[int], reset: bool = True, stopping_criteria=None) -> Generator[int, Optional[Sequence[int]], None]:
+        """llamacpp_utils.py:97-181.  The agent always calls next(generate(ids, reset=False)) and drops the
+        generator, so the first yield is the fused step; continuing the generator keeps sampling."""
+        tokens = list(tokens)
+        if reset and self.n_tokens > 0:
+            longest_prefix = 0
+            for a, b in zip(self._input_ids[: self.n_tokens], tokens[:-1]):
+                if a == b:
+                    longest_prefix += 1
+                else:
+                    break
+            if longest_prefix > 0:
+                reset = False
+                tokens = tokens[longest_prefix:]
+                self.n_tokens = longest_prefix
+        if reset:
+            self.reset()
+        while True:
+            token = self.step(tokens)
+            if stopping_criteria is not None and stopping_criteria(self._input_ids[: self.n_tokens], self._fetch_logits()):
+                return
+            tokens_or_none = yield token
+            tokens = [token]
+            if tokens_or_none is not None:
+                tokens.extend(tokens_or_none)
+
+    def token_probs(self, token_ids: Sequence[int]) -> np.ndarray:
+        """softmax(last logits)[ids], reduced on the device (measure_event_prob, realtime_agent_v2.py:448-452)."""
+        ids = (C.c_int32 * len(token_ids))(*token_ids)
+        out = (C.c_float * len(token_ids))()
+        N.check(self._lib.rca_lm_token_probs(self._h, ids, len(token_ids), out), "rca_lm_token_probs")
+        return np.array(out[:], dtype=np.float32)
+
+    def sync(self) -> None:
+        N.check(self._lib.rca_lm_sync(self._h), "rca_lm_sync")
+
+    def set_graphs(self, enable: bool) -> None:
+        N.check(self._lib.rca_lm_set_graphs(self._h, 1 if enable else 0), "rca_lm_set_graphs")
+
+
+class _LogitBiasProcessorList(list):
+    """Return type of get_logits_bias_processor: a one-element processor list that also exposes the
+    bias map so the device sampler can apply it (the llama.cpp path copies the whole logits array on the
+    host per step, llamacpp_utils.py:13-22)."""
+    logit_bias_map: Dict[int, float] = {}
+
+
+def get_logits_bias_processor(logit_bias: Dict[int, float]):
+    """llamacpp_utils.py:8-24."""
+    logit_bias_map = {int(k): float(v) for k, v in logit_bias.items()}
+
+    def logit_bias_processor(input_ids, scores):
+        new_scores = np.copy(scores)
+        for input_id, score in logit_bias_map.items():
+            new_scores[input_id] = score + scores[input_id]
+        return new_scores
+
+    out = _LogitBiasProcessorList([logit_bias_processor])
+    out.logit_bias_map = logit_bias_map
+    return out
