@@ -715,10 +715,20 @@ static int lm_upload_bf16(rca_lm* h, const rca_tensor_t* ts, int nt, const std::
 static int lm_upload_f32(const rca_tensor_t* ts, int nt, const std::string& name, long numel, float** out) {
     const rca_tensor_t* t = find_tensor(ts, nt, name);
     if (!t) return fail(RCA_ERR_MISSING, "tensor '%s' missing", name.c_str());
-    if (t->numel != numel || t->dtype != RCA_F32) return fail(RCA_ERR_ARG, "tensor '%s': want %ld f32 values", name.c_str(), numel);
+    if (t->numel != numel) return fail(RCA_ERR_ARG, "tensor '%s': numel %ld, expected %ld", name.c_str(), (long)t->numel, numel);
     int rc;
     if ((rc = lm_alloc((void**)out, (size_t)numel * 4)) != RCA_OK) return rc;
-    RCA_HIP(hipMemcpy(*out, t->data, (size_t)numel * 4, hipMemcpyHostToDevice));
+    if (t->dtype == RCA_BF16) {  // small tensors (norm weights): widen on the host
+        std::vector<float> tmp((size_t)numel);
+        const bf16_t* src = (const bf16_t*)t->data;
+        for (long i = 0; i < numel; ++i) {
+            const unsigned u = (unsigned)src[i] << 16;
+            memcpy(&tmp[i], &u, 4);
+        }
+        RCA_HIP(hipMemcpy(*out, tmp.data(), (size_t)numel * 4, hipMemcpyHostToDevice));
+    } else {
+        RCA_HIP(hipMemcpy(*out, t->data, (size_t)numel * 4, hipMemcpyHostToDevice));
+    }
     return RCA_OK;
 }
 
