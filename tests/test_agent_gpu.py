@@ -1,0 +1,61 @@
+"""End-to-end duplex loop on the GPU: the real HIP AudioTokenizer + HIP LM under RealtimeAgent."""
+import numpy as np
+import pytest
+
+from conftest import rich_signal
+
+pytestmark = pytest.mark.gpu
+
+
+def make_agent(chunk=0.08, **cfg_kw):
+    from realtime_codec_agent_amd.llm import LMConfig
+    from realtime_codec_agent_amd.realtime_agent_config import RealtimeAgentConfig
+    from realtime_codec_agent_amd.realtime_agent_resources import RealtimeAgentResources
+    from realtime_codec_agent_amd.realtime_agent_v2 import RealtimeAgent
+    lm = LMConfig(vocab_size=259344, hidden=256, n_layers=2, n_heads=4, n_kv_heads=2, head_dim=64, ffn=512)
+    res = RealtimeAgentResources(llm_model_path="random:small", llm_n_ctx=4096, llm_config=lm, with_aux_llm=False, llm_random_seed=3)
+    cfg = RealtimeAgentConfig(chunk_size_secs=chunk, use_whisper=False, force_trans_after_inactivity_secs=0.0,
+                              force_response_after_inactivity_secs=0.0, **cfg_kw)
+    return RealtimeAgent(resources=res, config=cfg), res
+
+
+def test_duplex_loop_end_to_end_and_deterministic():
+    sig = rich_signal(16000 * 2, 4)
+    runs = []
+    for _ in range(2):
+        agent, res = make_agent()
+        outs = [agent.process_audio(sig[s:s + 1280]) for s in range(0, len(sig) - 1279, 1280)]
+        assert all(o.shape == (1280,) and np.isfinite(o).all() for o in outs)
+        runs.append((list(agent.input_ids), np.concatenate(outs)))
+        summ = agent.profilers.summary()
+        assert summ["total"]["p50"] is not None
+    # seeded sampler + bit-stable kernels: the whole session is reproducible
+    assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1])
+    ids = runs[0][0]
+    assert all(t > agent.end_header_token_id for t in ids[-50:])
+    # user channel tokens in the sequence equal the tokenizer's codes for the user audio
+    from realtime_codec_agent_amd.audio_tokenizer import AudioTokenizer
+    tok2 = AudioTokenizer(codec_model=res.audio_tokenizer.codec_model, device=res.audio_tokenizer.device)
+    tok2.chunked_tokenize_audio(np.zeros(48000, np.float32), 0.08)  # the enrollment audio precedes the stream (reset())
+    want = res.tokenizer.encode(tok2.chunked_tokenize_audio(sig[: 1280 * 25], 0.08), add_special_tokens=False)
+    got = [agent.input_ids[i] for i in agent.audio_tokens_idx[1::2]]
+    assert got == want
+
+
+def test_trim_recompute_matches_fresh_prefill():
+    """After the sliding-window eviction (realtime_agent_v2.py:187-190,725-733) the LM state equals a
+    fresh prefill of header + surviving suffix: next-step logits are identical."""
+    agent, res = make_agent(chunk=0.1, max_context_secs=1.0, trim_by_secs=0.4)
+    sig = rich_signal(16000 * 2, 9)
+    for s in range(0, len(sig) - 1599, 1600):
+        agent.process_audio(sig[s:s + 1600])
+    assert agent.trim_to_secs > 0
+    llm = res.llm
+    trim_pos = agent.audio_tokens_idx[agent.frames_from_secs(agent.trim_to_secs)]
+    seq = agent.input_ids[: agent.context_start_pos] + agent.input_ids[trim_pos:]
+    assert llm.n_tokens == len(seq) - 2
+    llm.eval(agent.input_ids[-2:])
+    a = llm._scores[-1].copy()
+    llm.reset()
+    llm.eval(seq)
+    assert np.array_equal(llm._scores[-1], a)
