@@ -229,6 +229,9 @@ int rca_lm_step(rca_lm_t* h, const int32_t* ids, int32_t n, int32_t* token);
 /* softmax(logits)[token] of the last position, reduced on the device
  * (measure_event_prob, realtime_agent_v2.py:448-452) */
 int rca_lm_token_probs(rca_lm_t* h, const int32_t* token_ids, int32_t n, float* probs_out);
+/* zero lm_head rows [row_begin, row_end) (random-init bench models: keeps the sampler on codec tokens,
+ * as a trained model in audio mode does; the bytes streamed per step are unchanged) */
+int rca_lm_mask_head_rows(rca_lm_t* h, int32_t row_begin, int32_t row_end);
 /* enable / disable hipGraph replay of the steady-state step (eager launches otherwise); tests and
  * bench compare the two */
 int rca_lm_set_graphs(rca_lm_t* h, int32_t enable);

@@ -140,14 +140,20 @@ __global__ __launch_bounds__(256) void convtr1d_chain_kernel(const float* __rest
 // GEMM view: M = Cout, N = B*Lout (columns flattened over windows, so Lout = 100 wastes nothing),
 // K = Cin*KS walked ci-major / tap-minor in chunks of CIC input channels.
 //
-// LDS sliding window: for every input channel of the chunk the workgroup stages the contiguous
-// input span of its NT columns ONCE (coalesced loads, LeakyReLU fused), de-interleaved by stride
-// phase:  xs[ci][p][slot] = act(x[b][ci][t*S + p]) for the column (b,t) in `slot` (one halo slot on
-// each side).  Tap kk of column j is then xs[ci][(kk-padL) mod S][j + floor((kk-padL)/S)], i.e.
+// Every WAVE is a self-contained pipeline over its own (WM*32 channels) x (WN*32 columns) tile: no
+// workgroup barrier anywhere.  Per chunk the wave (a) issues the global loads of the NEXT chunk's input
+// span and weight fragments, (b) runs the MFMA block of the current chunk from its private LDS
+// window, (c) writes the next window to LDS.  Other waves on the SIMD fill the matrix pipe while one
+// waits.
+//
+// LDS sliding window (per wave): for every input channel of the chunk the contiguous input span of
+// the wave's columns is staged ONCE (coalesced loads, LeakyReLU fused at the LDS write),
+// de-interleaved by stride phase:  xs[ci][p][slot] = act(x[b][ci][t*S + p]) for the column (b,t) in
+// `slot` (one halo slot each side).  Tap kk of column j is xs[ci][(kk-padL) mod S][j + floor((kk-padL)/S)]:
 // consecutive lanes read consecutive LDS words (no bank conflicts, no im2col copy).  Reads that
-// would cross a window edge are zeroed by a per-lane bit mask (fma(w, 0, acc) == acc, the oracle
-// skips those taps).  Each wave issues v_mfma_f32_32x32x2_f32 in ascending k into WM x WN
-// accumulator tiles; A operands (weights) come pre-packed in fragment order from L2
+// would cross a window edge are zeroed by a per-lane bit mask (fma(w, 0, acc) == acc; the oracle
+// skips those taps).  v_mfma_f32_32x32x2_f32 is issued in ascending k into WM x WN accumulator
+// tiles; A operands (weights) come pre-packed in fragment order from L2
 // (wp[co_tile][kquad][lane][4]) and are prefetched one chunk ahead.
 template <int S>
 struct ConvLds {
@@ -161,47 +167,47 @@ struct ConvLds {
     }
 };
 
-template <int KS, int S, int CIC, int WM, int WN, int GM, int GN>
+template <int KS, int S, int CIC, int WM, int WN>
 __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           int Cin, int Lin, int Cout, int Lout, long Ncols, int nchunks,
-                                                          int pre, float slope, int abl) {
-    constexpr int MT = GM * WM * 32;
-    constexpr int NT = GN * WN * 32;
-    constexpr int U = ConvLds<S>::stride(NT);
+                                                          int pre, float slope) {
+    constexpr int MT = WM * 32;            // channels per wave (and per workgroup)
+    constexpr int NW = WN * 32;            // columns per wave
+    constexpr int U = ConvLds<S>::stride(NW);
     constexpr int KPC = CIC * KS / 2;      // k pairs per chunk
     constexpr int QPC = KPC / 4;           // float4 weight quads per chunk per co-tile
-    constexpr int E = (NT + 2) * S;        // staged elements per input channel
-    constexpr int RE = (E + 255) / 256;    // per thread
+    constexpr int E = (NW + 2) * S;        // staged elements per input channel
+    constexpr int RE = (E + 63) / 64;      // per lane
     constexpr int padL = (KS - S + 1) / 2;
-    constexpr int BUF = CIC * S * U;
+    constexpr int BUF = CIC * S * U + 4;   // + a spare word that absorbs the lanes past the window
     static_assert((CIC * KS) % 8 == 0, "chunk must hold whole weight quads");
 
-    extern __shared__ __attribute__((aligned(16))) float xs[];  // [2][CIC][S][U]
+    extern __shared__ __attribute__((aligned(16))) float xs_all[];  // [4 waves][2][CIC][S][U]
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int gm = wave / GN, gn = wave % GN;
-    const long n0 = (long)blockIdx.x * NT;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* xs = xs_all + wave * 2 * BUF;
+    const long n0 = ((long)blockIdx.x * 4 + wave) * NW;   // first column of this wave
     const int co0 = blockIdx.y * MT;
+    if (n0 >= Ncols) return;  // whole wave out of range (no barriers: safe)
 
-    // ---- staging role: element e -> (slot, phase); fixed per thread, channel added per load
-    long s_goff[RE];   // offset of x[b][0][t*S + p]
-    int s_loff[RE];    // p*U + slot, or -1
+    // ---- staging role: element e -> (slot, phase); fixed per lane, channel added per load
+    long s_goff[RE];   // offset of x[b][0][t*S + p] (0 when the slot is outside the signal)
+    int s_loff[RE];    // p*U + slot; -1: lane past the window (its write lands in the spare word)
     bool s_ok[RE];
 #pragma unroll
     for (int r = 0; r < RE; ++r) {
-        const int e = tid + 256 * r;
+        const int e = lane + 64 * r;
         const int slot = e / S, p = e - slot * S;
         const long n = n0 - 1 + slot;
-        s_loff[r] = e < E ? p * U + slot : -1;
         s_ok[r] = e < E && n >= 0 && n < Ncols;
+        s_loff[r] = e < E ? p * U + slot : -1;
         const long nn = s_ok[r] ? n : 0;
         const long b = nn / Lout;
         const int t = (int)(nn - b * Lout);
-        s_goff[r] = b * Cin * (long)Lin + (long)t * S + p;
+        s_goff[r] = s_ok[r] ? b * Cin * (long)Lin + (long)t * S + p : 0;
     }
     // ---- B-read role: per k-pair LDS offset and edge masks for this lane's half
     int b_off[KPC];
@@ -213,14 +219,14 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const float* __restric
         const int d = kk - padL;
         const int q = (d >= 0) ? d / S : -((-d + S - 1) / S);
         const int p = d - q * S;
-        b_off[kp] = (ci * S + p) * U + 1 + q + gn * WN * 32 + (lane & 31);
+        b_off[kp] = (ci * S + p) * U + 1 + q + (lane & 31);
         if (q < 0) m_first |= 1u << kp;
         if (q > 0) m_last |= 1u << kp;
     }
     unsigned zmask[WN];
 #pragma unroll
     for (int wn = 0; wn < WN; ++wn) {
-        const long n = n0 + (gn * WN + wn) * 32 + (lane & 31);
+        const long n = n0 + wn * 32 + (lane & 31);
         const int t = (int)(n % Lout);
         zmask[wn] = (t == 0 ? m_first : 0u) | (t == Lout - 1 ? m_last : 0u);
     }
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const float* __restric
     f32x16 acc[WM][WN];
 #pragma unroll
     for (int wm = 0; wm < WM; ++wm) {
-        const int cot = co0 + (gm * WM + wm) * 32;
+        const int cot = co0 + wm * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = cot + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -243,33 +249,35 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const float* __restric
 #pragma unroll
         for (int cl = 0; cl < CIC; ++cl) {
             const int ci = c * CIC + cl;
+            // branch-free: every lane loads from a valid address (slot outside the signal -> element 0) and the
+            // value is discarded at the LDS write.  Raw value only: nothing consumes it before the MFMA block.
+            const float* xc = x + (long)(ci < Cin ? ci : 0) * Lin;
 #pragma unroll
-            for (int r = 0; r < RE; ++r) {
-                // raw load only: the activation is applied in stage_write so that nothing consumes the
-                // loaded value (and forces an s_waitcnt) before the MFMA block of this chunk
-                float v = 0.0f;
-                if (s_ok[r] && ci < Cin && !(abl & 1)) v = x[s_goff[r] + (long)ci * Lin];
-                sreg[cl][r] = v;
-            }
+            for (int r = 0; r < RE; ++r) sreg[cl][r] = xc[s_goff[r]];
         }
     };
-    auto stage_write = [&](int buf) {
+    auto stage_write = [&](int c, int buf) {
         float* dst = xs + buf * BUF;
 #pragma unroll
-        for (int cl = 0; cl < CIC; ++cl)
+        for (int cl = 0; cl < CIC; ++cl) {
+            const bool cok = (c * CIC + cl) < Cin;
 #pragma unroll
-            for (int r = 0; r < RE; ++r)
-                if (s_loff[r] >= 0) dst[cl * S * U + s_loff[r]] = pre ? lrelu(sreg[cl][r], slope) : sreg[cl][r];
+            for (int r = 0; r < RE; ++r) {
+                float v = (s_ok[r] && cok) ? sreg[cl][r] : 0.0f;
+                if (pre) v = lrelu(v, slope);
+                dst[s_loff[r] >= 0 ? cl * S * U + s_loff[r] : CIC * S * U] = v;
+            }
+        }
     };
 
     const long kquads = (long)nchunks * QPC;
     auto load_w = [&](float4 (&a)[WM][QPC], int c) {
 #pragma unroll
         for (int wm = 0; wm < WM; ++wm) {
-            const int cot = blockIdx.y * (GM * WM) + gm * WM + wm;
+            const int cot = blockIdx.y * WM + wm;
             const float4* p = reinterpret_cast<const float4*>(wp) + ((long)cot * kquads + (long)c * QPC) * 64 + lane;
 #pragma unroll
-            for (int q = 0; q < QPC; ++q) a[wm][q] = (abl & 4) ? make_float4(1.f, 2.f, 3.f, 4.f) : p[q * 64];
+            for (int q = 0; q < QPC; ++q) a[wm][q] = p[q * 64];
         }
     };
     auto compute = [&](const float4 (&a)[WM][QPC], int buf) {
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const float* __restric
             float bfr[WN];
 #pragma unroll
             for (int wn = 0; wn < WN; ++wn) {
-                const float v = (abl & 2) ? (float)(lane + kp) : xb[b_off[kp] + wn * 32];
+                const float v = xb[b_off[kp] + wn * 32];
                 bfr[wn] = ((zmask[wn] >> kp) & 1u) ? 0.0f : v;
             }
 #pragma unroll
@@ -296,34 +304,33 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const float* __restric
     float4 a0[WM][QPC], a1[WM][QPC];
     stage_load(0);
     load_w(a0, 0);
-    stage_write(0);
-    __syncthreads();
+    stage_write(0, 0);
+    __builtin_amdgcn_wave_barrier();
     for (int c = 0; c < nchunks; c += 2) {
-        // even chunk: compute from a0 / buffer 0 while chunk c+1 streams in
         const bool more1 = (c + 1) < nchunks;
         if (more1) { load_w(a1, c + 1); stage_load(c + 1); }
         compute(a0, 0);
-        if (more1) stage_write(1);
-        __syncthreads();
+        if (more1) stage_write(c + 1, 1);
+        __builtin_amdgcn_wave_barrier();
         if (!more1) break;
         const bool more2 = (c + 2) < nchunks;
         if (more2) { load_w(a0, c + 2); stage_load(c + 2); }
         compute(a1, 1);
-        if (more2) stage_write(0);
-        __syncthreads();
+        if (more2) stage_write(c + 2, 0);
+        __builtin_amdgcn_wave_barrier();
     }
 
     // epilogue: C/D layout col = lane&31 (column), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel)
 #pragma unroll
     for (int wn = 0; wn < WN; ++wn) {
-        const long n = n0 + (gn * WN + wn) * 32 + (lane & 31);
+        const long n = n0 + wn * 32 + (lane & 31);
         if (n >= Ncols) continue;
         const long b = n / Lout;
         const int t = (int)(n - b * Lout);
         float* yb = y + b * Cout * (long)Lout + t;
 #pragma unroll
         for (int wm = 0; wm < WM; ++wm) {
-            const int cot = co0 + (gm * WM + wm) * 32;
+            const int cot = co0 + wm * 32;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = cot + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -789,28 +796,23 @@ extern "C" int rca_codec_sync(rca_codec_t* h) {
     return RCA_OK;
 }
 
-template <int KS, int S, int CIC, int WM, int WN, int GM, int GN>
+template <int KS, int S, int CIC, int WM, int WN>
 static void launch_conv_cfg(const ConvLayer& L, const float* x, float* y, int Lin, int Lout, long Ncols, float slope, hipStream_t st) {
-    constexpr int NT = GN * WN * 32, MT = GM * WM * 32;
-    constexpr int lds = 2 * CIC * S * ConvLds<S>::stride(NT) * 4;
+    constexpr int NT = 4 * WN * 32, MT = WM * 32;
+    constexpr int lds = 4 * 2 * (CIC * S * ConvLds<S>::stride(WN * 32) + 4) * 4;
     static_assert(lds <= 65536, "LDS budget");
     dim3 grid(cdiv(Ncols, NT), cdiv(L.cout, MT));
-    static const int abl = getenv("RCA_CONV_ABLATE") ? atoi(getenv("RCA_CONV_ABLATE")) : 0;  // timing experiments only
-    conv1d_mfma_kernel<KS, S, CIC, WM, WN, GM, GN><<<grid, 256, lds, st>>>(x, L.wp, L.b, y, L.cin, Lin, L.cout, Lout, Ncols, L.nchunks, L.pre, slope, abl);
+    conv1d_mfma_kernel<KS, S, CIC, WM, WN><<<grid, 256, lds, st>>>(x, L.wp, L.b, y, L.cin, Lin, L.cout, Lout, Ncols, L.nchunks, L.pre, slope);
 }
 
 template <int KS, int S, int CIC>
 static int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B, int Lin, int Lout, float slope, hipStream_t st) {
     const long Ncols = (long)B * Lout;
-    // tile choice: big tiles while they still fill the chip, otherwise 64x64 tiles (4x the workgroups)
-    if (L.cout <= 64) {
-        if ((long)cdiv(Ncols, 256) >= 256) launch_conv_cfg<KS, S, CIC, 2, 2, 1, 4>(L, x, y, Lin, Lout, Ncols, slope, st);
-        else launch_conv_cfg<KS, S, CIC, 1, 1, 2, 2>(L, x, y, Lin, Lout, Ncols, slope, st);
-    } else if ((long)cdiv(Ncols, 128) * cdiv(L.cout, 128) >= 256) {
-        launch_conv_cfg<KS, S, CIC, 2, 2, 2, 2>(L, x, y, Lin, Lout, Ncols, slope, st);
-    } else {
-        launch_conv_cfg<KS, S, CIC, 1, 1, 2, 2>(L, x, y, Lin, Lout, Ncols, slope, st);
-    }
+    // wave tile 64 channels x 64 columns while that still yields >= ~2 waves per SIMD on the chip,
+    // otherwise 32 x 32 tiles (4x the waves; streaming / small batches)
+    const long waves_big = (long)cdiv(Ncols, 64) * cdiv(L.cout, 64);
+    if (waves_big >= 2048) launch_conv_cfg<KS, S, CIC, 2, 2>(L, x, y, Lin, Lout, Ncols, slope, st);
+    else launch_conv_cfg<KS, S, CIC, 1, 1>(L, x, y, Lin, Lout, Ncols, slope, st);
     RCA_LAUNCH_CHECK();
     return RCA_OK;
 }

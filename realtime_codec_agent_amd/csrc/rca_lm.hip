@@ -74,79 +74,187 @@ __global__ __launch_bounds__(256) void lm_embed_kernel(const LmDevState* __restr
     for (int h = threadIdx.x; h < H; h += 256) x[(long)m * H + h] = __uint_as_float((unsigned)row[h] << 16);
 }
 
-// --------------------------------------------------------------- residual add + RMSNorm (one WG per token)
-// x[m] += sum_s parts[s][m] (s ascending) ; xn[m] = x[m] * rsqrt(mean(x^2) + eps) * w
-__global__ __launch_bounds__(256) void lm_add_rmsnorm_kernel(const LmDevState* __restrict__ stt, float* __restrict__ x,
-                                                             const float* __restrict__ parts, int nparts, long part_stride,
-                                                             const float* __restrict__ w, float* __restrict__ xn, int H,
-                                                             float eps, int only_last) {
-    int m = blockIdx.x;
-    const int M = stt->m;
-    if (only_last) m = M - 1;
-    if (m >= M) return;
-    float* xr = x + (long)m * H;
-    float ss = 0.0f;
-    for (int h = threadIdx.x; h < H; h += 256) {
-        float v = xr[h];
-        for (int s = 0; s < nparts; ++s) v += parts[s * part_stride + (long)m * H + h];
-        if (nparts) xr[h] = v;
-        ss = __builtin_fmaf(v, v, ss);
-    }
-    __shared__ float red[4];
-    ss = wave_sum(ss);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
-    __syncthreads();
-    const float tot = red[0] + red[1] + red[2] + red[3];
-    const float rstd = rsqrtf(tot / (float)H + eps);
-    float* out = xn + (long)(only_last ? 0 : m) * H;
-    for (int h = threadIdx.x; h < H; h += 256) out[h] = (xr[h] * rstd) * w[h];
-}
-
 // ------------------------------------------------------------------------------------ GEMV
 // y[slice][m][n] = sum_{k in slice} W[n][k] * x[m][k].   One wave owns 2 rows at a time and walks
-// its K slice in 16-byte (8 x bf16) lane chunks; x sits in LDS as f32.  EPI 0: store partials,
-// EPI 1: rows (2i, 2i+1) are (gate_i, up_i): store silu(gate) * up into h[m][i].
-template <int M, int EPI>
-__global__ __launch_bounds__(256) void lm_gemv_kernel(const bf16_t* __restrict__ W, const float* __restrict__ x, float* __restrict__ y,
-                                                      int N, int K, int kslice, int rows_per_wg, long y_slice_stride, int ldy,
-                                                      int x_row_offset) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];  // [M][kslice]
+// its K slice (<= 2048) in 16-byte (8 x bf16) lane chunks, all of a row pair's loads issued before
+// the first use; x sits in LDS as f32.
+//   PRO 1: prologue = residual add + RMSNorm: v = xin[m] + sum_s parts[s][m]; the first workgroup
+//          writes v to xout (ping-pong residual stream); xs = v * rsqrt(mean(v^2)+eps) * norm_w
+//   EPI 0: store partial sums                 EPI 1: rows (2i, 2i+1) = (gate_i, up_i): h = silu(g)*u
+//   EPI 2: QKV rows paired (d, d+32) inside each head: RoPE (HF rotate_half), q back to qkv[],
+//          k / v straight into the fp16 KV cache at position n_tokens + m
+struct GemvPro {
+    const float* xin; float* xout; const float* parts; int nparts; long part_stride; const float* norm_w; float eps; int only_last;
+};
+struct GemvRope {
+    const float* cos_t; const float* sin_t; f16_t* kc; f16_t* vc; int nh, nkv, n_ctx;
+};
+template <int M, int PRO, int EPI, int KW>
+__global__ __launch_bounds__(256) void lm_gemv_kernel(const LmDevState* __restrict__ stt, const bf16_t* __restrict__ W,
+                                                      const float* __restrict__ x, float* __restrict__ y, int N, int K, int kslice,
+                                                      int rows_per_wg, long y_slice_stride, int ldy, GemvPro pro, GemvRope rope) {
+    // KW = 1: the 4 waves of the workgroup split K between them (kslice = K/4 each) and work on the SAME row
+    // pair; their partial sums are added in wave order on top of the residual (EPI 3).
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [M][KW ? K : kslice]
+    __shared__ float red[M][4];
+    __shared__ float kred[4][2][M];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int sl = blockIdx.y;
+    const int sl = KW ? wave : blockIdx.y;
     const int k0 = sl * kslice;
     const int kl = min(kslice, K - k0);
-    for (int i = threadIdx.x; i < M * kl; i += 256) {
-        const int m = i / kl, k = i - m * kl;
-        xs[m * kslice + k] = x[(long)(m + x_row_offset) * K + k0 + k];
-    }
-    __syncthreads();
-    const int nchunk = kl >> 3;  // 8-element chunks in this slice
+    const int xld = KW ? K : kslice;      // LDS row stride
+    const int xoff = KW ? k0 : 0;         // this wave's slice inside the LDS row
+    const int nchunk = kl >> 3;           // 8-element chunks in this slice (<= 256)
     const int row_beg = blockIdx.x * rows_per_wg;
     const int row_end = min(N, row_beg + rows_per_wg);
-    for (int r0 = row_beg + wave * 2; r0 < row_end; r0 += 8) {
+    const int rstep = KW ? 2 : 8;
+    auto rows_of = [&](int rb, int& r0, int& r1) {
+        r0 = rb; r1 = rb + 1;
+        if (EPI == 2) {  // pair index -> rows (d, d+32) of one head
+            const int pidx = rb >> 1;
+            r0 = (pidx >> 5) * 64 + (pidx & 31);
+            r1 = r0 + 32;
+        }
+    };
+    u32x4 wa[4], wb[4];
+    auto load_rows = [&](int rb) {
+        int r0, r1;
+        rows_of(rb, r0, r1);
+        const u32x4* w0 = reinterpret_cast<const u32x4*>(W + (long)r0 * K + k0);
+        const u32x4* w1 = reinterpret_cast<const u32x4*>(W + (long)(r1 < N ? r1 : r0) * K + k0);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int c = lane + 64 * it;
+            if (c < nchunk) {
+                wa[it] = __builtin_nontemporal_load(w0 + c);
+                wb[it] = __builtin_nontemporal_load(w1 + c);
+            }
+        }
+    };
+    // the first row pair's weights do not depend on x: get them in flight before the prologue
+    const int rb0 = row_beg + (KW ? 0 : wave * 2);
+    if (rb0 < row_end) load_rows(rb0);
+
+    if (PRO == 1) {
+        // rows of the residual stream handled by this pass (only_last: just the final token)
+        const int Mv = stt->m;
+        const int mbase = pro.only_last ? Mv - 1 : 0;
+        float ss[M];
+        // K <= 2048: at most 8 elements per thread and token; all loads are issued before any is used
+        float pv[M][8];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            ss[m] = 0.0f;
+            const int mr = mbase + m;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = threadIdx.x + 256 * i;
+                pv[m][i] = (mr < Mv && k < K) ? pro.xin[(long)mr * K + k] : 0.0f;
+            }
+        }
+        for (int s2 = 0; s2 < pro.nparts; ++s2) {
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const int mr = mbase + m;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int k = threadIdx.x + 256 * i;
+                    if (mr < Mv && k < K) pv[m][i] += pro.parts[s2 * pro.part_stride + (long)mr * K + k];
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const int mr = mbase + m;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = threadIdx.x + 256 * i;
+                if (k < K) {
+                    const float v = pv[m][i];
+                    if (blockIdx.x == 0 && pro.xout && mr < Mv) pro.xout[(long)mr * K + k] = v;
+                    xs[m * xld + k] = v;
+                    ss[m] = __builtin_fmaf(v, v, ss[m]);
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const float t = wave_sum(ss[m]);
+            if (lane == 0) red[m][wave] = t;
+        }
+        __syncthreads();
+        float rstd[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) rstd[m] = rsqrtf((red[m][0] + red[m][1] + red[m][2] + red[m][3]) / (float)K + pro.eps);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = threadIdx.x + 256 * i;
+            if (k < K) {
+                const float w = pro.norm_w[k];
+#pragma unroll
+                for (int m = 0; m < M; ++m) xs[m * xld + k] = (pv[m][i] * rstd[m]) * w;
+            }
+        }
+    } else if (KW) {
+        // M*K/4 <= 4096 float4: 16 per thread, loaded in two batches of 8
+        const int n4 = (M * K) >> 2;
+#pragma unroll
+        for (int b8 = 0; b8 < 2; ++b8) {
+            float4 t[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int j = threadIdx.x + 256 * (b8 * 8 + i);
+                if (j < n4) t[i] = reinterpret_cast<const float4*>(x)[j];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int j = threadIdx.x + 256 * (b8 * 8 + i);
+                if (j < n4) reinterpret_cast<float4*>(xs)[j] = t[i];
+            }
+        }
+    } else {
+        const int kl4 = kl >> 2;
+        for (int i = threadIdx.x; i < M * kl4; i += 256) {
+            const int m = i / kl4, k4 = i - m * kl4;
+            reinterpret_cast<float4*>(xs + m * xld)[k4] = reinterpret_cast<const float4*>(x + (long)m * K + k0)[k4];
+        }
+    }
+    __syncthreads();
+    for (int rb = rb0; rb < row_end; rb += rstep) {
+        int r0, r1;
+        rows_of(rb, r0, r1);
+        const bool has2 = r1 < N;
         float acc[2][M];
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
             for (int m = 0; m < M; ++m) acc[rr][m] = 0.0f;
-        const bool has2 = (r0 + 1) < row_end;
-        const u32x4* w0 = reinterpret_cast<const u32x4*>(W + (long)r0 * K + k0);
-        const u32x4* w1 = reinterpret_cast<const u32x4*>(W + (long)(has2 ? r0 + 1 : r0) * K + k0);
-        for (int c = lane; c < nchunk; c += 64) {
-            const u32x4 a = __builtin_nontemporal_load(w0 + c);
-            const u32x4 b = __builtin_nontemporal_load(w1 + c);
-            const float wa[8] = {bf16_lo(a.x), bf16_hi(a.x), bf16_lo(a.y), bf16_hi(a.y), bf16_lo(a.z), bf16_hi(a.z), bf16_lo(a.w), bf16_hi(a.w)};
-            const float wb[8] = {bf16_lo(b.x), bf16_hi(b.x), bf16_lo(b.y), bf16_hi(b.y), bf16_lo(b.z), bf16_hi(b.z), bf16_lo(b.w), bf16_hi(b.w)};
+        // unpack this pair to f32, then immediately refill the weight registers with the next pair
+        float fa[4][8], fb[4][8];
 #pragma unroll
-            for (int m = 0; m < M; ++m) {
-                const float4 x0 = *reinterpret_cast<const float4*>(xs + m * kslice + c * 8);
-                const float4 x1 = *reinterpret_cast<const float4*>(xs + m * kslice + c * 8 + 4);
-                const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        for (int it = 0; it < 4; ++it) {
+            const u32x4 a = wa[it], b = wb[it];
+            fa[it][0] = bf16_lo(a.x); fa[it][1] = bf16_hi(a.x); fa[it][2] = bf16_lo(a.y); fa[it][3] = bf16_hi(a.y);
+            fa[it][4] = bf16_lo(a.z); fa[it][5] = bf16_hi(a.z); fa[it][6] = bf16_lo(a.w); fa[it][7] = bf16_hi(a.w);
+            fb[it][0] = bf16_lo(b.x); fb[it][1] = bf16_hi(b.x); fb[it][2] = bf16_lo(b.y); fb[it][3] = bf16_hi(b.y);
+            fb[it][4] = bf16_lo(b.z); fb[it][5] = bf16_hi(b.z); fb[it][6] = bf16_lo(b.w); fb[it][7] = bf16_hi(b.w);
+        }
+        if (rb + rstep < row_end) load_rows(rb + rstep);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    acc[0][m] = __builtin_fmaf(wa[j], xv[j], acc[0][m]);
-                    acc[1][m] = __builtin_fmaf(wb[j], xv[j], acc[1][m]);
+        for (int it = 0; it < 4; ++it) {
+            const int c = lane + 64 * it;
+            if (c < nchunk) {
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const float4 x0 = *reinterpret_cast<const float4*>(xs + m * xld + xoff + c * 8);
+                    const float4 x1 = *reinterpret_cast<const float4*>(xs + m * xld + xoff + c * 8 + 4);
+                    const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        acc[0][m] = __builtin_fmaf(fa[it][j], xv[j], acc[0][m]);
+                        acc[1][m] = __builtin_fmaf(fb[it][j], xv[j], acc[1][m]);
+                    }
                 }
             }
         }
@@ -154,59 +262,73 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const bf16_t* __restrict__
         for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
             for (int m = 0; m < M; ++m) acc[rr][m] = wave_sum(acc[rr][m]);
-        if (lane == 0) {
+        if (KW) {
+            if (lane == 0) {
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int m = 0; m < M; ++m) kred[wave][rr][m] = acc[rr][m];
+            }
+            __syncthreads();
+            if (threadIdx.x < 2 * M) {
+                const int rr = threadIdx.x / M, m = threadIdx.x % M;
+                const int r = rr ? r1 : r0;
+                if (r < N && m < stt->m) {
+                    float v = y[(long)m * ldy + r];
+                    v += kred[0][rr][m]; v += kred[1][rr][m]; v += kred[2][rr][m]; v += kred[3][rr][m];
+                    y[(long)m * ldy + r] = v;
+                }
+            }
+            __syncthreads();
+        } else if (lane == 0) {
             if (EPI == 1) {
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
                     const float g = acc[0][m], u = acc[1][m];
                     y[(long)m * ldy + (r0 >> 1)] = (g / (1.0f + __expf(-g))) * u;
                 }
+            } else if (EPI == 2) {
+                const int head = r0 >> 6, d = r0 & 63;  // d < 32
+                const int Mv = stt->m, pos0 = stt->n_tokens;
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const int pos = pos0 + m;
+                    if (m >= Mv || pos >= rope.n_ctx) continue;
+                    const float x1 = acc[0][m], x2 = acc[1][m];
+                    if (head < rope.nh + rope.nkv) {
+                        const float c = rope.cos_t[(long)pos * 32 + d], sn = rope.sin_t[(long)pos * 32 + d];
+                        const float o1 = x1 * c + (-x2) * sn;
+                        const float o2 = x2 * c + x1 * sn;
+                        if (head < rope.nh) {
+                            y[(long)m * ldy + r0] = o1;
+                            y[(long)m * ldy + r1] = o2;
+                        } else {
+                            f16_t* kp = rope.kc + ((long)pos * rope.nkv + (head - rope.nh)) * 64;
+                            kp[d] = (f16_t)o1;
+                            kp[d + 32] = (f16_t)o2;
+                        }
+                    } else {
+                        f16_t* vp = rope.vc + ((long)pos * rope.nkv + (head - rope.nh - rope.nkv)) * 64;
+                        vp[d] = (f16_t)x1;
+                        vp[d + 32] = (f16_t)x2;
+                    }
+                }
+            } else if (EPI == 3) {  // residual add in place (single K slice)
+                const int Mv = stt->m;
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    if (m >= Mv) continue;
+                    y[(long)m * ldy + r0] = y[(long)m * ldy + r0] + acc[0][m];
+                    if (has2) y[(long)m * ldy + r1] = y[(long)m * ldy + r1] + acc[1][m];
+                }
             } else {
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
                     y[sl * y_slice_stride + (long)m * ldy + r0] = acc[0][m];
-                    if (has2) y[sl * y_slice_stride + (long)m * ldy + r0 + 1] = acc[1][m];
+                    if (has2) y[sl * y_slice_stride + (long)m * ldy + r1] = acc[1][m];
                 }
             }
         }
-    }
-}
-
-// ----------------------------------------------------------------------- RoPE + KV-cache write
-// qkv [M][(nh + 2*nkv) * hd] f32.  q rotated in place; k rotated and stored fp16; v stored fp16.
-// HF convention (rotate_half): out[d] = x[d]*cos[d] - x[d+hd/2]*sin[d]; out[d+hd/2] = x[d+hd/2]*cos[d] + x[d]*sin[d].
-__global__ __launch_bounds__(256) void lm_rope_kv_kernel(const LmDevState* __restrict__ stt, float* __restrict__ qkv,
-                                                         const float* __restrict__ cos_t, const float* __restrict__ sin_t,
-                                                         f16_t* __restrict__ kc, f16_t* __restrict__ vc, int nh, int nkv, int hd,
-                                                         int n_ctx) {
-    const int m = blockIdx.x;
-    if (m >= stt->m) return;
-    const int pos = stt->n_tokens + m;
-    if (pos >= n_ctx) return;
-    const int half = hd >> 1;
-    const int ld = (nh + 2 * nkv) * hd;
-    float* row = qkv + (long)m * ld;
-    const float* cs = cos_t + (long)pos * half;
-    const float* sn = sin_t + (long)pos * half;
-    // q and k heads
-    for (int i = threadIdx.x; i < (nh + nkv) * half; i += 256) {
-        const int head = i / half, d = i - head * half;
-        float* hp = row + head * hd;
-        const float x1 = hp[d], x2 = hp[d + half];
-        const float c = cs[d], s = sn[d];
-        const float o1 = x1 * c + (-x2) * s;
-        const float o2 = x2 * c + x1 * s;
-        if (head < nh) {
-            hp[d] = o1;
-            hp[d + half] = o2;
-        } else {
-            f16_t* kp = kc + ((long)pos * nkv + (head - nh)) * hd;
-            kp[d] = (f16_t)o1;
-            kp[d + half] = (f16_t)o2;
-        }
-    }
-    for (int i = threadIdx.x; i < nkv * hd; i += 256) {
-        vc[(long)pos * nkv * hd + i] = (f16_t)row[(nh + nkv) * hd + i];
     }
 }
 
@@ -418,11 +540,89 @@ __device__ __forceinline__ unsigned long long sample_key(float v, unsigned idx) 
     return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
 }
 
-// One workgroup of 1024 threads: exact top-k by 8-bit radix select over 64-bit (value, index) keys,
-// bitonic sort of the k survivors, then the llama.cpp chain order top_k -> top_p -> min_p -> temp ->
-// softmax -> inverse-CDF draw (llamacpp_utils.py:39-95; realtime_agent_config.py:11-20,29).
-__global__ __launch_bounds__(1024) void lm_sample_kernel(const float* __restrict__ logits, int V, const SamplerDev* __restrict__ sp,
-                                                         LmDevState* __restrict__ stt, int feed_back) {
+// Sampler = three launches (llama.cpp chain order top_k -> top_p -> min_p -> temp -> softmax -> draw;
+// llamacpp_utils.py:39-95; realtime_agent_config.py:11-20,29):
+//   1. samp_hist:   2048-bin histogram of the monotone keys' top 11 bits (128 workgroups, LDS then global)
+//   2. samp_gather: every workgroup finds the bin holding the k-th largest value from the histogram and
+//                   appends its slice's elements at or above that bin to a candidate list (a few hundred)
+//   3. samp_final:  one workgroup: exact top-k of the candidates by 8-bit radix select over 64-bit
+//                   (value, index) keys, bitonic sort, then the serial chain with the polynomial exp and
+//                   the counter RNG.  Falls back to scanning the whole vocabulary if the list overflowed.
+#define SAMP_BINS 2048
+#define SAMP_CAND_CAP 4096
+struct SampWork {
+    unsigned hist[SAMP_BINS];
+    unsigned ncand;
+    unsigned overflow;
+    unsigned pad[2];
+    unsigned long long cand[SAMP_CAND_CAP];
+};
+
+__device__ __forceinline__ float samp_value(const float* __restrict__ logits, const SamplerDev* __restrict__ sp, int i) {
+    float v = logits[i];
+    const int nb = sp->n_bias;
+    for (int b = 0; b < nb; ++b)
+        if (sp->bias_ids[b] == i) v = v + sp->bias_vals[b];
+    return v;
+}
+__device__ __forceinline__ int samp_k(const SamplerDev* sp, int V) {
+    int k = sp->temp <= 0.0f ? 1 : sp->top_k;
+    if (k <= 0 || k > SAMP_MAXK) k = SAMP_MAXK;
+    return k > V ? V : k;
+}
+
+__global__ __launch_bounds__(256) void samp_hist_kernel(const float* __restrict__ logits, int V, const SamplerDev* __restrict__ sp,
+                                                        SampWork* __restrict__ w) {
+    __shared__ unsigned hl[SAMP_BINS];
+    for (int b = threadIdx.x; b < SAMP_BINS; b += 256) hl[b] = 0;
+    __syncthreads();
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < V; i += gridDim.x * 256) {
+        const unsigned long long key = sample_key(samp_value(logits, sp, i), (unsigned)i);
+        atomicAdd(&hl[(unsigned)(key >> 53)], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < SAMP_BINS; b += 256)
+        if (hl[b]) atomicAdd(&w->hist[b], hl[b]);
+}
+
+__global__ __launch_bounds__(256) void samp_gather_kernel(const float* __restrict__ logits, int V, const SamplerDev* __restrict__ sp,
+                                                          SampWork* __restrict__ w) {
+    __shared__ unsigned grp[256];
+    __shared__ unsigned thr_bin;
+    const int k = samp_k(sp, V);
+    unsigned s8 = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s8 += w->hist[threadIdx.x * 8 + j];
+    grp[threadIdx.x] = s8;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned acc = 0;
+        int g = 255;
+        for (; g > 0; --g) {
+            if (acc + grp[g] >= (unsigned)k) break;
+            acc += grp[g];
+        }
+        int b = g * 8 + 7;
+        for (; b > g * 8; --b) {
+            if (acc + w->hist[b] >= (unsigned)k) break;
+            acc += w->hist[b];
+        }
+        thr_bin = (unsigned)b;
+    }
+    __syncthreads();
+    const unsigned tb = thr_bin;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < V; i += gridDim.x * 256) {
+        const unsigned long long key = sample_key(samp_value(logits, sp, i), (unsigned)i);
+        if ((unsigned)(key >> 53) >= tb) {
+            const unsigned slot = atomicAdd(&w->ncand, 1u);
+            if (slot < SAMP_CAND_CAP) w->cand[slot] = key;
+            else w->overflow = 1u;
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void samp_final_kernel(const float* __restrict__ logits, int V, const SamplerDev* __restrict__ sp,
+                                                          LmDevState* __restrict__ stt, SampWork* __restrict__ w) {
     __shared__ unsigned hist[256];
     __shared__ unsigned long long sel_prefix;
     __shared__ int sel_shift;      // bits already fixed (from the top)
@@ -431,29 +631,24 @@ __global__ __launch_bounds__(1024) void lm_sample_kernel(const float* __restrict
     __shared__ unsigned ncand;
     __shared__ float cval[SAMP_MAXK];
     const int tid = threadIdx.x;
-    int k = sp->top_k;
     const bool greedy = sp->temp <= 0.0f;
-    if (greedy) k = 1;
-    if (k <= 0 || k > SAMP_MAXK) k = SAMP_MAXK;
-    if (k > V) k = V;
-    const int nb = sp->n_bias;
-    auto value_of = [&](int i) {
-        float v = logits[i];
-        for (int b = 0; b < nb; ++b)
-            if (sp->bias_ids[b] == i) v = v + sp->bias_vals[b];
-        return v;
+    const int k = samp_k(sp, V);
+    const bool full = w->overflow != 0u;
+    const int NN = full ? V : (int)min(w->ncand, (unsigned)SAMP_CAND_CAP);
+    auto key_at = [&](int i) -> unsigned long long {
+        return full ? sample_key(samp_value(logits, sp, i), (unsigned)i) : w->cand[i];
     };
-    if (tid == 0) { sel_prefix = 0ull; sel_shift = 0; need = (unsigned)k; ncand = 0; }
+    if (tid == 0) { sel_prefix = 0ull; sel_shift = 0; need = (unsigned)min(k, NN); ncand = 0; }
     __syncthreads();
-    // radix select: after the loop, keys >= threshold are exactly the k largest
+    // radix select: afterwards the keys >= threshold are exactly the k largest
     for (int pass = 0; pass < 8; ++pass) {
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
         const int shift = 56 - 8 * pass;
         const unsigned long long prefix = sel_prefix;
         const int fixed = sel_shift;
-        for (int i = tid; i < V; i += 1024) {
-            const unsigned long long key = sample_key(value_of(i), (unsigned)i);
+        for (int i = tid; i < NN; i += 1024) {
+            const unsigned long long key = key_at(i);
             const bool match = fixed == 0 ? true : ((key >> (64 - fixed)) == (prefix >> (64 - fixed)));
             if (match) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
         }
@@ -473,11 +668,9 @@ __global__ __launch_bounds__(1024) void lm_sample_kernel(const float* __restrict
         __syncthreads();
         if (need == 0xFFFFFFFFu) break;
     }
-    const int fixed = sel_shift;
-    const unsigned long long thr = fixed >= 64 ? sel_prefix : (sel_prefix >> (64 - fixed)) << (64 - fixed);
-    for (int i = tid; i < V; i += 1024) {
-        const float v = value_of(i);
-        const unsigned long long key = sample_key(v, (unsigned)i);
+    const unsigned long long thr = sel_prefix;  // unfixed low bits are zero
+    for (int i = tid; i < NN; i += 1024) {
+        const unsigned long long key = key_at(i);
         if (key >= thr) {
             const unsigned slot = atomicAdd(&ncand, 1u);
             if (slot < SAMP_MAXK) cand[slot] = key;
@@ -485,10 +678,9 @@ __global__ __launch_bounds__(1024) void lm_sample_kernel(const float* __restrict
     }
     __syncthreads();
     const int n = min((int)ncand, SAMP_MAXK);
-    // bitonic sort (descending) of 256 slots, padding = 0
     if (tid < SAMP_MAXK && tid >= n) cand[tid] = 0ull;
     __syncthreads();
-    for (int size = 2; size <= SAMP_MAXK; size <<= 1) {
+    for (int size = 2; size <= SAMP_MAXK; size <<= 1) {  // bitonic sort, descending; padding (0) sinks
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             if (tid < SAMP_MAXK) {
                 const int j = tid ^ stride;
@@ -503,7 +695,7 @@ __global__ __launch_bounds__(1024) void lm_sample_kernel(const float* __restrict
     }
     if (tid < n) {
         const unsigned idx = 0xFFFFFFFFu - (unsigned)(cand[tid] & 0xFFFFFFFFull);
-        cval[tid] = value_of((int)idx);
+        cval[tid] = samp_value(logits, sp, (int)idx);
     }
     __syncthreads();
     if (tid == 0) {
@@ -542,10 +734,12 @@ __global__ __launch_bounds__(1024) void lm_sample_kernel(const float* __restrict
             }
         }
         stt->rng_counter += 1ull;
-        const int tok = (int)(0xFFFFFFFFu - (unsigned)(cand[pick] & 0xFFFFFFFFull));
-        stt->out_token = tok;
-        if (feed_back) stt->ids[0] = tok;
+        stt->out_token = (int)(0xFFFFFFFFu - (unsigned)(cand[pick] & 0xFFFFFFFFull));
     }
+    // re-arm the shared work area for the next call
+    __syncthreads();
+    for (int b = tid; b < SAMP_BINS; b += 1024) w->hist[b] = 0u;
+    if (tid == 0) { w->ncand = 0u; w->overflow = 0u; }
 }
 
 // probs[i] = softmax(logits)[ids[i]] : one workgroup, two sweeps (max, sum)
@@ -635,13 +829,14 @@ struct rca_lm {
     long kv_layer_stride = 0;
     int n_ctx_pad = 0, n_splits = 0;
     // activations
-    float *x = nullptr, *xn = nullptr, *qkv = nullptr, *attn = nullptr, *part_o = nullptr, *hbuf = nullptr, *part_d = nullptr,
+    float *x = nullptr, *x2 = nullptr, *xn = nullptr, *qkv = nullptr, *attn = nullptr, *part_o = nullptr, *hbuf = nullptr, *part_d = nullptr,
           *att_part = nullptr, *logits = nullptr, *probs_dev = nullptr;
     int* probe_ids_dev = nullptr;
     long logits_rows_cap = 0;   // rows allocated in `logits` (1, or more when logits_all)
     int logits_rows = 0;        // rows valid from the last eval
     LmDevState* stt = nullptr;  // device
     SamplerDev* samp = nullptr; // device
+    SampWork* swork = nullptr;  // device: sampler histogram + candidate list
     LmDevState* h_stt = nullptr;   // pinned host staging (ids, n_tokens, m in; out_token back)
     int n_tokens = 0;           // host mirror (llama_cpp.Llama.n_tokens)
     bool sampler_set = false;
@@ -667,8 +862,8 @@ extern "C" int rca_lm_destroy(rca_lm_t* h) {
         for (void* p : {(void*)L.wqkv, (void*)L.wo, (void*)L.wgu, (void*)L.wdown, (void*)L.attn_norm, (void*)L.ffn_norm})
             if (p) (void)hipFree(p);
     for (void* p : {(void*)h->embed, (void*)h->head, (void*)h->final_norm, (void*)h->cos_t, (void*)h->sin_t, (void*)h->kc, (void*)h->vc,
-                    (void*)h->x, (void*)h->xn, (void*)h->qkv, (void*)h->attn, (void*)h->part_o, (void*)h->hbuf, (void*)h->part_d,
-                    (void*)h->att_part, (void*)h->logits, (void*)h->probs_dev, (void*)h->probe_ids_dev, (void*)h->stt, (void*)h->samp})
+                    (void*)h->x, (void*)h->x2, (void*)h->xn, (void*)h->qkv, (void*)h->attn, (void*)h->part_o, (void*)h->hbuf, (void*)h->part_d,
+                    (void*)h->att_part, (void*)h->logits, (void*)h->probs_dev, (void*)h->probe_ids_dev, (void*)h->stt, (void*)h->samp, (void*)h->swork})
         if (p) (void)hipFree(p);
     if (h->h_stt) (void)hipHostFree(h->h_stt);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -780,6 +975,7 @@ static int lm_common_init(rca_lm* h, const rca_tensor_t* ts, int nt) {
     h->ksplit_down = (c.ffn + LM_KSLICE - 1) / LM_KSLICE;
     h->kslice_down = c.ffn <= LM_KSLICE ? c.ffn : LM_KSLICE;
     if ((rc = lm_alloc((void**)&h->x, (size_t)LM_MAXM * H * 4)) != RCA_OK) return rc;
+    if ((rc = lm_alloc((void**)&h->x2, (size_t)LM_MAXM * H * 4)) != RCA_OK) return rc;
     if ((rc = lm_alloc((void**)&h->xn, (size_t)LM_MAXM * H * 4)) != RCA_OK) return rc;
     if ((rc = lm_alloc((void**)&h->qkv, (size_t)LM_MAXM * QKV * 4)) != RCA_OK) return rc;
     if ((rc = lm_alloc((void**)&h->attn, (size_t)LM_MAXM * AO * 4)) != RCA_OK) return rc;
@@ -795,6 +991,8 @@ static int lm_common_init(rca_lm* h, const rca_tensor_t* ts, int nt) {
     if ((rc = lm_alloc((void**)&h->samp, sizeof(SamplerDev))) != RCA_OK) return rc;
     RCA_HIP(hipMemsetAsync(h->stt, 0, sizeof(LmDevState), h->stream));
     RCA_HIP(hipMemsetAsync(h->samp, 0, sizeof(SamplerDev), h->stream));
+    if ((rc = lm_alloc((void**)&h->swork, sizeof(SampWork))) != RCA_OK) return rc;
+    RCA_HIP(hipMemsetAsync(h->swork, 0, sizeof(SampWork), h->stream));
     RCA_HIP(hipHostMalloc((void**)&h->h_stt, sizeof(LmDevState), hipHostMallocDefault));
     memset(h->h_stt, 0, sizeof(LmDevState));
     RCA_HIP(hipStreamSynchronize(h->stream));
@@ -895,44 +1093,63 @@ extern "C" int rca_lm_create_random(const rca_lm_config_t* cfg, uint64_t seed, f
 }
 
 // ------------------------------------------------------------------------- forward pass (M tokens)
-template <int M>
-static void launch_gemv(rca_lm* h, const bf16_t* W, const float* x, float* y, int N, int K, int kslice, int nsl, long y_slice_stride,
-                        int ldy, int epi, int x_row_offset, hipStream_t st) {
-    // rows per workgroup: enough workgroups to fill 256 CUs several times over, multiples of 8
-    int rpw = 8;
-    while ((long)cdiv(N, rpw) * nsl > 4096 && rpw < 64) rpw *= 2;
-    dim3 grid(cdiv(N, rpw), nsl);
-    const size_t lds = (size_t)M * kslice * 4;
-    if (epi == 1) lm_gemv_kernel<M, 1><<<grid, 256, lds, st>>>(W, x, y, N, K, kslice, rpw, y_slice_stride, ldy, x_row_offset);
-    else lm_gemv_kernel<M, 0><<<grid, 256, lds, st>>>(W, x, y, N, K, kslice, rpw, y_slice_stride, ldy, x_row_offset);
+template <int M, int PRO, int EPI, int KW>
+static void launch_gemv_t(rca_lm* h, const bf16_t* W, const float* x, float* y, int N, int K, int kslice, int nsl, long yss, int ldy,
+                          const GemvPro& pro, const GemvRope& rope, hipStream_t st) {
+    // rows per workgroup: aim at ~512 workgroups (2 per CU).  KW kernels take 2 rows per iteration.
+    const int gran = 8;
+    const int groups = KW ? 1 : nsl;
+    long want = ((long)N * groups + 511) / 512;
+    int rpw = (int)std::min<long>(64, std::max<long>(gran, (want + gran - 1) / gran * gran));
+    dim3 grid(cdiv(N, rpw), groups);
+    const size_t lds = (size_t)M * (KW ? K : kslice) * 4;
+    auto kern = lm_gemv_kernel<M, PRO, EPI, KW>;
+    if (lds > 48 * 1024) {
+        static bool done = false;  // one-time opt-in above the default dynamic LDS size
+        if (!done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); done = true; }
+    }
+    kern<<<grid, 256, lds, st>>>(h->stt, W, x, y, N, K, kslice, rpw, yss, ldy, pro, rope);
 }
-static void gemv(rca_lm* h, int M, const bf16_t* W, const float* x, float* y, int N, int K, int kslice, int nsl, long yss, int ldy, int epi,
-                 int xro, hipStream_t st) {
+template <int PRO, int EPI>
+static void launch_gemv(rca_lm* h, int M, const bf16_t* W, const float* x, float* y, int N, int K, int kslice, int nsl, long yss, int ldy,
+                        const GemvPro& pro, const GemvRope& rope, hipStream_t st) {
     switch (M) {
-        case 1: launch_gemv<1>(h, W, x, y, N, K, kslice, nsl, yss, ldy, epi, xro, st); break;
-        case 2: launch_gemv<2>(h, W, x, y, N, K, kslice, nsl, yss, ldy, epi, xro, st); break;
-        case 3: case 4: launch_gemv<4>(h, W, x, y, N, K, kslice, nsl, yss, ldy, epi, xro, st); break;
-        default: launch_gemv<8>(h, W, x, y, N, K, kslice, nsl, yss, ldy, epi, xro, st); break;
+        case 1: launch_gemv_t<1, PRO, EPI, 0>(h, W, x, y, N, K, kslice, nsl, yss, ldy, pro, rope, st); break;
+        case 2: launch_gemv_t<2, PRO, EPI, 0>(h, W, x, y, N, K, kslice, nsl, yss, ldy, pro, rope, st); break;
+        case 3: case 4: launch_gemv_t<4, PRO, EPI, 0>(h, W, x, y, N, K, kslice, nsl, yss, ldy, pro, rope, st); break;
+        default: launch_gemv_t<8, PRO, EPI, 0>(h, W, x, y, N, K, kslice, nsl, yss, ldy, pro, rope, st); break;
     }
 }
 
 // Enqueue one pass over the M tokens whose ids / position are already in h->stt (device).
 // want_logits: 0 none, 1 last token only, 2 every token (logits_all).
+// Per layer: [norm+QKV+RoPE/KV-write] -> [split attention] -> [combine] -> [O proj] -> [norm+gate/up+SwiGLU] -> [down]
 static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st) {
     const rca_lm_config_t& c = h->cfg;
     const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim, F = c.ffn;
     const int G = c.n_heads / c.n_kv_heads;
-    const int Mt = M <= 2 ? M : (M <= 4 ? 4 : 8);  // template width (extra rows compute on stale-but-finite data, never stored to state)
+    const int Mt = M <= 2 ? M : (M <= 4 ? 4 : 8);
     const float scale = 1.0f / sqrtf((float)c.head_dim);
-    lm_embed_kernel<<<M, 256, 0, st>>>(h->stt, h->embed, h->x, H, c.vocab_size);
+    const long ps = (long)LM_MAXM * H;
+    const GemvPro nopro{nullptr, nullptr, nullptr, 0, 0, nullptr, 0.0f, 0};
+    GemvRope rope{h->cos_t, h->sin_t, nullptr, nullptr, c.n_heads, c.n_kv_heads, c.n_ctx};
+    const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    float* cur = h->x;
+    float* nxt = h->x2;
+    // decode passes (M <= 2) reduce the down projection's K inside the workgroup; needs ffn % 32 == 0 and
+    // [M][ffn] f32 in LDS
+    const bool in_wg_ksplit = Mt <= 2 && h->ksplit_down == 4 && (F % 32) == 0;
+    lm_embed_kernel<<<M, 256, 0, st>>>(h->stt, h->embed, cur, H, c.vocab_size);
     for (int l = 0; l < c.n_layers; ++l) {
         const LmLayer& L = h->layers[l];
-        // residual add of the previous layer's down-projection partials is folded into this norm
-        lm_add_rmsnorm_kernel<<<M, 256, 0, st>>>(h->stt, h->x, h->part_d, l == 0 ? 0 : h->ksplit_down, (long)LM_MAXM * H, L.attn_norm, h->xn, H, c.rms_eps, 0);
-        gemv(h, Mt, L.wqkv, h->xn, h->qkv, QKV, H, H, 1, 0, QKV, 0, 0, st);
         f16_t* kc = h->kc + (long)l * h->kv_layer_stride;
         f16_t* vc = h->vc + (long)l * h->kv_layer_stride;
-        lm_rope_kv_kernel<<<M, 256, 0, st>>>(h->stt, h->qkv, h->cos_t, h->sin_t, kc, vc, c.n_heads, c.n_kv_heads, c.head_dim, c.n_ctx);
+        rope.kc = kc; rope.vc = vc;
+        // the previous layer's down-projection partials join the residual stream inside this prologue
+        const int np1 = (l == 0 || in_wg_ksplit) ? 0 : h->ksplit_down;
+        GemvPro p1{cur, np1 ? nxt : nullptr, h->part_d, np1, ps, L.attn_norm, c.rms_eps, 0};
+        launch_gemv<1, 2>(h, Mt, L.wqkv, nullptr, h->qkv, QKV, H, H, 1, 0, QKV, p1, rope, st);
+        if (np1) std::swap(cur, nxt);
         dim3 ag(c.n_kv_heads, h->n_splits, (M + 1) / 2);
         if (G == 4) {
             lm_attn_kernel<4><<<ag, 256, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale);
@@ -944,19 +1161,23 @@ static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st) {
             lm_attn_kernel<1><<<ag, 256, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale);
             lm_attn_combine_kernel<1><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
         }
-        gemv(h, Mt, L.wo, h->attn, h->part_o, H, AO, AO, 1, 0, H, 0, 0, st);
-        lm_add_rmsnorm_kernel<<<M, 256, 0, st>>>(h->stt, h->x, h->part_o, 1, (long)LM_MAXM * H, L.ffn_norm, h->xn, H, c.rms_eps, 0);
-        gemv(h, Mt, L.wgu, h->xn, h->hbuf, 2 * F, H, H, 1, 0, F, 1, 0, st);
-        gemv(h, Mt, L.wdown, h->hbuf, h->part_d, H, F, h->kslice_down, h->ksplit_down, (long)LM_MAXM * H, H, 0, 0, st);
+        // O projection adds straight into the residual stream (one K slice: each output has a single writer)
+        launch_gemv<0, 3>(h, Mt, L.wo, h->attn, cur, H, AO, AO, 1, 0, H, nopro, norope, st);
+        GemvPro p2{cur, nullptr, nullptr, 0, 0, L.ffn_norm, c.rms_eps, 0};
+        launch_gemv<1, 1>(h, Mt, L.wgu, nullptr, h->hbuf, 2 * F, H, H, 1, 0, F, p2, norope, st);
+        if (in_wg_ksplit) {
+            // decode: the 4 waves of a workgroup split K and add x + p0 + p1 + p2 + p3 in place
+            if (Mt == 1) launch_gemv_t<1, 0, 3, 1>(h, L.wdown, h->hbuf, cur, H, F, F / 4, 4, 0, H, nopro, norope, st);
+            else launch_gemv_t<2, 0, 3, 1>(h, L.wdown, h->hbuf, cur, H, F, F / 4, 4, 0, H, nopro, norope, st);
+        } else {
+            // prefill chunks: K slices across workgroups; the partials join the residual in the next prologue
+            launch_gemv<0, 0>(h, Mt, L.wdown, h->hbuf, h->part_d, H, F, h->kslice_down, h->ksplit_down, ps, H, nopro, norope, st);
+        }
     }
-    if (want_logits == 1) {
-        lm_add_rmsnorm_kernel<<<1, 256, 0, st>>>(h->stt, h->x, h->part_d, h->ksplit_down, (long)LM_MAXM * H, h->final_norm, h->xn, H, c.rms_eps, 1);
-        gemv(h, 1, h->head, h->xn, h->logits, c.vocab_size, H, H, 1, 0, c.vocab_size, 0, 0, st);
-    } else if (want_logits == 2) {
-        lm_add_rmsnorm_kernel<<<M, 256, 0, st>>>(h->stt, h->x, h->part_d, h->ksplit_down, (long)LM_MAXM * H, h->final_norm, h->xn, H, c.rms_eps, 0);
-        gemv(h, Mt, h->head, h->xn, h->logits, c.vocab_size, H, H, 1, 0, c.vocab_size, 0, 0, st);
+    if (want_logits) {
+        GemvPro pf{cur, nullptr, h->part_d, in_wg_ksplit ? 0 : h->ksplit_down, ps, h->final_norm, c.rms_eps, want_logits == 1 ? 1 : 0};
+        launch_gemv<1, 0>(h, want_logits == 1 ? 1 : Mt, h->head, nullptr, h->logits, c.vocab_size, H, H, 1, 0, c.vocab_size, pf, norope, st);
     }
-    lm_advance_kernel<<<1, 1, 0, st>>>(h->stt);
     RCA_LAUNCH_CHECK();
     return RCA_OK;
 }
@@ -1069,6 +1290,13 @@ extern "C" int rca_lm_sampler_init(rca_lm_t* h, const rca_sampler_params_t* p) {
     return RCA_OK;
 }
 
+static void lm_enqueue_sample(rca_lm* h, const float* lg, hipStream_t st) {
+    const int V = h->cfg.vocab_size;
+    samp_hist_kernel<<<128, 256, 0, st>>>(lg, V, h->samp, h->swork);
+    samp_gather_kernel<<<128, 256, 0, st>>>(lg, V, h->samp, h->swork);
+    samp_final_kernel<<<1, 1024, 0, st>>>(lg, V, h->samp, h->stt, h->swork);
+}
+
 static int lm_fetch_token(rca_lm* h, int32_t* token, hipStream_t st) {
     RCA_HIP(hipMemcpyAsync(&h->h_stt->out_token, &h->stt->out_token, 4, hipMemcpyDeviceToHost, st));
     RCA_HIP(hipStreamSynchronize(st));
@@ -1082,7 +1310,7 @@ extern "C" int rca_lm_sample(rca_lm_t* h, int32_t* token) {
     if (h->logits_rows < 1) return fail(RCA_ERR_STATE, "no logits: call eval first");
     RCA_HIP(hipSetDevice(h->device));
     const float* lg = h->logits + (long)(h->logits_rows - 1) * h->cfg.vocab_size;
-    lm_sample_kernel<<<1, 1024, 0, h->stream>>>(lg, h->cfg.vocab_size, h->samp, h->stt, 0);
+    lm_enqueue_sample(h, lg, h->stream);
     RCA_LAUNCH_CHECK();
     return lm_fetch_token(h, token, h->stream);
 }
@@ -1111,7 +1339,7 @@ extern "C" int rca_lm_step(rca_lm_t* h, const int32_t* ids, int32_t n, int32_t* 
         hipError_t e = hipMemcpyAsync(h->stt, h->h_stt, 8 + 4 * LM_MAXM, hipMemcpyHostToDevice, st);
         rc = e == hipSuccess ? lm_enqueue_pass(h, n, 1, st) : fail(RCA_ERR_HIP, "capture memcpy: %s", hipGetErrorString(e));
         if (rc == RCA_OK) {
-            lm_sample_kernel<<<1, 1024, 0, st>>>(h->logits, h->cfg.vocab_size, h->samp, h->stt, 0);
+            lm_enqueue_sample(h, h->logits, st);
             e = hipMemcpyAsync(&h->h_stt->out_token, &h->stt->out_token, 4, hipMemcpyDeviceToHost, st);
             if (e != hipSuccess) rc = fail(RCA_ERR_HIP, "capture d2h: %s", hipGetErrorString(e));
         }
@@ -1148,5 +1376,20 @@ extern "C" int rca_lm_token_probs(rca_lm_t* h, const int32_t* token_ids, int32_t
 extern "C" int rca_lm_set_graphs(rca_lm_t* h, int32_t enable) {
     if (!h) return fail(RCA_ERR_ARG, "null");
     h->graphs_enabled = enable != 0;
+    return RCA_OK;
+}
+
+__global__ __launch_bounds__(256) void lm_zero_rows_kernel(bf16_t* __restrict__ w, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) w[i] = 0;
+}
+// zero lm_head rows [row_begin, row_end): used with random-init weights so that, like a trained codec LM in
+// audio mode, the sampler's top-k only ever holds codec tokens (text rows get logit 0)
+extern "C" int rca_lm_mask_head_rows(rca_lm_t* h, int32_t row_begin, int32_t row_end) {
+    if (!h || row_begin < 0 || row_end > h->cfg.vocab_size || row_begin > row_end) return fail(RCA_ERR_ARG, "mask_head_rows: bad range");
+    RCA_HIP(hipSetDevice(h->device));
+    const long n = (long)(row_end - row_begin) * h->cfg.hidden;
+    if (n > 0) lm_zero_rows_kernel<<<2048, 256, 0, h->stream>>>(h->head + (long)row_begin * h->cfg.hidden, n);
+    RCA_LAUNCH_CHECK();
+    RCA_HIP(hipStreamSynchronize(h->stream));
     return RCA_OK;
 }

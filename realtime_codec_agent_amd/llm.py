@@ -401,6 +401,10 @@ class LlamaForAlternatingCodeChannels:
     def sync(self) -> None:
         N.check(self._lib.rca_lm_sync(self._h), "rca_lm_sync")
 
+    def mask_head_rows(self, row_begin: int, row_end: int) -> None:
+        """Zero lm_head rows (random-init models: keep sampling on codec tokens like a trained model in audio mode)."""
+        N.check(self._lib.rca_lm_mask_head_rows(self._h, int(row_begin), int(row_end)), "rca_lm_mask_head_rows")
+
     def set_graphs(self, enable: bool) -> None:
         N.check(self._lib.rca_lm_set_graphs(self._h, 1 if enable else 0), "rca_lm_set_graphs")
 

@@ -45,6 +45,14 @@ class RealtimeAgentResources:
         self.tokenizer = tokenizer
         if self.tokenizer.vocab_size > self.llm.n_vocab():
             raise ValueError(f"tokenizer has {self.tokenizer.vocab_size} ids but the LM has {self.llm.n_vocab()} logits")
+        if llm_model_path.startswith("random:"):
+            # A trained codec LM in audio mode puts its probability mass on codec tokens.  Random-init weights
+            # do not, so the text / padding rows of lm_head are zeroed: the top-k then holds codec tokens only
+            # and the loop stays on its steady-state path.  Bytes streamed per step are unchanged.
+            for m in (self.llm, self.aux_llm):
+                if m is not None and hasattr(self.tokenizer, "codec_vocab_start"):
+                    m.mask_head_rows(0, self.tokenizer.codec_vocab_start)
+                    m.mask_head_rows(len(self.tokenizer), m.n_vocab())
         self._llm_config = self.llm.config
         self._llm_random_seed = llm_random_seed
 
