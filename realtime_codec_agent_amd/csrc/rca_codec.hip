@@ -168,7 +168,7 @@ struct ConvLds {
 };
 
 template <int KS, int S, int CIC, int WM, int WN>
-__global__ __launch_bounds__(256) void conv1d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+__global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           int Cin, int Lin, int Cout, int Lout, long Ncols, int nchunks,
                                                           int pre, float slope) {
@@ -189,8 +189,17 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const float* __restric
     const int half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* xs = xs_all + wave * 2 * BUF;
-    const long n0 = ((long)blockIdx.x * 4 + wave) * NW;   // first column of this wave
-    const int co0 = blockIdx.y * MT;
+    // Workgroup id -> (column tile, channel tile).  Workgroups are dealt round-robin to the 8 XCDs, each with
+    // its own L2: consecutive workgroups OF ONE XCD walk the channel tiles of the same column tile, so the
+    // input span is fetched from HBM once and re-read from that XCD's L2 (speed only; any placement is correct).
+    const int n_co = (Cout + MT - 1) / MT;
+    const long wg = blockIdx.x;
+    const int xcd = (int)(wg & 7);
+    const long seq = wg >> 3;
+    const int co_tile = (int)(seq % n_co);
+    const long col_tile = (seq / n_co) * 8 + xcd;
+    const long n0 = (col_tile * 4 + wave) * NW;   // first column of this wave
+    const int co0 = co_tile * MT;
     if (n0 >= Ncols) return;  // whole wave out of range (no barriers: safe)
 
     // ---- staging role: element e -> (slot, phase); fixed per lane, channel added per load
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const float* __restric
     auto load_w = [&](float4 (&a)[WM][QPC], int c) {
 #pragma unroll
         for (int wm = 0; wm < WM; ++wm) {
-            const int cot = blockIdx.y * WM + wm;
+            const int cot = co_tile * WM + wm;
             const float4* p = reinterpret_cast<const float4*>(wp) + ((long)cot * kquads + (long)c * QPC) * 64 + lane;
 #pragma unroll
             for (int q = 0; q < QPC; ++q) a[wm][q] = p[q * 64];
@@ -282,21 +291,32 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const float* __restric
     };
     auto compute = [&](const float4 (&a)[WM][QPC], int buf) {
         const float* xb = xs + buf * BUF;
+        // the B fragments of (half) a chunk are requested up front; the MFMAs then consume them in order
+        // behind counted lgkmcnt waits, so the matrix pipe is not re-stalled on LDS latency every k step
+        constexpr int NB = (KPC * WN > 32) ? ((KPC % 4 == 0) ? 4 : 2) : 1;  // register budget for the fragment prefetch
+        constexpr int PB = KPC / NB;
+        static_assert(KPC % NB == 0, "batching");
 #pragma unroll
-        for (int kp = 0; kp < KPC; ++kp) {
-            float bfr[WN];
+        for (int nb = 0; nb < NB; ++nb) {
+            float bv[PB][WN];
 #pragma unroll
-            for (int wn = 0; wn < WN; ++wn) {
-                const float v = xb[b_off[kp] + wn * 32];
-                bfr[wn] = ((zmask[wn] >> kp) & 1u) ? 0.0f : v;
-            }
+            for (int i = 0; i < PB; ++i)
 #pragma unroll
-            for (int wm = 0; wm < WM; ++wm) {
-                const float4 q4 = a[wm][kp >> 2];
-                const float av = (kp & 3) == 0 ? q4.x : (kp & 3) == 1 ? q4.y : (kp & 3) == 2 ? q4.z : q4.w;
+                for (int wn = 0; wn < WN; ++wn) bv[i][wn] = xb[b_off[nb * PB + i] + wn * 32];
 #pragma unroll
-                for (int wn = 0; wn < WN; ++wn)
-                    acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bfr[wn], acc[wm][wn], 0, 0, 0);
+            for (int i = 0; i < PB; ++i) {
+                const int kp = nb * PB + i;
+                float bfr[WN];
+#pragma unroll
+                for (int wn = 0; wn < WN; ++wn) bfr[wn] = ((zmask[wn] >> kp) & 1u) ? 0.0f : bv[i][wn];
+#pragma unroll
+                for (int wm = 0; wm < WM; ++wm) {
+                    const float4 q4 = a[wm][kp >> 2];
+                    const float av = (kp & 3) == 0 ? q4.x : (kp & 3) == 1 ? q4.y : (kp & 3) == 2 ? q4.z : q4.w;
+#pragma unroll
+                    for (int wn = 0; wn < WN; ++wn)
+                        acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bfr[wn], acc[wm][wn], 0, 0, 0);
+                }
             }
         }
     };
@@ -591,11 +611,11 @@ struct ConvLayer {
 
 // input channels per K chunk of the MFMA conv, by (kernel size, stride)
 static int conv_cic(int k, int s) {
-    if (k == 4 && s == 2) return 8;
+    if (k == 4 && s == 2) return 4;
     if (k == 8 && s == 4) return 4;
     if (k == 10 && s == 5) return 4;
     if (k == 16 && s == 8) return 2;
-    if (k == 3 && s == 1) return 16;
+    if (k == 3 && s == 1) return 8;
     return 0;
 }
 
@@ -801,7 +821,9 @@ static void launch_conv_cfg(const ConvLayer& L, const float* x, float* y, int Li
     constexpr int NT = 4 * WN * 32, MT = WM * 32;
     constexpr int lds = 4 * 2 * (CIC * S * ConvLds<S>::stride(WN * 32) + 4) * 4;
     static_assert(lds <= 65536, "LDS budget");
-    dim3 grid(cdiv(Ncols, NT), cdiv(L.cout, MT));
+    // 1-D grid: column tiles padded to a multiple of 8 (one per XCD), times the channel tiles
+    const long col_tiles = (cdiv(Ncols, NT) + 7) / 8 * 8;
+    dim3 grid((unsigned)(col_tiles * cdiv(L.cout, MT)));
     conv1d_mfma_kernel<KS, S, CIC, WM, WN><<<grid, 256, lds, st>>>(x, L.wp, L.b, y, L.cin, Lin, L.cout, Lout, Ncols, L.nchunks, L.pre, slope);
 }
 
@@ -830,11 +852,11 @@ static int run_conv(rca_codec* h, const ConvLayer& L, const float* x, float* y, 
     const double cbytes = 4.0 * ((double)B * L.cin * Lin + (double)B * L.cout * Lout + (double)L.cin * L.k * L.cout);
     if (h->variant == 1 && L.wp && !clamp_out) {
         ProfScope ps(h, st, 0, cflops, cbytes);
-        if (L.k == 4 && L.s == 2) return launch_conv_mfma<4, 2, 8>(L, x, y, B, Lin, Lout, slope, st);
+        if (L.k == 4 && L.s == 2) return launch_conv_mfma<4, 2, 4>(L, x, y, B, Lin, Lout, slope, st);
         if (L.k == 8 && L.s == 4) return launch_conv_mfma<8, 4, 4>(L, x, y, B, Lin, Lout, slope, st);
         if (L.k == 10 && L.s == 5) return launch_conv_mfma<10, 5, 4>(L, x, y, B, Lin, Lout, slope, st);
         if (L.k == 16 && L.s == 8) return launch_conv_mfma<16, 8, 2>(L, x, y, B, Lin, Lout, slope, st);
-        if (L.k == 3 && L.s == 1) return launch_conv_mfma<3, 1, 16>(L, x, y, B, Lin, Lout, slope, st);
+        if (L.k == 3 && L.s == 1) return launch_conv_mfma<3, 1, 8>(L, x, y, B, Lin, Lout, slope, st);
     }
     const long total = (long)B * L.cout * Lout;
     ProfScope ps(h, st, 3, cflops, cbytes);

@@ -1,0 +1,119 @@
+"""The N>1 path on CPU: two gloo ranks run the sharded batch-encode CLI (no data-path collective) with a
+CPU encoder injected; outputs must equal the single-process run.  Also the ABI surface check."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+import wave
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, bench_signal, rich_signal
+from realtime_codec_agent_amd.dist_utils import shard_by_duration, shard_chunk_range
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+from oracle.codec import OracleCodec
+from realtime_codec_agent_amd.codec_model import init_codec_weights, tiny_codec_config
+from realtime_codec_agent_amd import audio_to_codes
+
+class CpuEncoder:  # test-only stand-in for HipWindowEncoder
+    def __init__(self):
+        self.cfg = tiny_codec_config()
+        self.oc = OracleCodec(self.cfg, init_codec_weights(self.cfg, seed=0))
+    def encode(self, audio, chunk, ctx, batch):
+        return self.oc.encode_windows(audio, chunk, ctx)
+
+out = audio_to_codes.main({argv!r}, encoder=CpuEncoder(), backend="gloo")
+'''
+
+
+def _make_corpus(tmp):
+    raw = os.path.join(tmp, "raw")
+    os.makedirs(os.path.join(raw, "CallHome", "a"))
+    os.makedirs(os.path.join(raw, "Other"))
+    lens = {"CallHome/a/x1.wav": 9600, "CallHome/a/x2.wav": 25600, "CallHome/x3.npy": 16000, "Other/y.wav": 8000, "CallHome/x4.wav": 12800}
+    for i, (rel, n) in enumerate(lens.items()):
+        sig = np.stack([bench_signal(n, i), rich_signal(n, i + 10)])
+        p = os.path.join(raw, rel)
+        if rel.endswith(".npy"):
+            np.save(p, sig)
+        else:
+            with wave.open(p, "wb") as w:
+                w.setnchannels(2); w.setsampwidth(2); w.setframerate(16000)
+                w.writeframes((np.clip(sig.T, -1, 1) * 32767).astype("<i2").tobytes())
+    return raw
+
+
+def _run(tmp, raw, world, tag):
+    codes = os.path.join(tmp, f"codes_{tag}")
+    argv = ["--audio_path", raw, "--codes_path", codes, "--stereo", "--audio_filter", "CallHome"]
+    script = os.path.join(tmp, f"worker_{tag}.py")
+    with open(script, "w") as f:
+        f.write(WORKER.format(root=ROOT, argv=argv))
+    if world == 1:
+        env = dict(os.environ, RANK="0", WORLD_SIZE="1")
+        out = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=300)
+    else:
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                              "--master-port", "29541", script], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    summary = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    return codes, summary
+
+
+def test_sharded_batch_encode_two_gloo_ranks(tmp_path):
+    tmp = str(tmp_path)
+    raw = _make_corpus(tmp)
+    c1, s1 = _run(tmp, raw, 1, "w1")
+    c2, s2 = _run(tmp, raw, 2, "w2")
+    assert s1["files"] == s2["files"] == 4 and s2["world_size"] == 2
+    assert s1["codes"] == s2["codes"] == 2 * 5 * (6 + 16 + 10 + 8) and abs(s1["audio_hours"] - s2["audio_hours"]) < 1e-12
+    files1 = sorted(os.path.relpath(os.path.join(r, f), c1) for r, _, fs in os.walk(c1) for f in fs)
+    files2 = sorted(os.path.relpath(os.path.join(r, f), c2) for r, _, fs in os.walk(c2) for f in fs)
+    assert files1 == files2 and len(files1) == 1 + 2 * 4
+    for f in files1:
+        if f.endswith(".npy"):
+            a, b = np.load(os.path.join(c1, f)), np.load(os.path.join(c2, f))
+            assert a.shape == b.shape and a.ndim == 2 and a.shape[0] == 1 and a.dtype == np.int64 and np.array_equal(a, b)
+            assert re.match(r"(.+)_c(\d+)[_.]", os.path.basename(f))  # lm_dataset_builder.py:79
+    info = json.load(open(os.path.join(c1, "MagiCodec-50Hz-Base", "0.1s_2.0s", "stereo", "codec_info.json")))
+    assert info == {"num_codebooks": 1, "codebook_size": 1024, "framerate": 50.0}
+    assert os.path.isdir(os.path.join(c1, "MagiCodec-50Hz-Base", "0.1s_2.0s", "stereo", "CallHome", "a"))
+
+
+def test_shard_plans():
+    d = [5.0, 1.0, 3.0, 3.0, 8.0, 0.5, 2.0]
+    for world in (1, 2, 3, 8):
+        shards = shard_by_duration(d, world)
+        assert sorted(i for s in shards for i in s) == list(range(len(d))) and len(shards) == world
+        loads = [sum(d[i] for i in s) for s in shards]
+        assert max(loads) - min(loads) <= max(d)
+    assert shard_by_duration(d, 2) == shard_by_duration(d, 2)
+    for n, w in ((10, 3), (7, 8), (36000, 8)):
+        rs = [shard_chunk_range(n, w, r) for r in range(w)]
+        assert rs[0][0] == 0 and rs[-1][1] == n and all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
+        assert max(b - a for a, b in rs) - min(b - a for a, b in rs) <= 1
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    """The in-tree HIP library loads without a GPU and exports exactly the entry points include/rca.h
+    declares (no compute call is made here)."""
+    from realtime_codec_agent_amd import _native
+    header = open(os.path.join(ROOT, "include", "rca.h")).read()
+    declared = sorted(set(re.findall(r"\b(rca_[a-z0-9_]+)\s*\(", header)))
+    assert declared == sorted(_native.ABI_SYMBOLS)
+    if _native.needs_build():
+        _native.build()
+    lib = _native.lib()
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert b"gfx950" in lib.rca_version()
+    # error behaviour without a device: bad arguments are rejected before any HIP call
+    lib.rca_codec_hop.restype = ctypes.c_int
+    assert lib.rca_codec_hop(None, None) == -1 and b"null" in lib.rca_last_error()
