@@ -193,13 +193,16 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_encode(cfg, weights, chunk, ctx, 64, C)
-    if world == 1 and not args.no_duplex:
-        try:
-            from realtime_codec_agent_amd.duplex_bench import run_duplex_bench
-        except ImportError:
-            run_duplex_bench = None
-        if run_duplex_bench is not None:
-            out["duplex"] = run_duplex_bench(dev, secs=args.duplex_secs)
+    if not args.no_duplex:
+        # one independent duplex session per GPU (BASELINE configs[3]/[4]; no exchange between sessions)
+        from realtime_codec_agent_amd.duplex_bench import run_duplex_bench
+        mine = run_duplex_bench(dev, secs=args.duplex_secs if world == 1 else min(args.duplex_secs, 10.0))
+        if dist is not None:
+            allr = [None] * world
+            dist.all_gather_object(allr, {k: mine[k] for k in ("xRT", "p50_frame_step_ms", "p95_frame_step_ms", "lm_step_ms")})
+            mine = dict(mine, sessions=world, per_gpu=allr, xRT_min=min(r["xRT"] for r in allr),
+                        p50_frame_step_ms_max=max(r["p50_frame_step_ms"] for r in allr))
+        out["duplex"] = mine
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

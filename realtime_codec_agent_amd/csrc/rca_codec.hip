@@ -326,17 +326,29 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
     load_w(a0, 0);
     stage_write(0, 0);
     __builtin_amdgcn_wave_barrier();
+    const int lastc = nchunks - 1;
     for (int c = 0; c < nchunks; c += 2) {
-        const bool more1 = (c + 1) < nchunks;
-        if (more1) { load_w(a1, c + 1); stage_load(c + 1); }
+        // The next chunk's loads are issued UNCONDITIONALLY (past the end they re-read the last chunk and the
+        // result is never used): a branch around them would merge two paths in front of the MFMA block and
+        // force its s_waitcnt to the conservative vmcnt(~0) of the path without newer loads.
+        // sched_barrier(0) pins the three phases in program order so the scheduler does not sink the loads
+        // down to their first use.
+        const int c1 = min(c + 1, lastc);
+        load_w(a1, c1);
+        stage_load(c1);
+        __builtin_amdgcn_sched_barrier(0);
         compute(a0, 0);
-        if (more1) stage_write(c + 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_write(c1, 1);
         __builtin_amdgcn_wave_barrier();
-        if (!more1) break;
-        const bool more2 = (c + 2) < nchunks;
-        if (more2) { load_w(a0, c + 2); stage_load(c + 2); }
+        if (c + 1 >= nchunks) break;
+        const int c2 = min(c + 2, lastc);
+        load_w(a0, c2);
+        stage_load(c2);
+        __builtin_amdgcn_sched_barrier(0);
         compute(a1, 1);
-        if (more2) stage_write(c + 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_write(c2, 0);
         __builtin_amdgcn_wave_barrier();
     }
 
