@@ -167,11 +167,20 @@ struct ConvLds {
     }
 };
 
-template <int KS, int S, int CIC, int WM, int WN>
+// FUSE = 1 (first strided layer only): the input channels are not read from HBM but recomputed on the fly as
+// conv_in(PCM) -- 7-tap Cin=1 conv, bias first, taps ascending, exactly conv_in_kernel's chain -- from a
+// per-lane register window of raw PCM that is loaded once per wave.  Removes conv_in's 1 GB write and this
+// layer's 1 GB read per 256-window step.
+struct FuseIn {
+    RowSrc src;           // raw PCM rows
+    const float* w_in;    // [Cin][7]
+    const float* b_in;    // [Cin]
+};
+template <int KS, int S, int CIC, int WM, int WN, int FUSE>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           int Cin, int Lin, int Cout, int Lout, long Ncols, int nchunks,
-                                                          int pre, float slope) {
+                                                          int pre, float slope, FuseIn fin) {
     constexpr int MT = WM * 32;            // channels per wave (and per workgroup)
     constexpr int NW = WN * 32;            // columns per wave
     constexpr int U = ConvLds<S>::stride(NW);
@@ -203,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
     if (n0 >= Ncols) return;  // whole wave out of range (no barriers: safe)
 
     // ---- staging role: element e -> (slot, phase); fixed per lane, channel added per load
-    long s_goff[RE];   // offset of x[b][0][t*S + p] (0 when the slot is outside the signal)
+    unsigned s_goff[RE];   // element offset of x[b][0][t*S + p] (0 when the slot is outside the signal); < 2^32 by the host check
     int s_loff[RE];    // p*U + slot; -1: lane past the window (its write lands in the spare word)
     bool s_ok[RE];
 #pragma unroll
@@ -216,7 +225,26 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
         const long nn = s_ok[r] ? n : 0;
         const long b = nn / Lout;
         const int t = (int)(nn - b * Lout);
-        s_goff[r] = s_ok[r] ? b * Cin * (long)Lin + (long)t * S + p : 0;
+        s_goff[r] = s_ok[r] ? (unsigned)(b * Cin * (long)Lin + (long)t * S + p) : 0u;
+    }
+    // ---- fused conv_in: 7-sample PCM window per staged element (zero outside the row's valid samples)
+    float pc[FUSE ? RE : 1][7];
+    if (FUSE) {
+#pragma unroll
+        for (int r = 0; r < RE; ++r) {
+            const int e = lane + 64 * r;
+            const int slot = e / S, p = e - slot * S;
+            const long n = n0 - 1 + slot;
+            const long nn = s_ok[r] ? n : 0;
+            const long b = nn / Lout;
+            const int i = (int)(nn - b * Lout) * S + p;  // PCM sample index == conv_in output index
+            const float* row = fin.src.base + (long)(b % fin.src.C) * fin.src.chan_stride + (long)(b / fin.src.C) * fin.src.win_stride;
+#pragma unroll
+            for (int kk = 0; kk < 7; ++kk) {
+                const int j = i + kk - 3;
+                pc[r][kk] = (s_ok[r] && j >= 0 && j < fin.src.T) ? row[j] : 0.0f;
+            }
+        }
     }
     // ---- B-read role: per k-pair LDS offset and edge masks for this lane's half
     int b_off[KPC];
@@ -253,6 +281,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
         }
     }
 
+    const float act_slope = pre ? slope : 1.0f;  // slope 1 = identity (no pre-activation)
     float sreg[CIC][RE];
     auto stage_load = [&](int c) {
 #pragma unroll
@@ -260,9 +289,23 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
             const int ci = c * CIC + cl;
             // branch-free: every lane loads from a valid address (slot outside the signal -> element 0) and the
             // value is discarded at the LDS write.  Raw value only: nothing consumes it before the MFMA block.
-            const float* xc = x + (long)(ci < Cin ? ci : 0) * Lin;
+            if (FUSE) {
+                const int cc = ci < Cin ? ci : 0;
+                const float* wr = fin.w_in + cc * 7;   // wave-uniform: scalar loads
+                const float bi = fin.b_in[cc];
 #pragma unroll
-            for (int r = 0; r < RE; ++r) sreg[cl][r] = xc[s_goff[r]];
+                for (int r = 0; r < RE; ++r) {
+                    float a = bi;
+                    // out-of-range taps hold 0: fma(w, 0, a) == a (the oracle skips them)
+#pragma unroll
+                    for (int kk = 0; kk < 7; ++kk) a = __builtin_fmaf(wr[kk], pc[r][kk], a);
+                    sreg[cl][r] = a;
+                }
+            } else {
+                const float* xc = x + (long)(ci < Cin ? ci : 0) * Lin;
+#pragma unroll
+                for (int r = 0; r < RE; ++r) sreg[cl][r] = xc[s_goff[r]];
+            }
         }
     };
     auto stage_write = [&](int c, int buf) {
@@ -273,7 +316,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
 #pragma unroll
             for (int r = 0; r < RE; ++r) {
                 float v = (s_ok[r] && cok) ? sreg[cl][r] : 0.0f;
-                if (pre) v = lrelu(v, slope);
+                // LeakyReLU as max(v, slope*v): identical values for 0 < slope < 1 (incl. -0), two VALU ops
+                v = fmaxf(v, v * act_slope);
                 dst[s_loff[r] >= 0 ? cl * S * U + s_loff[r] : CIC * S * U] = v;
             }
         }
@@ -337,7 +381,9 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
         load_w(a1, c1);
         stage_load(c1);
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
         compute(a0, 0);
+        __builtin_amdgcn_s_setprio(2);  // staging phases run at raised priority (measured +2.4 %)
         __builtin_amdgcn_sched_barrier(0);
         stage_write(c1, 1);
         __builtin_amdgcn_wave_barrier();
@@ -346,7 +392,9 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
         load_w(a0, c2);
         stage_load(c2);
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
         compute(a1, 1);
+        __builtin_amdgcn_s_setprio(2);
         __builtin_amdgcn_sched_barrier(0);
         stage_write(c2, 0);
         __builtin_amdgcn_wave_barrier();
@@ -742,6 +790,7 @@ extern "C" int rca_codec_create(const rca_codec_config_t* cfg, const rca_tensor_
     if (cfg->codebook_dim != 16) return fail(RCA_ERR_ARG, "codebook_dim must be 16 (got %d)", cfg->codebook_dim);
     if (cfg->codebook_size % 128 != 0) return fail(RCA_ERR_ARG, "codebook_size must be a multiple of 128");
     if (cfg->k_in != 7 && cfg->k_in != 3 && cfg->k_in != 5) return fail(RCA_ERR_ARG, "k_in must be 3, 5 or 7");
+    if (!(cfg->leaky_slope > 0.0f && cfg->leaky_slope < 1.0f)) return fail(RCA_ERR_ARG, "leaky_slope must be in (0, 1)");
     RCA_HIP(hipSetDevice(device));
     rca_codec* h = new rca_codec();
     h->cfg = *cfg;
@@ -828,25 +877,33 @@ extern "C" int rca_codec_sync(rca_codec_t* h) {
     return RCA_OK;
 }
 
-template <int KS, int S, int CIC, int WM, int WN>
-static void launch_conv_cfg(const ConvLayer& L, const float* x, float* y, int Lin, int Lout, long Ncols, float slope, hipStream_t st) {
+template <int KS, int S, int CIC, int WM, int WN, int FUSE>
+static void launch_conv_cfg(const ConvLayer& L, const float* x, float* y, int Lin, int Lout, long Ncols, float slope, const FuseIn& fin,
+                            hipStream_t st) {
     constexpr int NT = 4 * WN * 32, MT = WM * 32;
     constexpr int lds = 4 * 2 * (CIC * S * ConvLds<S>::stride(WN * 32) + 4) * 4;
     static_assert(lds <= 65536, "LDS budget");
     // 1-D grid: column tiles padded to a multiple of 8 (one per XCD), times the channel tiles
     const long col_tiles = (cdiv(Ncols, NT) + 7) / 8 * 8;
     dim3 grid((unsigned)(col_tiles * cdiv(L.cout, MT)));
-    conv1d_mfma_kernel<KS, S, CIC, WM, WN><<<grid, 256, lds, st>>>(x, L.wp, L.b, y, L.cin, Lin, L.cout, Lout, Ncols, L.nchunks, L.pre, slope);
+    conv1d_mfma_kernel<KS, S, CIC, WM, WN, FUSE><<<grid, 256, lds, st>>>(x, L.wp, L.b, y, L.cin, Lin, L.cout, Lout, Ncols, L.nchunks, L.pre, slope, fin);
 }
 
 template <int KS, int S, int CIC>
-static int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B, int Lin, int Lout, float slope, hipStream_t st) {
+static int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B, int Lin, int Lout, float slope, hipStream_t st,
+                            const FuseIn* fuse = nullptr) {
     const long Ncols = (long)B * Lout;
     // wave tile 64 channels x 64 columns while that still yields >= ~2 waves per SIMD on the chip,
     // otherwise 32 x 32 tiles (4x the waves; streaming / small batches)
     const long waves_big = (long)cdiv(Ncols, 64) * cdiv(L.cout, 64);
-    if (waves_big >= 2048) launch_conv_cfg<KS, S, CIC, 2, 2>(L, x, y, Lin, Lout, Ncols, slope, st);
-    else launch_conv_cfg<KS, S, CIC, 1, 1>(L, x, y, Lin, Lout, Ncols, slope, st);
+    const FuseIn none{};
+    if (fuse) {
+        if (waves_big >= 2048) launch_conv_cfg<KS, S, CIC, 2, 2, 1>(L, x, y, Lin, Lout, Ncols, slope, *fuse, st);
+        else launch_conv_cfg<KS, S, CIC, 1, 1, 1>(L, x, y, Lin, Lout, Ncols, slope, *fuse, st);
+    } else {
+        if (waves_big >= 2048) launch_conv_cfg<KS, S, CIC, 2, 2, 0>(L, x, y, Lin, Lout, Ncols, slope, none, st);
+        else launch_conv_cfg<KS, S, CIC, 1, 1, 0>(L, x, y, Lin, Lout, Ncols, slope, none, st);
+    }
     RCA_LAUNCH_CHECK();
     return RCA_OK;
 }
@@ -862,7 +919,8 @@ static int run_conv(rca_codec* h, const ConvLayer& L, const float* x, float* y, 
     const int Lout = Lin / L.s;
     const double cflops = 2.0 * L.cin * L.k * L.cout * (double)B * Lout;
     const double cbytes = 4.0 * ((double)B * L.cin * Lin + (double)B * L.cout * Lout + (double)L.cin * L.k * L.cout);
-    if (h->variant == 1 && L.wp && !clamp_out) {
+    // the MFMA kernel indexes the input with 32-bit element offsets
+    if (h->variant == 1 && L.wp && !clamp_out && (double)B * L.cin * Lin < 4.0e9) {
         ProfScope ps(h, st, 0, cflops, cbytes);
         if (L.k == 4 && L.s == 2) return launch_conv_mfma<4, 2, 4>(L, x, y, B, Lin, Lout, slope, st);
         if (L.k == 8 && L.s == 4) return launch_conv_mfma<8, 4, 4>(L, x, y, B, Lin, Lout, slope, st);
@@ -896,7 +954,29 @@ static int run_encoder(rca_codec* h, RowSrc src, int B, hipStream_t st, float** 
     if ((rc = h->act[1].ensure(max_elems * 4)) != RCA_OK) return rc;
     int cur = 0;
     int L = Tp;
-    {
+    size_t first = 1;
+    const ConvLayer& E0 = h->enc[0];
+    const ConvLayer& E1 = h->enc[1];
+    // conv_in fused into the first strided layer (MFMA variant, 7-tap conv_in, layer 0 not tapped)
+    const bool fuse01 = h->variant == 1 && tap_layer != 0 && E0.k == 7 && E1.wp && E1.k == 2 * E1.s && (double)B * E1.cin * L < 4.0e9 &&
+                        ((E1.k == 4 && E1.s == 2) || (E1.k == 8 && E1.s == 4) || (E1.k == 16 && E1.s == 8));
+    if (fuse01) {
+        float* y = h->act[cur].as<float>();
+        FuseIn fin{src, E0.w, E0.b};
+        const float slope = c.leaky_slope;
+        const int Lout = L / E1.s;
+        {
+            ProfScope ps(h, st, 0, 2.0 * E1.cin * E1.k * E1.cout * (double)B * Lout + 2.0 * E0.k * E0.cout * (double)B * L,
+                         4.0 * ((double)B * src.T + (double)B * E1.cout * Lout + (double)E1.cin * E1.k * E1.cout));
+            if (E1.k == 4) rc = launch_conv_mfma<4, 2, 4>(E1, nullptr, y, B, L, Lout, slope, st, &fin);
+            else if (E1.k == 8) rc = launch_conv_mfma<8, 4, 4>(E1, nullptr, y, B, L, Lout, slope, st, &fin);
+            else rc = launch_conv_mfma<16, 8, 2>(E1, nullptr, y, B, L, Lout, slope, st, &fin);
+        }
+        if (rc != RCA_OK) return rc;
+        L = Lout;
+        first = 2;
+        if (tap_layer == 1) RCA_HIP(hipMemcpyAsync(tap_dev, y, (size_t)B * E1.cout * L * 4, hipMemcpyDeviceToDevice, st));
+    } else {
         const ConvLayer& L0 = h->enc[0];
         const long total = (long)B * L;
         float* y = h->act[cur].as<float>();
@@ -907,7 +987,7 @@ static int run_encoder(rca_codec* h, RowSrc src, int B, hipStream_t st, float** 
         RCA_LAUNCH_CHECK();
         if (tap_layer == 0) RCA_HIP(hipMemcpyAsync(tap_dev, y, (size_t)B * L0.cout * L * 4, hipMemcpyDeviceToDevice, st));
     }
-    for (size_t li = 1; li < h->enc.size(); ++li) {
+    for (size_t li = first; li < h->enc.size(); ++li) {
         const ConvLayer& Ly = h->enc[li];
         float* x = h->act[cur].as<float>();
         float* y = h->act[cur ^ 1].as<float>();
