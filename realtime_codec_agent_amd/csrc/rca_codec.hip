@@ -176,11 +176,18 @@ struct FuseIn {
     const float* w_in;    // [Cin][7]
     const float* b_in;    // [Cin]
 };
-template <int KS, int S, int CIC, int WM, int WN, int FUSE>
+// TR = 1: one launch computes a whole ConvTranspose1d (k = 2s) as s phase GEMMs.  Output u = s*t0 - padL + r
+// (phase r) = bias + sum_ci ( w[ci][co][r] * x[ci][t0] + w[ci][co][r+s] * x[ci][t0-1] ): a 2-tap stride-1 conv over
+// Lin+1 columns per row whose k order (channel-major, tap r before tap r+s) is the oracle's.  The phase rides
+// on the channel-tile index (weights packed per phase), so one column tile's phases share the XCD's L2.
+struct TrInfo {
+    int s, padL, Lout, n_co;   // upsampling stride, left pad, output length per row, real channel tiles
+};
+template <int KS, int S, int CIC, int WM, int WN, int FUSE, int TR>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           int Cin, int Lin, int Cout, int Lout, long Ncols, int nchunks,
-                                                          int pre, float slope, FuseIn fin) {
+                                                          int pre, float slope, FuseIn fin, TrInfo tr) {
     constexpr int MT = WM * 32;            // channels per wave (and per workgroup)
     constexpr int NW = WN * 32;            // columns per wave
     constexpr int U = ConvLds<S>::stride(NW);
@@ -201,11 +208,14 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
     // Workgroup id -> (column tile, channel tile).  Workgroups are dealt round-robin to the 8 XCDs, each with
     // its own L2: consecutive workgroups OF ONE XCD walk the channel tiles of the same column tile, so the
     // input span is fetched from HBM once and re-read from that XCD's L2 (speed only; any placement is correct).
-    const int n_co = (Cout + MT - 1) / MT;
+    const int n_co_real = (Cout + MT - 1) / MT;
+    const int n_co = TR ? n_co_real * tr.s : n_co_real;   // TR: (phase, channel tile) pairs
     const long wg = blockIdx.x;
     const int xcd = (int)(wg & 7);
     const long seq = wg >> 3;
-    const int co_tile = (int)(seq % n_co);
+    const int co_tile_x = (int)(seq % n_co);
+    const int phase = TR ? co_tile_x / n_co_real : 0;
+    const int co_tile = TR ? co_tile_x % n_co_real : co_tile_x;
     const long col_tile = (seq / n_co) * 8 + xcd;
     const long n0 = (col_tile * 4 + wave) * NW;   // first column of this wave
     const int co0 = co_tile * MT;
@@ -225,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
         const long nn = s_ok[r] ? n : 0;
         const long b = nn / Lout;
         const int t = (int)(nn - b * Lout);
+        if (TR && t >= Lin) s_ok[r] = false;   // column t0 = Lin exists (its x[t0-1] tap is valid) but has no x[t0]
         s_goff[r] = s_ok[r] ? (unsigned)(b * Cin * (long)Lin + (long)t * S + p) : 0u;
     }
     // ---- fused conv_in: 7-sample PCM window per staged element (zero outside the row's valid samples)
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
     for (int kp = 0; kp < KPC; ++kp) {
         const int kl = 2 * kp + half;
         const int ci = kl / KS, kk = kl - ci * KS;
-        const int d = kk - padL;
+        const int d = TR ? -kk : kk - padL;    // TR: tap 0 reads x[t0], tap 1 reads x[t0-1]
         const int q = (d >= 0) ? d / S : -((-d + S - 1) / S);
         const int p = d - q * S;
         b_off[kp] = (ci * S + p) * U + 1 + q + (lane & 31);
@@ -327,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
     auto load_w = [&](float4 (&a)[WM][QPC], int c) {
 #pragma unroll
         for (int wm = 0; wm < WM; ++wm) {
-            const int cot = co_tile * WM + wm;
+            const int cot = (TR ? phase * tr.n_co : 0) + co_tile * WM + wm;   // TR: tr.n_co 32-row tiles per phase
             const float4* p = reinterpret_cast<const float4*>(wp) + ((long)cot * kquads + (long)c * QPC) * 64 + lane;
 #pragma unroll
             for (int q = 0; q < QPC; ++q) a[wm][q] = p[q * 64];
@@ -401,6 +412,253 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
     }
 
     // epilogue: C/D layout col = lane&31 (column), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel)
+#pragma unroll
+    for (int wn = 0; wn < WN; ++wn) {
+        const long n = n0 + wn * 32 + (lane & 31);
+        if (n >= Ncols) continue;
+        const long b = n / Lout;
+        const int t = (int)(n - b * Lout);
+        long ocol = t;
+        long orow = Lout;
+        if (TR) {   // phase r of column t0 lands on output sample s*t0 - padL + r
+            ocol = (long)tr.s * t - tr.padL + phase;
+            orow = tr.Lout;
+            if (ocol < 0 || ocol >= orow) continue;
+        }
+        float* yb = y + b * Cout * orow + ocol;
+#pragma unroll
+        for (int wm = 0; wm < WM; ++wm) {
+            const int cot = co0 + wm * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cot + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (co < Cout) yb[(long)co * orow] = acc[wm][wn][r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------ warp-specialised variant of the implicit-GEMM conv
+// Same GEMM view, LDS window layout, k order and results as conv1d_mfma_kernel, different division of
+// labour: a workgroup is 8 waves = 4 CONSUMERS (waves 0-3, one per SIMD) + 4 PRODUCERS (waves 4-7).
+// Consumer i owns a 64-channel x 64-column tile and does nothing but LDS fragment reads and
+// v_mfma_f32_32x32x2_f32 (the matrix pipe of its SIMD sees a dense stream); producer i stages consumer i's
+// input window (global loads one chunk ahead, LeakyReLU / fused conv_in, LDS writes) and a quarter of the
+// chunk's weight fragments, which all four consumers share through LDS.  One workgroup barrier per chunk
+// (32 k-pairs = 128 MFMAs per consumer) hands buffer (c+1)&1 over.
+template <int KS, int S, int CIC, int FUSE>
+__global__ __launch_bounds__(512) void conv1d_ws_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                        int Cin, int Lin, int Cout, int Lout, long Ncols, int nchunks,
+                                                        int pre, float slope, FuseIn fin) {
+    constexpr int WM = 2, WN = 2;
+    constexpr int MT = WM * 32, NW = WN * 32;
+    constexpr int U = ConvLds<S>::stride(NW);
+    constexpr int KPC = CIC * KS / 2;
+    constexpr int QPC = KPC / 4;
+    constexpr int E = (NW + 2) * S;
+    constexpr int RE = (E + 63) / 64;
+    constexpr int padL = (KS - S + 1) / 2;
+    constexpr int BUF = CIC * S * U + 4;
+    constexpr int WBUF = WM * QPC * 64 * 4;   // floats of weight fragments per chunk
+    static_assert(KPC % 4 == 0 && KPC <= 64, "chunk shape");
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* aw_all = lds;                       // [2][WM][QPC][64] float4
+    float* xs_all = lds + 2 * WBUF;            // [4 consumers][2][BUF]
+
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool producer = wave >= 4;
+    const int cw = wave & 3;                   // consumer index this wave is / serves
+    float* xs = xs_all + cw * 2 * BUF;
+
+    const int n_co = (Cout + MT - 1) / MT;
+    const long wg = blockIdx.x;
+    const int xcd = (int)(wg & 7);
+    const long seq = wg >> 3;
+    const int co_tile = (int)(seq % n_co);
+    const long col_tile = (seq / n_co) * 8 + xcd;
+    const long n0 = (col_tile * 4 + cw) * NW;
+    const int co0 = co_tile * MT;
+    const bool active = n0 < Ncols;            // inactive waves still take part in every barrier
+    const long kquads = (long)nchunks * QPC;
+    const int lastc = nchunks - 1;
+
+    if (producer) {
+        // ------------------------------------------------------------------ producer
+        unsigned s_goff[RE];
+        int s_loff[RE];
+        bool s_ok[RE];
+#pragma unroll
+        for (int r = 0; r < RE; ++r) {
+            const int e = lane + 64 * r;
+            const int slot = e / S, p = e - slot * S;
+            const long n = n0 - 1 + slot;
+            s_ok[r] = active && e < E && n >= 0 && n < Ncols;
+            s_loff[r] = e < E ? p * U + slot : -1;
+            const long nn = s_ok[r] ? n : 0;
+            const long b = nn / Lout;
+            const int t = (int)(nn - b * Lout);
+            s_goff[r] = s_ok[r] ? (unsigned)(b * Cin * (long)Lin + (long)t * S + p) : 0u;
+        }
+        float pc[FUSE ? RE : 1][7];
+        if (FUSE) {
+#pragma unroll
+            for (int r = 0; r < RE; ++r) {
+                const int e = lane + 64 * r;
+                const int slot = e / S, p = e - slot * S;
+                const long n = n0 - 1 + slot;
+                const long nn = s_ok[r] ? n : 0;
+                const long b = nn / Lout;
+                const int i = (int)(nn - b * Lout) * S + p;
+                const float* row = fin.src.base + (long)(b % fin.src.C) * fin.src.chan_stride + (long)(b / fin.src.C) * fin.src.win_stride;
+#pragma unroll
+                for (int kk = 0; kk < 7; ++kk) {
+                    const int j = i + kk - 3;
+                    pc[r][kk] = (s_ok[r] && j >= 0 && j < fin.src.T) ? row[j] : 0.0f;
+                }
+            }
+        }
+        const float act_slope = pre ? slope : 1.0f;
+        // weight share of this producer: items t, t+256, ... of the WM*QPC*64 float4 of a chunk
+        constexpr int WITEMS = WM * QPC * 64;
+        constexpr int WPER = (WITEMS + 255) / 256;
+        const int ptid = threadIdx.x - 256;
+        float sreg[CIC][RE];
+        float4 wreg[WPER];
+        auto issue_loads = [&](int c) {
+#pragma unroll
+            for (int i = 0; i < WPER; ++i) {
+                const int it = ptid + 256 * i;
+                const int itc = it < WITEMS ? it : 0;
+                const int wm = itc / (QPC * 64), rem = itc - wm * (QPC * 64);   // rem = q*64 + lane
+                const int cot = co_tile * WM + wm;
+                wreg[i] = reinterpret_cast<const float4*>(wp)[((long)cot * kquads + (long)c * QPC) * 64 + rem];
+            }
+#pragma unroll
+            for (int cl = 0; cl < CIC; ++cl) {
+                const int ci = c * CIC + cl;
+                if (FUSE) {
+                    const int cc = ci < Cin ? ci : 0;
+                    const float* wr = fin.w_in + cc * 7;
+                    const float bi = fin.b_in[cc];
+#pragma unroll
+                    for (int r = 0; r < RE; ++r) {
+                        float a = bi;
+#pragma unroll
+                        for (int kk = 0; kk < 7; ++kk) a = __builtin_fmaf(wr[kk], pc[r][kk], a);
+                        sreg[cl][r] = a;
+                    }
+                } else {
+                    const float* xc = x + (long)(ci < Cin ? ci : 0) * Lin;
+#pragma unroll
+                    for (int r = 0; r < RE; ++r) sreg[cl][r] = xc[s_goff[r]];
+                }
+            }
+        };
+        auto write_lds = [&](int c, int buf) {
+            float4* aw = reinterpret_cast<float4*>(aw_all + buf * WBUF);
+#pragma unroll
+            for (int i = 0; i < WPER; ++i) {
+                const int it = ptid + 256 * i;
+                if (it < WITEMS) aw[it] = wreg[i];
+            }
+            float* dst = xs + buf * BUF;
+#pragma unroll
+            for (int cl = 0; cl < CIC; ++cl) {
+                const bool cok = (c * CIC + cl) < Cin;
+#pragma unroll
+                for (int r = 0; r < RE; ++r) {
+                    float v = (s_ok[r] && cok) ? sreg[cl][r] : 0.0f;
+                    v = fmaxf(v, v * act_slope);
+                    dst[s_loff[r] >= 0 ? cl * S * U + s_loff[r] : CIC * S * U] = v;
+                }
+            }
+        };
+        issue_loads(0);
+        write_lds(0, 0);
+        issue_loads(min(1, lastc));
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            const int c1 = min(c + 1, lastc);
+            write_lds(c1, (c + 1) & 1);          // loaded during the previous iteration
+            issue_loads(min(c + 2, lastc));      // in flight across the barrier and the next iteration
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumer
+    __builtin_amdgcn_s_setprio(3);
+    int b_off[KPC];
+    unsigned long long m_first = 0, m_last = 0;
+#pragma unroll
+    for (int kp = 0; kp < KPC; ++kp) {
+        const int kl = 2 * kp + half;
+        const int ci = kl / KS, kk = kl - ci * KS;
+        const int d = kk - padL;
+        const int q = (d >= 0) ? d / S : -((-d + S - 1) / S);
+        const int p = d - q * S;
+        b_off[kp] = (ci * S + p) * U + 1 + q + (lane & 31);
+        if (q < 0) m_first |= 1ull << kp;
+        if (q > 0) m_last |= 1ull << kp;
+    }
+    unsigned long long zmask[WN];
+#pragma unroll
+    for (int wn = 0; wn < WN; ++wn) {
+        const long n = n0 + wn * 32 + (lane & 31);
+        const int t = (int)(n % Lout);
+        zmask[wn] = (t == 0 ? m_first : 0ull) | (t == Lout - 1 ? m_last : 0ull);
+    }
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int wm = 0; wm < WM; ++wm) {
+        const int cot = co0 + wm * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cot + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float bv = co < Cout ? bias[co] : 0.0f;
+#pragma unroll
+            for (int wn = 0; wn < WN; ++wn) acc[wm][wn][r] = bv;
+        }
+    }
+    __syncthreads();   // chunk 0 staged
+    for (int c = 0; c < nchunks; ++c) {
+        if (active) {
+            const float* xb = xs + (c & 1) * BUF;
+            const float4* aw = reinterpret_cast<const float4*>(aw_all + (c & 1) * WBUF) + lane;
+            constexpr int NB = (KPC > 16) ? ((KPC % 16 == 0) ? KPC / 16 : ((KPC % 10 == 0) ? KPC / 10 : KPC / 12)) : 1;
+            constexpr int PB = KPC / NB;      // k pairs per fragment batch (<= 16, multiple of 2)
+            static_assert(KPC % NB == 0 && PB % 2 == 0, "batching");
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                float bv[PB][WN];
+#pragma unroll
+                for (int i = 0; i < PB; ++i)
+#pragma unroll
+                    for (int wn = 0; wn < WN; ++wn) bv[i][wn] = xb[b_off[nb * PB + i] + wn * 32];
+#pragma unroll
+                for (int i = 0; i < PB; ++i) {
+                    const int kp = nb * PB + i;
+                    float bfr[WN];
+#pragma unroll
+                    for (int wn = 0; wn < WN; ++wn) bfr[wn] = ((zmask[wn] >> kp) & 1ull) ? 0.0f : bv[i][wn];
+#pragma unroll
+                    for (int wm = 0; wm < WM; ++wm) {
+                        const float4 q4 = aw[(wm * QPC + (kp >> 2)) * 64];
+                        const float av = (kp & 3) == 0 ? q4.x : (kp & 3) == 1 ? q4.y : (kp & 3) == 2 ? q4.z : q4.w;
+#pragma unroll
+                        for (int wn = 0; wn < WN; ++wn)
+                            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bfr[wn], acc[wm][wn], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!active) return;
 #pragma unroll
     for (int wn = 0; wn < WN; ++wn) {
         const long n = n0 + wn * 32 + (lane & 31);
@@ -667,6 +925,10 @@ struct ConvLayer {
     float* b = nullptr;
     float* wp = nullptr;    // MFMA-packed (encoder non-transposed layers with cin*k >= 32)
     int K = 0, Kpad = 0, cout_pad = 0, nchunks = 0;
+    float* wp2 = nullptr;   // packing for the warp-specialised kernel (larger K chunks)
+    int nchunks2 = 0;
+    float* wp_tr = nullptr; // transposed conv: per-phase packing [phase][co_tile][kquad][lane][4]
+    int nchunks_tr = 0;
 };
 
 // input channels per K chunk of the MFMA conv, by (kernel size, stride)
@@ -676,6 +938,15 @@ static int conv_cic(int k, int s) {
     if (k == 10 && s == 5) return 4;
     if (k == 16 && s == 8) return 2;
     if (k == 3 && s == 1) return 8;
+    return 0;
+}
+// ... and of the warp-specialised kernel (32 k-pairs = 128 MFMAs per consumer between barriers)
+static int conv_cic_ws(int k, int s) {
+    if (k == 4 && s == 2) return 16;
+    if (k == 8 && s == 4) return 8;
+    if (k == 10 && s == 5) return 8;
+    if (k == 16 && s == 8) return 4;
+    if (k == 3 && s == 1) return 16;
     return 0;
 }
 
@@ -726,27 +997,63 @@ static int upload(const rca_tensor_t* ts, int n, const std::string& name, long n
     return RCA_OK;
 }
 
-// pack W[cout][K] into MFMA A-fragment order, zero padded to cout_pad x Kpad
-static int pack_weights(const float* w_host, ConvLayer& L) {
-    L.K = L.cin * L.k;
-    const int cic = conv_cic(L.k, L.s);
-    L.nchunks = (L.cin + cic - 1) / cic;
-    L.Kpad = L.nchunks * cic * L.k;
-    L.cout_pad = (L.cout + 127) / 128 * 128;  // whole number of the largest workgroup tile
-    const long n = (long)(L.cout_pad / 32) * (L.Kpad / 8) * 64 * 4;
+// pack W[cout][K] into MFMA A-fragment order, zero padded to cout_pad x (nchunks*cic*k)
+static int pack_weights_cic(const float* w_host, const ConvLayer& L, int cic, float** out, int* nchunks_out) {
+    const int K = L.cin * L.k;
+    const int nchunks = (L.cin + cic - 1) / cic;
+    const int Kpad = nchunks * cic * L.k;
+    const int cout_pad = (L.cout + 127) / 128 * 128;
+    const long n = (long)(cout_pad / 32) * (Kpad / 8) * 64 * 4;
     std::vector<float> p((size_t)n, 0.0f);
-    for (int cot = 0; cot < L.cout_pad / 32; ++cot)
-        for (int q = 0; q < L.Kpad / 8; ++q)
+    for (int cot = 0; cot < cout_pad / 32; ++cot)
+        for (int q = 0; q < Kpad / 8; ++q)
             for (int lane = 0; lane < 64; ++lane)
                 for (int e = 0; e < 4; ++e) {
                     const int co = cot * 32 + (lane & 31);
                     const int k = 2 * (4 * q + e) + (lane >> 5);
                     float v = 0.0f;
-                    if (co < L.cout && k < L.K) v = w_host[(long)co * L.K + k];
-                    p[(((long)cot * (L.Kpad / 8) + q) * 64 + lane) * 4 + e] = v;
+                    if (co < L.cout && k < K) v = w_host[(long)co * K + k];
+                    p[(((long)cot * (Kpad / 8) + q) * 64 + lane) * 4 + e] = v;
                 }
-    RCA_HIP(hipMalloc((void**)&L.wp, (size_t)n * sizeof(float)));
-    RCA_HIP(hipMemcpy(L.wp, p.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    RCA_HIP(hipMalloc((void**)out, (size_t)n * sizeof(float)));
+    RCA_HIP(hipMemcpy(*out, p.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    *nchunks_out = nchunks;
+    return RCA_OK;
+}
+static int pack_weights(const float* w_host, ConvLayer& L) {
+    L.K = L.cin * L.k;
+    L.cout_pad = (L.cout + 127) / 128 * 128;
+    int rc = pack_weights_cic(w_host, L, conv_cic(L.k, L.s), &L.wp, &L.nchunks);
+    if (rc != RCA_OK) return rc;
+    L.Kpad = L.nchunks * conv_cic(L.k, L.s) * L.k;
+    return pack_weights_cic(w_host, L, conv_cic_ws(L.k, L.s), &L.wp2, &L.nchunks2);
+}
+
+// ConvTranspose1d weights w[Cin][Cout][2s] -> per phase r the GEMM matrix Wr[co][2*ci + j] = w[ci][co][r + j*s]
+static int pack_weights_tr(const float* w_host, ConvLayer& L) {
+    const int cic = 16, K = 2 * L.cin;
+    const int nchunks = (L.cin + cic - 1) / cic;
+    const int Kpad = nchunks * cic * 2;
+    L.cout_pad = (L.cout + 127) / 128 * 128;
+    const long per_phase = (long)(L.cout_pad / 32) * (Kpad / 8) * 64 * 4;
+    std::vector<float> p((size_t)per_phase * L.s, 0.0f);
+    for (int r = 0; r < L.s; ++r)
+        for (int cot = 0; cot < L.cout_pad / 32; ++cot)
+            for (int q = 0; q < Kpad / 8; ++q)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int co = cot * 32 + (lane & 31);
+                        const int k = 2 * (4 * q + e) + (lane >> 5);
+                        float v = 0.0f;
+                        if (co < L.cout && k < K) {
+                            const int ci = k >> 1, j = k & 1;
+                            v = w_host[((long)ci * L.cout + co) * L.k + r + j * L.s];
+                        }
+                        p[r * per_phase + (((long)cot * (Kpad / 8) + q) * 64 + lane) * 4 + e] = v;
+                    }
+    RCA_HIP(hipMalloc((void**)&L.wp_tr, p.size() * sizeof(float)));
+    RCA_HIP(hipMemcpy(L.wp_tr, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
+    L.nchunks_tr = nchunks;
     return RCA_OK;
 }
 
@@ -770,6 +1077,8 @@ extern "C" int rca_codec_destroy(rca_codec_t* h) {
             if (L.w) (void)hipFree(L.w);
             if (L.b) (void)hipFree(L.b);
             if (L.wp) (void)hipFree(L.wp);
+            if (L.wp2) (void)hipFree(L.wp2);
+            if (L.wp_tr) (void)hipFree(L.wp_tr);
         }
     for (float* p : {h->q_in_w, h->q_in_b, h->cb, h->hc, h->cbp})
         if (p) (void)hipFree(p);
@@ -811,6 +1120,10 @@ extern "C" int rca_codec_create(const rca_codec_config_t* cfg, const rca_tensor_
         if (pack && !tr && mfma_supported(k, s)) {
             const rca_tensor_t* t = find_tensor(ts, nt, name + ".weight");
             if ((rc = pack_weights((const float*)t->data, L)) != RCA_OK) { v.push_back(L); return rc; }
+        }
+        if (tr && k == 2 * s) {
+            const rca_tensor_t* t = find_tensor(ts, nt, name + ".weight");
+            if ((rc = pack_weights_tr((const float*)t->data, L)) != RCA_OK) { v.push_back(L); return rc; }
         }
         v.push_back(L);
         return RCA_OK;
@@ -866,7 +1179,7 @@ extern "C" int rca_codec_num_frames(const rca_codec_t* h, int32_t T, int32_t* F)
     return RCA_OK;
 }
 extern "C" int rca_codec_set_variant(rca_codec_t* h, int32_t v) {
-    if (!h || v < 0 || v > 1) return fail(RCA_ERR_ARG, "variant must be 0 or 1");
+    if (!h || v < 0 || v > 2) return fail(RCA_ERR_ARG, "variant must be 0, 1 or 2");
     h->variant = v;
     return RCA_OK;
 }
@@ -877,16 +1190,16 @@ extern "C" int rca_codec_sync(rca_codec_t* h) {
     return RCA_OK;
 }
 
-template <int KS, int S, int CIC, int WM, int WN, int FUSE>
-static void launch_conv_cfg(const ConvLayer& L, const float* x, float* y, int Lin, int Lout, long Ncols, float slope, const FuseIn& fin,
-                            hipStream_t st) {
+template <int KS, int S, int CIC, int WM, int WN, int FUSE, int TR>
+static void launch_conv_cfg(const ConvLayer& L, const float* wp, int nchunks, const float* x, float* y, int Lin, int Lc, long Ncols,
+                            float slope, const FuseIn& fin, const TrInfo& tr, hipStream_t st) {
     constexpr int NT = 4 * WN * 32, MT = WM * 32;
     constexpr int lds = 4 * 2 * (CIC * S * ConvLds<S>::stride(WN * 32) + 4) * 4;
     static_assert(lds <= 65536, "LDS budget");
-    // 1-D grid: column tiles padded to a multiple of 8 (one per XCD), times the channel tiles
+    // 1-D grid: column tiles padded to a multiple of 8 (one per XCD), times the channel tiles (times the phases)
     const long col_tiles = (cdiv(Ncols, NT) + 7) / 8 * 8;
-    dim3 grid((unsigned)(col_tiles * cdiv(L.cout, MT)));
-    conv1d_mfma_kernel<KS, S, CIC, WM, WN, FUSE><<<grid, 256, lds, st>>>(x, L.wp, L.b, y, L.cin, Lin, L.cout, Lout, Ncols, L.nchunks, L.pre, slope, fin);
+    dim3 grid((unsigned)(col_tiles * cdiv(L.cout, MT) * (TR ? tr.s : 1)));
+    conv1d_mfma_kernel<KS, S, CIC, WM, WN, FUSE, TR><<<grid, 256, lds, st>>>(x, wp, L.b, y, L.cin, Lin, L.cout, Lc, Ncols, nchunks, L.pre, slope, fin, tr);
 }
 
 template <int KS, int S, int CIC>
@@ -897,19 +1210,61 @@ static int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B,
     // otherwise 32 x 32 tiles (4x the waves; streaming / small batches)
     const long waves_big = (long)cdiv(Ncols, 64) * cdiv(L.cout, 64);
     const FuseIn none{};
+    const TrInfo notr{};
     if (fuse) {
-        if (waves_big >= 2048) launch_conv_cfg<KS, S, CIC, 2, 2, 1>(L, x, y, Lin, Lout, Ncols, slope, *fuse, st);
-        else launch_conv_cfg<KS, S, CIC, 1, 1, 1>(L, x, y, Lin, Lout, Ncols, slope, *fuse, st);
+        if (waves_big >= 2048) launch_conv_cfg<KS, S, CIC, 2, 2, 1, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, *fuse, notr, st);
+        else launch_conv_cfg<KS, S, CIC, 1, 1, 1, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, *fuse, notr, st);
     } else {
-        if (waves_big >= 2048) launch_conv_cfg<KS, S, CIC, 2, 2, 0>(L, x, y, Lin, Lout, Ncols, slope, none, st);
-        else launch_conv_cfg<KS, S, CIC, 1, 1, 0>(L, x, y, Lin, Lout, Ncols, slope, none, st);
+        if (waves_big >= 2048) launch_conv_cfg<KS, S, CIC, 2, 2, 0, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, none, notr, st);
+        else launch_conv_cfg<KS, S, CIC, 1, 1, 0, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, none, notr, st);
     }
     RCA_LAUNCH_CHECK();
     return RCA_OK;
 }
 
+// ConvTranspose1d (k = 2s) as s phase GEMMs in one launch of the same kernel (KS=2, S=1 view)
+static int launch_convtr_mfma(const ConvLayer& L, const float* x, float* y, int B, int Lin, float slope, hipStream_t st) {
+    const int Lc = Lin + 1;
+    const long Ncols = (long)B * Lc;
+    const FuseIn none{};
+    const TrInfo tr{L.s, (L.k - L.s + 1) / 2, Lin * L.s, L.cout_pad / 32};
+    const long waves_big = (long)cdiv(Ncols, 64) * cdiv(L.cout, 64) * L.s;
+    if (L.cout > 32 && waves_big >= 2048) launch_conv_cfg<2, 1, 16, 2, 2, 0, 1>(L, L.wp_tr, L.nchunks_tr, x, y, Lin, Lc, Ncols, slope, none, tr, st);
+    else launch_conv_cfg<2, 1, 16, 1, 1, 0, 1>(L, L.wp_tr, L.nchunks_tr, x, y, Lin, Lc, Ncols, slope, none, tr, st);
+    RCA_LAUNCH_CHECK();
+    return RCA_OK;
+}
+
+template <int KS, int S, int CIC, int FUSE>
+static void launch_conv_ws(const ConvLayer& L, const float* x, float* y, int Lin, int Lout, long Ncols, float slope, const FuseIn& fin,
+                           hipStream_t st) {
+    constexpr int KPC = CIC * KS / 2, QPC = KPC / 4;
+    constexpr int lds = (2 * (2 * QPC * 64 * 4) + 4 * 2 * (CIC * S * ConvLds<S>::stride(64) + 4)) * 4;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = conv1d_ws_kernel<KS, S, CIC, FUSE>;
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; }
+    const long col_tiles = (cdiv(Ncols, 256) + 7) / 8 * 8;
+    dim3 grid((unsigned)(col_tiles * cdiv(L.cout, 64)));
+    kern<<<grid, 512, lds, st>>>(x, L.wp2, L.b, y, L.cin, Lin, L.cout, Lout, Ncols, L.nchunks2, L.pre, slope, fin);
+}
+// variant 2 (experimental, slower than variant 1 as measured in round 1): true when the warp-specialised kernel was launched
+static bool try_conv_ws(const ConvLayer& L, const float* x, float* y, int B, int Lin, int Lout, float slope, hipStream_t st, const FuseIn* fuse) {
+    const long Ncols = (long)B * Lout;
+    if (!L.wp2 || (long)cdiv(Ncols, 64) * cdiv(L.cout, 64) < 1024) return false;
+    const FuseIn none{};
+    if (L.k == 4 && L.s == 2) { if (fuse) launch_conv_ws<4, 2, 16, 1>(L, x, y, Lin, Lout, Ncols, slope, *fuse, st); else launch_conv_ws<4, 2, 16, 0>(L, x, y, Lin, Lout, Ncols, slope, none, st); }
+    else if (L.k == 8 && L.s == 4 && !fuse) launch_conv_ws<8, 4, 8, 0>(L, x, y, Lin, Lout, Ncols, slope, none, st);
+    else if (L.k == 16 && L.s == 8 && !fuse) launch_conv_ws<16, 8, 4, 0>(L, x, y, Lin, Lout, Ncols, slope, none, st);
+    else if (L.k == 10 && L.s == 5 && !fuse) launch_conv_ws<10, 5, 8, 0>(L, x, y, Lin, Lout, Ncols, slope, none, st);
+    else if (L.k == 3 && L.s == 1 && !fuse) launch_conv_ws<3, 1, 16, 0>(L, x, y, Lin, Lout, Ncols, slope, none, st);
+    else return false;
+    return true;
+}
+
 static int run_conv(rca_codec* h, const ConvLayer& L, const float* x, float* y, int B, int Lin, int clamp_out, hipStream_t st) {
     const float slope = h->cfg.leaky_slope;
+    if (L.tr && h->variant >= 1 && L.wp_tr && (double)B * L.cin * Lin < 4.0e9) return launch_convtr_mfma(L, x, y, B, Lin, slope, st);
     if (L.tr) {
         const long total = (long)B * L.cout * Lin * L.s;
         convtr1d_chain_kernel<<<cdiv(total, 256), 256, 0, st>>>(x, L.w, L.b, y, B, L.cin, Lin, L.cout, L.k, L.s, L.pre, slope);
@@ -920,8 +1275,9 @@ static int run_conv(rca_codec* h, const ConvLayer& L, const float* x, float* y, 
     const double cflops = 2.0 * L.cin * L.k * L.cout * (double)B * Lout;
     const double cbytes = 4.0 * ((double)B * L.cin * Lin + (double)B * L.cout * Lout + (double)L.cin * L.k * L.cout);
     // the MFMA kernel indexes the input with 32-bit element offsets
-    if (h->variant == 1 && L.wp && !clamp_out && (double)B * L.cin * Lin < 4.0e9) {
+    if (h->variant >= 1 && L.wp && !clamp_out && (double)B * L.cin * Lin < 4.0e9) {
         ProfScope ps(h, st, 0, cflops, cbytes);
+        if (h->variant == 2 && try_conv_ws(L, x, y, B, Lin, Lout, slope, st, nullptr)) { RCA_LAUNCH_CHECK(); return RCA_OK; }
         if (L.k == 4 && L.s == 2) return launch_conv_mfma<4, 2, 4>(L, x, y, B, Lin, Lout, slope, st);
         if (L.k == 8 && L.s == 4) return launch_conv_mfma<8, 4, 4>(L, x, y, B, Lin, Lout, slope, st);
         if (L.k == 10 && L.s == 5) return launch_conv_mfma<10, 5, 4>(L, x, y, B, Lin, Lout, slope, st);
@@ -958,7 +1314,7 @@ static int run_encoder(rca_codec* h, RowSrc src, int B, hipStream_t st, float** 
     const ConvLayer& E0 = h->enc[0];
     const ConvLayer& E1 = h->enc[1];
     // conv_in fused into the first strided layer (MFMA variant, 7-tap conv_in, layer 0 not tapped)
-    const bool fuse01 = h->variant == 1 && tap_layer != 0 && E0.k == 7 && E1.wp && E1.k == 2 * E1.s && (double)B * E1.cin * L < 4.0e9 &&
+    const bool fuse01 = h->variant >= 1 && tap_layer != 0 && E0.k == 7 && E1.wp && E1.k == 2 * E1.s && (double)B * E1.cin * L < 4.0e9 &&
                         ((E1.k == 4 && E1.s == 2) || (E1.k == 8 && E1.s == 4) || (E1.k == 16 && E1.s == 8));
     if (fuse01) {
         float* y = h->act[cur].as<float>();
@@ -968,7 +1324,8 @@ static int run_encoder(rca_codec* h, RowSrc src, int B, hipStream_t st, float** 
         {
             ProfScope ps(h, st, 0, 2.0 * E1.cin * E1.k * E1.cout * (double)B * Lout + 2.0 * E0.k * E0.cout * (double)B * L,
                          4.0 * ((double)B * src.T + (double)B * E1.cout * Lout + (double)E1.cin * E1.k * E1.cout));
-            if (E1.k == 4) rc = launch_conv_mfma<4, 2, 4>(E1, nullptr, y, B, L, Lout, slope, st, &fin);
+            if (h->variant == 2 && try_conv_ws(E1, nullptr, y, B, L, Lout, slope, st, &fin)) { rc = RCA_OK; RCA_LAUNCH_CHECK(); }
+            else if (E1.k == 4) rc = launch_conv_mfma<4, 2, 4>(E1, nullptr, y, B, L, Lout, slope, st, &fin);
             else if (E1.k == 8) rc = launch_conv_mfma<8, 4, 4>(E1, nullptr, y, B, L, Lout, slope, st, &fin);
             else rc = launch_conv_mfma<16, 8, 2>(E1, nullptr, y, B, L, Lout, slope, st, &fin);
         }
@@ -1020,7 +1377,7 @@ static int run_quantize(rca_codec* h, const float* ze, int ze_is_rows, int B, in
     if (ztap_dev) RCA_HIP(hipMemcpyAsync(ztap_dev, z, (size_t)rows * J * 4, hipMemcpyDeviceToDevice, st));
     unsigned long long* keys = h->keys.as<unsigned long long>();
     ProfScope ps(h, st, 1, 2.0 * (double)rows * N * J, 4.0 * ((double)N * (J + 1) + (double)rows * J) + 8.0 * rows);
-    if (h->variant == 1) {
+    if (h->variant >= 1) {
         constexpr int FN = 2;
         const int ftiles = (int)cdiv(rows, FN * 32);
         const int total_tiles = N / 32;

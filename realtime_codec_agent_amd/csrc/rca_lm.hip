@@ -74,6 +74,50 @@ __global__ __launch_bounds__(256) void lm_embed_kernel(const LmDevState* __restr
     for (int h = threadIdx.x; h < H; h += 256) x[(long)m * H + h] = __uint_as_float((unsigned)row[h] << 16);
 }
 
+// ------------------------------------------------ residual add + RMSNorm, one workgroup per token (prefill chunks)
+// Identical arithmetic and summation order as the PRO=1 prologue of lm_gemv_kernel (k = tid + 256 i, fma chain,
+// wave shuffle tree, 4-wave sum), so M > 2 passes (this kernel) and decode passes (prologue) agree bit for bit.
+__global__ __launch_bounds__(256) void lm_add_rmsnorm_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ xin,
+                                                             float* __restrict__ xout, const float* __restrict__ parts, int nparts,
+                                                             long part_stride, const float* __restrict__ w, float* __restrict__ xn,
+                                                             int K, float eps) {
+    const int m = blockIdx.x;
+    if (m >= stt->m) return;
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float pv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = threadIdx.x + 256 * i;
+        pv[i] = k < K ? xin[(long)m * K + k] : 0.0f;
+    }
+    for (int s2 = 0; s2 < nparts; ++s2) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = threadIdx.x + 256 * i;
+            if (k < K) pv[i] += parts[s2 * part_stride + (long)m * K + k];
+        }
+    }
+    float ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = threadIdx.x + 256 * i;
+        if (k < K) {
+            if (xout) xout[(long)m * K + k] = pv[i];
+            ss = __builtin_fmaf(pv[i], pv[i], ss);
+        }
+    }
+    const float t = wave_sum(ss);
+    if (lane == 0) red[wave] = t;
+    __syncthreads();
+    const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = threadIdx.x + 256 * i;
+        if (k < K) xn[(long)m * K + k] = (pv[i] * rstd) * w[k];
+    }
+}
+
 // ------------------------------------------------------------------------------------ GEMV
 // y[slice][m][n] = sum_{k in slice} W[n][k] * x[m][k].   One wave owns 2 rows at a time and walks
 // its K slice (<= 2048) in 16-byte (8 x bf16) lane chunks, all of a row pair's loads issued before
@@ -1147,8 +1191,14 @@ static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st) {
         rope.kc = kc; rope.vc = vc;
         // the previous layer's down-projection partials join the residual stream inside this prologue
         const int np1 = (l == 0 || in_wg_ksplit) ? 0 : h->ksplit_down;
-        GemvPro p1{cur, np1 ? nxt : nullptr, h->part_d, np1, ps, L.attn_norm, c.rms_eps, 0};
-        launch_gemv<1, 2>(h, Mt, L.wqkv, nullptr, h->qkv, QKV, H, H, 1, 0, QKV, p1, rope, st);
+        if (Mt > 2) {
+            // prefill chunks: one norm kernel per token instead of a redundant prologue in every GEMV workgroup
+            lm_add_rmsnorm_kernel<<<M, 256, 0, st>>>(h->stt, cur, np1 ? nxt : nullptr, h->part_d, np1, ps, L.attn_norm, h->xn, H, c.rms_eps);
+            launch_gemv<0, 2>(h, Mt, L.wqkv, h->xn, h->qkv, QKV, H, H, 1, 0, QKV, nopro, rope, st);
+        } else {
+            GemvPro p1{cur, np1 ? nxt : nullptr, h->part_d, np1, ps, L.attn_norm, c.rms_eps, 0};
+            launch_gemv<1, 2>(h, Mt, L.wqkv, nullptr, h->qkv, QKV, H, H, 1, 0, QKV, p1, rope, st);
+        }
         if (np1) std::swap(cur, nxt);
         dim3 ag(c.n_kv_heads, h->n_splits, (M + 1) / 2);
         if (G == 4) {
@@ -1163,8 +1213,13 @@ static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st) {
         }
         // O projection adds straight into the residual stream (one K slice: each output has a single writer)
         launch_gemv<0, 3>(h, Mt, L.wo, h->attn, cur, H, AO, AO, 1, 0, H, nopro, norope, st);
-        GemvPro p2{cur, nullptr, nullptr, 0, 0, L.ffn_norm, c.rms_eps, 0};
-        launch_gemv<1, 1>(h, Mt, L.wgu, nullptr, h->hbuf, 2 * F, H, H, 1, 0, F, p2, norope, st);
+        if (Mt > 2) {
+            lm_add_rmsnorm_kernel<<<M, 256, 0, st>>>(h->stt, cur, nullptr, nullptr, 0, 0, L.ffn_norm, h->xn, H, c.rms_eps);
+            launch_gemv<0, 1>(h, Mt, L.wgu, h->xn, h->hbuf, 2 * F, H, H, 1, 0, F, nopro, norope, st);
+        } else {
+            GemvPro p2{cur, nullptr, nullptr, 0, 0, L.ffn_norm, c.rms_eps, 0};
+            launch_gemv<1, 1>(h, Mt, L.wgu, nullptr, h->hbuf, 2 * F, H, H, 1, 0, F, p2, norope, st);
+        }
         if (in_wg_ksplit) {
             // decode: the 4 waves of a workgroup split K and add x + p0 + p1 + p2 + p3 in place
             if (Mt == 1) launch_gemv_t<1, 0, 3, 1>(h, L.wdown, h->hbuf, cur, H, F, F / 4, 4, 0, H, nopro, norope, st);

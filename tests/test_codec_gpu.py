@@ -30,7 +30,7 @@ def test_codebook_bit_exact(tag, hip_tiny, hip_full, tiny_oracle, full_oracle):
     assert np.array_equal(hip.codebook(), oc.codebook())
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("tag", ["tiny", "full"])
 def test_encoder_layers_bit_exact(tag, variant, hip_tiny, hip_full, tiny_oracle, full_oracle):
     hip, oc = _pair(tag, hip_tiny, hip_full, tiny_oracle, full_oracle)
@@ -44,7 +44,7 @@ def test_encoder_layers_bit_exact(tag, variant, hip_tiny, hip_full, tiny_oracle,
         assert bad.size == 0, f"layer {layer}: {bad.size} mismatches, first at {bad[:5]}, max|d|={np.abs(got - want).max()}"
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("tag", ["tiny", "full"])
 def test_encode_matches_golden_and_oracle(tag, variant, hip_tiny, hip_full, tiny_oracle, full_oracle):
     hip, oc = _pair(tag, hip_tiny, hip_full, tiny_oracle, full_oracle)
@@ -91,7 +91,7 @@ def test_decode_rejects_out_of_range(hip_tiny, tiny_codec):
     assert hip_tiny.decode(np.array([[0, 1]])).shape == (1, 640)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_batch_windows_match_streaming_semantics(variant, hip_full, full_oracle):
     """rca_codec_encode_windows_dev == chunk-by-chunk tokenize_audio semantics (oracle.encode_windows)
     on 4 s of stereo, for both standard chunk sizes, including the warm-up windows."""
@@ -118,14 +118,14 @@ def test_variants_agree_at_bench_batch_size(hip_full):
     x = np.stack([rich_signal(32000, 100 + (i % 7)) for i in range(256)])
     dev = torch.from_numpy(x).cuda()
     outs = []
-    for v in (1, 0):
+    for v in (1, 0, 2):
         hip_full.set_variant(v)
         codes = torch.empty((256, 100), dtype=torch.int64, device="cuda")
         hip_full.encode_dev(dev.data_ptr(), 256, 32000, codes.data_ptr(), torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         outs.append(codes.cpu().numpy())
     hip_full.set_variant(1)
-    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     assert np.array_equal(outs[0][0], outs[0][7]) and not np.array_equal(outs[0][0], outs[0][1])
     assert outs[0].min() >= 0 and outs[0].max() < 131072
 
