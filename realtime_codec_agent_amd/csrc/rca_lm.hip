@@ -74,48 +74,97 @@ __global__ __launch_bounds__(256) void lm_embed_kernel(const LmDevState* __restr
     for (int h = threadIdx.x; h < H; h += 256) x[(long)m * H + h] = __uint_as_float((unsigned)row[h] << 16);
 }
 
-// ------------------------------------------------ residual add + RMSNorm, one workgroup per token (prefill chunks)
-// Identical arithmetic and summation order as the PRO=1 prologue of lm_gemv_kernel (k = tid + 256 i, fma chain,
-// wave shuffle tree, 4-wave sum), so M > 2 passes (this kernel) and decode passes (prologue) agree bit for bit.
-__global__ __launch_bounds__(256) void lm_add_rmsnorm_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ xin,
-                                                             float* __restrict__ xout, const float* __restrict__ parts, int nparts,
-                                                             long part_stride, const float* __restrict__ w, float* __restrict__ xn,
-                                                             int K, float eps) {
-    const int m = blockIdx.x;
-    if (m >= stt->m) return;
-    __shared__ float red[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float pv[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int k = threadIdx.x + 256 * i;
-        pv[i] = k < K ? xin[(long)m * K + k] : 0.0f;
-    }
-    for (int s2 = 0; s2 < nparts; ++s2) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k = threadIdx.x + 256 * i;
-            if (k < K) pv[i] += parts[s2 * part_stride + (long)m * K + k];
-        }
-    }
+// --------------------------------------------------- residual add + RMSNorm shared arithmetic
+// A wave owns one token row: lane l holds the 8-element chunks c = l + 64*it (it < 4, K <= 2048), adds the
+// partial slices in order, accumulates sum(v^2) as an fma chain (it ascending, element ascending), reduces it
+// with the xor-shuffle tree and scales (v * rstd) * w.  Used verbatim by the decode GEMV prologue (registers) and
+// by the prefill norm kernel, so both paths produce identical bits.
+template <typename F>
+__device__ __forceinline__ float lm_row_norm(float (&v)[4][8], int nchunk, int K, float eps, F&& after_add) {
+    const int lane = threadIdx.x & 63;
     float ss = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int k = threadIdx.x + 256 * i;
-        if (k < K) {
-            if (xout) xout[(long)m * K + k] = pv[i];
-            ss = __builtin_fmaf(pv[i], pv[i], ss);
+    for (int it = 0; it < 4; ++it) {
+        const int c = lane + 64 * it;
+        if (c < nchunk) {
+            after_add(it, c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss = __builtin_fmaf(v[it][j], v[it][j], ss);
         }
     }
-    const float t = wave_sum(ss);
-    if (lane == 0) red[wave] = t;
-    __syncthreads();
-    const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);
+    ss = wave_sum(ss);
+    return rsqrtf(ss / (float)K + eps);
+}
+__device__ __forceinline__ void lm_load_row(float (&v)[4][8], const float* __restrict__ row, int nchunk, bool valid) {
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int k = threadIdx.x + 256 * i;
-        if (k < K) xn[(long)m * K + k] = (pv[i] * rstd) * w[k];
+    for (int it = 0; it < 4; ++it) {
+        const int c = lane + 64 * it;
+        if (valid && c < nchunk) {
+            const float4 a = *reinterpret_cast<const float4*>(row + c * 8);
+            const float4 b = *reinterpret_cast<const float4*>(row + c * 8 + 4);
+            v[it][0] = a.x; v[it][1] = a.y; v[it][2] = a.z; v[it][3] = a.w;
+            v[it][4] = b.x; v[it][5] = b.y; v[it][6] = b.z; v[it][7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[it][j] = 0.0f;
+        }
     }
+}
+__device__ __forceinline__ void lm_add_row(float (&v)[4][8], const float* __restrict__ row, int nchunk) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = lane + 64 * it;
+        if (c < nchunk) {
+            const float4 a = *reinterpret_cast<const float4*>(row + c * 8);
+            const float4 b = *reinterpret_cast<const float4*>(row + c * 8 + 4);
+            v[it][0] += a.x; v[it][1] += a.y; v[it][2] += a.z; v[it][3] += a.w;
+            v[it][4] += b.x; v[it][5] += b.y; v[it][6] += b.z; v[it][7] += b.w;
+        }
+    }
+}
+__device__ __forceinline__ void lm_store_row(const float (&v)[4][8], float* __restrict__ row, int nchunk) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = lane + 64 * it;
+        if (c < nchunk) {
+            *reinterpret_cast<float4*>(row + c * 8) = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
+            *reinterpret_cast<float4*>(row + c * 8 + 4) = make_float4(v[it][4], v[it][5], v[it][6], v[it][7]);
+        }
+    }
+}
+__device__ __forceinline__ void lm_scale_row(float (&v)[4][8], float rstd, const float* __restrict__ w, int nchunk) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = lane + 64 * it;
+        if (c < nchunk) {
+            const float4 a = *reinterpret_cast<const float4*>(w + c * 8);
+            const float4 b = *reinterpret_cast<const float4*>(w + c * 8 + 4);
+            const float wv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[it][j] = (v[it][j] * rstd) * wv[j];
+        }
+    }
+}
+
+// prefill chunks: one wave per token
+__global__ __launch_bounds__(64) void lm_add_rmsnorm_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ xin,
+                                                            float* __restrict__ xout, const float* __restrict__ parts, int nparts,
+                                                            long part_stride, const float* __restrict__ w, float* __restrict__ xn,
+                                                            int K, float eps) {
+    const int m = blockIdx.x;
+    if (m >= stt->m) return;
+    const int nchunk = K >> 3;
+    float v[4][8];
+    lm_load_row(v, xin + (long)m * K, nchunk, true);
+    for (int s2 = 0; s2 < nparts; ++s2) lm_add_row(v, parts + s2 * part_stride + (long)m * K, nchunk);
+    if (xout) lm_store_row(v, xout + (long)m * K, nchunk);
+    const float rstd = lm_row_norm(v, nchunk, K, eps, [](int, int) {});
+    lm_scale_row(v, rstd, w, nchunk);
+    lm_store_row(v, xn + (long)m * K, nchunk);
 }
 
 // ------------------------------------------------------------------------------------ GEMV
@@ -133,12 +182,15 @@ struct GemvPro {
 struct GemvRope {
     const float* cos_t; const float* sin_t; f16_t* kc; f16_t* vc; int nh, nkv, n_ctx;
 };
-template <int M, int PRO, int EPI, int KW>
+template <int M, int PRO, int EPI, int KW, int XR>
 __global__ __launch_bounds__(256) void lm_gemv_kernel(const LmDevState* __restrict__ stt, const bf16_t* __restrict__ W,
                                                       const float* __restrict__ x, float* __restrict__ y, int N, int K, int kslice,
                                                       int rows_per_wg, long y_slice_stride, int ldy, GemvPro pro, GemvRope rope) {
     // KW = 1: the 4 waves of the workgroup split K between them (kslice = K/4 each) and work on the SAME row
     // pair; their partial sums are added in wave order on top of the residual (EPI 3).
+    // XR = 1 (decode, M <= 2): x lives in REGISTERS -- each lane loads exactly the chunks it multiplies
+    // (c = lane + 64*it) straight from L2, every wave normalises its own copy (lm_row_norm), and there is no LDS
+    // staging and no workgroup barrier in front of the weight stream.  XR = 0 keeps x in LDS (prefill, M > 2).
     extern __shared__ __attribute__((aligned(16))) float xs[];  // [M][KW ? K : kslice]
     __shared__ float red[M][4];
     __shared__ float kred[4][2][M];
@@ -180,91 +232,113 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const LmDevState* __restri
     const int rb0 = row_beg + (KW ? 0 : wave * 2);
     if (rb0 < row_end) load_rows(rb0);
 
-    if (PRO == 1) {
-        // rows of the residual stream handled by this pass (only_last: just the final token)
-        const int Mv = stt->m;
-        const int mbase = pro.only_last ? Mv - 1 : 0;
-        float ss[M];
-        // K <= 2048: at most 8 elements per thread and token; all loads are issued before any is used
-        float pv[M][8];
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            ss[m] = 0.0f;
-            const int mr = mbase + m;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int k = threadIdx.x + 256 * i;
-                pv[m][i] = (mr < Mv && k < K) ? pro.xin[(long)mr * K + k] : 0.0f;
-            }
-        }
-        for (int s2 = 0; s2 < pro.nparts; ++s2) {
+    float xr[XR ? M : 1][4][8];
+    if (XR) {
+        if (PRO == 1) {
+            const int Mv = stt->m;
+            const int mbase = pro.only_last ? Mv - 1 : 0;
 #pragma unroll
             for (int m = 0; m < M; ++m) {
                 const int mr = mbase + m;
+                const bool valid = mr < Mv;
+                lm_load_row(xr[m], pro.xin + (long)(valid ? mr : 0) * K, nchunk, valid);
+                for (int s2 = 0; s2 < pro.nparts; ++s2)
+                    if (valid) lm_add_row(xr[m], pro.parts + s2 * pro.part_stride + (long)mr * K, nchunk);
+                if (pro.xout && blockIdx.x == 0 && wave == 0 && valid) lm_store_row(xr[m], pro.xout + (long)mr * K, nchunk);
+                const float rstd = lm_row_norm(xr[m], nchunk, K, pro.eps, [](int, int) {});
+                lm_scale_row(xr[m], rstd, pro.norm_w, nchunk);
+            }
+        } else {
 #pragma unroll
+            for (int m = 0; m < M; ++m) lm_load_row(xr[m], x + (long)m * K + k0, nchunk, true);
+        }
+    } else {
+        if (PRO == 1) {
+            // rows of the residual stream handled by this pass (only_last: just the final token)
+            const int Mv = stt->m;
+            const int mbase = pro.only_last ? Mv - 1 : 0;
+            float ss[M];
+            // K <= 2048: at most 8 elements per thread and token; all loads are issued before any is used
+            float pv[M][8];
+    #pragma unroll
+            for (int m = 0; m < M; ++m) {
+                ss[m] = 0.0f;
+                const int mr = mbase + m;
+    #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int k = threadIdx.x + 256 * i;
-                    if (mr < Mv && k < K) pv[m][i] += pro.parts[s2 * pro.part_stride + (long)mr * K + k];
+                    pv[m][i] = (mr < Mv && k < K) ? pro.xin[(long)mr * K + k] : 0.0f;
                 }
             }
-        }
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            const int mr = mbase + m;
-#pragma unroll
+            for (int s2 = 0; s2 < pro.nparts; ++s2) {
+    #pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const int mr = mbase + m;
+    #pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int k = threadIdx.x + 256 * i;
+                        if (mr < Mv && k < K) pv[m][i] += pro.parts[s2 * pro.part_stride + (long)mr * K + k];
+                    }
+                }
+            }
+    #pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const int mr = mbase + m;
+    #pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int k = threadIdx.x + 256 * i;
+                    if (k < K) {
+                        const float v = pv[m][i];
+                        if (blockIdx.x == 0 && pro.xout && mr < Mv) pro.xout[(long)mr * K + k] = v;
+                        xs[m * xld + k] = v;
+                        ss[m] = __builtin_fmaf(v, v, ss[m]);
+                    }
+                }
+            }
+    #pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const float t = wave_sum(ss[m]);
+                if (lane == 0) red[m][wave] = t;
+            }
+            __syncthreads();
+            float rstd[M];
+    #pragma unroll
+            for (int m = 0; m < M; ++m) rstd[m] = rsqrtf((red[m][0] + red[m][1] + red[m][2] + red[m][3]) / (float)K + pro.eps);
+    #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int k = threadIdx.x + 256 * i;
                 if (k < K) {
-                    const float v = pv[m][i];
-                    if (blockIdx.x == 0 && pro.xout && mr < Mv) pro.xout[(long)mr * K + k] = v;
-                    xs[m * xld + k] = v;
-                    ss[m] = __builtin_fmaf(v, v, ss[m]);
+                    const float w = pro.norm_w[k];
+    #pragma unroll
+                    for (int m = 0; m < M; ++m) xs[m * xld + k] = (pv[m][i] * rstd[m]) * w;
                 }
             }
-        }
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            const float t = wave_sum(ss[m]);
-            if (lane == 0) red[m][wave] = t;
+        } else if (KW) {
+            // M*K/4 <= 4096 float4: 16 per thread, loaded in two batches of 8
+            const int n4 = (M * K) >> 2;
+    #pragma unroll
+            for (int b8 = 0; b8 < 2; ++b8) {
+                float4 t[8];
+    #pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int j = threadIdx.x + 256 * (b8 * 8 + i);
+                    if (j < n4) t[i] = reinterpret_cast<const float4*>(x)[j];
+                }
+    #pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int j = threadIdx.x + 256 * (b8 * 8 + i);
+                    if (j < n4) reinterpret_cast<float4*>(xs)[j] = t[i];
+                }
+            }
+        } else {
+            const int kl4 = kl >> 2;
+            for (int i = threadIdx.x; i < M * kl4; i += 256) {
+                const int m = i / kl4, k4 = i - m * kl4;
+                reinterpret_cast<float4*>(xs + m * xld)[k4] = reinterpret_cast<const float4*>(x + (long)m * K + k0)[k4];
+            }
         }
         __syncthreads();
-        float rstd[M];
-#pragma unroll
-        for (int m = 0; m < M; ++m) rstd[m] = rsqrtf((red[m][0] + red[m][1] + red[m][2] + red[m][3]) / (float)K + pro.eps);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k = threadIdx.x + 256 * i;
-            if (k < K) {
-                const float w = pro.norm_w[k];
-#pragma unroll
-                for (int m = 0; m < M; ++m) xs[m * xld + k] = (pv[m][i] * rstd[m]) * w;
-            }
-        }
-    } else if (KW) {
-        // M*K/4 <= 4096 float4: 16 per thread, loaded in two batches of 8
-        const int n4 = (M * K) >> 2;
-#pragma unroll
-        for (int b8 = 0; b8 < 2; ++b8) {
-            float4 t[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int j = threadIdx.x + 256 * (b8 * 8 + i);
-                if (j < n4) t[i] = reinterpret_cast<const float4*>(x)[j];
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int j = threadIdx.x + 256 * (b8 * 8 + i);
-                if (j < n4) reinterpret_cast<float4*>(xs)[j] = t[i];
-            }
-        }
-    } else {
-        const int kl4 = kl >> 2;
-        for (int i = threadIdx.x; i < M * kl4; i += 256) {
-            const int m = i / kl4, k4 = i - m * kl4;
-            reinterpret_cast<float4*>(xs + m * xld)[k4] = reinterpret_cast<const float4*>(x + (long)m * K + k0)[k4];
-        }
     }
-    __syncthreads();
     for (int rb = rb0; rb < row_end; rb += rstep) {
         int r0, r1;
         rows_of(rb, r0, r1);
@@ -291,9 +365,15 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const LmDevState* __restri
             if (c < nchunk) {
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
-                    const float4 x0 = *reinterpret_cast<const float4*>(xs + m * xld + xoff + c * 8);
-                    const float4 x1 = *reinterpret_cast<const float4*>(xs + m * xld + xoff + c * 8 + 4);
-                    const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                    float xv[8];
+                    if (XR) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) xv[j] = xr[m][it][j];
+                    } else {
+                        const float4 x0 = *reinterpret_cast<const float4*>(xs + m * xld + xoff + c * 8);
+                        const float4 x1 = *reinterpret_cast<const float4*>(xs + m * xld + xoff + c * 8 + 4);
+                        xv[0] = x0.x; xv[1] = x0.y; xv[2] = x0.z; xv[3] = x0.w; xv[4] = x1.x; xv[5] = x1.y; xv[6] = x1.z; xv[7] = x1.w;
+                    }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         acc[0][m] = __builtin_fmaf(fa[it][j], xv[j], acc[0][m]);
@@ -1137,17 +1217,18 @@ extern "C" int rca_lm_create_random(const rca_lm_config_t* cfg, uint64_t seed, f
 }
 
 // ------------------------------------------------------------------------- forward pass (M tokens)
-template <int M, int PRO, int EPI, int KW>
+template <int M, int PRO, int EPI, int KW, int XR = (M <= 2 ? 1 : 0)>
 static void launch_gemv_t(rca_lm* h, const bf16_t* W, const float* x, float* y, int N, int K, int kslice, int nsl, long yss, int ldy,
                           const GemvPro& pro, const GemvRope& rope, hipStream_t st) {
     // rows per workgroup: aim at ~512 workgroups (2 per CU).  KW kernels take 2 rows per iteration.
     const int gran = 8;
     const int groups = KW ? 1 : nsl;
-    long want = ((long)N * groups + 511) / 512;
+    static const int tgt = getenv("RCA_GEMV_WGS") ? atoi(getenv("RCA_GEMV_WGS")) : 512;  // experiment knob
+    long want = ((long)N * groups + tgt - 1) / tgt;
     int rpw = (int)std::min<long>(64, std::max<long>(gran, (want + gran - 1) / gran * gran));
     dim3 grid(cdiv(N, rpw), groups);
-    const size_t lds = (size_t)M * (KW ? K : kslice) * 4;
-    auto kern = lm_gemv_kernel<M, PRO, EPI, KW>;
+    const size_t lds = XR ? 0 : (size_t)M * (KW ? K : kslice) * 4;
+    auto kern = lm_gemv_kernel<M, PRO, EPI, KW, XR>;
     if (lds > 48 * 1024) {
         static bool done = false;  // one-time opt-in above the default dynamic LDS size
         if (!done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); done = true; }
@@ -1182,7 +1263,8 @@ static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st) {
     float* nxt = h->x2;
     // decode passes (M <= 2) reduce the down projection's K inside the workgroup; needs ffn % 32 == 0 and
     // [M][ffn] f32 in LDS
-    const bool in_wg_ksplit = Mt <= 2 && h->ksplit_down == 4 && (F % 32) == 0;
+    static const int kwmode = getenv("RCA_LM_KW") ? atoi(getenv("RCA_LM_KW")) : 1;  // experiment knob
+    const bool in_wg_ksplit = kwmode && Mt <= 2 && h->ksplit_down == 4 && (F % 32) == 0;
     lm_embed_kernel<<<M, 256, 0, st>>>(h->stt, h->embed, cur, H, c.vocab_size);
     for (int l = 0; l < c.n_layers; ++l) {
         const LmLayer& L = h->layers[l];
@@ -1193,7 +1275,7 @@ static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st) {
         const int np1 = (l == 0 || in_wg_ksplit) ? 0 : h->ksplit_down;
         if (Mt > 2) {
             // prefill chunks: one norm kernel per token instead of a redundant prologue in every GEMV workgroup
-            lm_add_rmsnorm_kernel<<<M, 256, 0, st>>>(h->stt, cur, np1 ? nxt : nullptr, h->part_d, np1, ps, L.attn_norm, h->xn, H, c.rms_eps);
+            lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, cur, np1 ? nxt : nullptr, h->part_d, np1, ps, L.attn_norm, h->xn, H, c.rms_eps);
             launch_gemv<0, 2>(h, Mt, L.wqkv, h->xn, h->qkv, QKV, H, H, 1, 0, QKV, nopro, rope, st);
         } else {
             GemvPro p1{cur, np1 ? nxt : nullptr, h->part_d, np1, ps, L.attn_norm, c.rms_eps, 0};
@@ -1214,7 +1296,7 @@ static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st) {
         // O projection adds straight into the residual stream (one K slice: each output has a single writer)
         launch_gemv<0, 3>(h, Mt, L.wo, h->attn, cur, H, AO, AO, 1, 0, H, nopro, norope, st);
         if (Mt > 2) {
-            lm_add_rmsnorm_kernel<<<M, 256, 0, st>>>(h->stt, cur, nullptr, nullptr, 0, 0, L.ffn_norm, h->xn, H, c.rms_eps);
+            lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, cur, nullptr, nullptr, 0, 0, L.ffn_norm, h->xn, H, c.rms_eps);
             launch_gemv<0, 1>(h, Mt, L.wgu, h->xn, h->hbuf, 2 * F, H, H, 1, 0, F, nopro, norope, st);
         } else {
             GemvPro p2{cur, nullptr, nullptr, 0, 0, L.ffn_norm, c.rms_eps, 0};
