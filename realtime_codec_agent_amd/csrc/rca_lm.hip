@@ -26,7 +26,8 @@ typedef _Float16 f16_t;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-#define LM_MAXM 8          // tokens per forward pass
+#define LM_MAXM 32         // tokens per forward pass (activation buffers); prefill tiles use all 32
+#define LM_GEMV_M 8        // largest pass served by the GEMV kernels; longer evals go through the MFMA prefill path
 #define LM_KSLICE 2048     // K handled by one workgroup pass of the GEMV
 #define LM_MAXSPLIT 4      // K splits (ffn 8192 / 2048)
 #define ATT_KEYS 256       // keys per attention workgroup
@@ -50,6 +51,12 @@ struct SamplerDev {
     float bias_vals[8];
 };
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ bf16_t f32_to_bf16_rne(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 __device__ __forceinline__ float wave_sum(float v) {
@@ -627,6 +634,136 @@ __global__ __launch_bounds__(64) void lm_attn_combine_kernel(const LmDevState* _
     attn[(long)m * nh * 64 + head * 64 + d] = O / L;
 }
 
+// ------------------------------------------------------------------------- prefill: bf16 MFMA GEMM
+// Prefill tiles (up to 32 tokens per pass) run the projections on v_mfma_f32_32x32x16_bf16: weights are bf16
+// already; the f32 activations are split into bf16 hi + lo (x ~= hi + lo keeps ~16 mantissa bits), so every
+// k step issues two MFMAs into one f32 accumulator.  A workgroup owns one 32-row x 32-token output tile, its 4
+// waves split K and are summed in wave order through LDS (deterministic).  Fragments are loaded straight from
+// global memory: A = 16 B of a weight row per lane, B = 16 B of a token row per lane.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void lm_split_bf16_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ x,
+                                                            bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int K) {
+    const int m = blockIdx.y;
+    if (m >= stt->m) return;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < K; k += gridDim.x * 256) {
+        const float v = x[(long)m * K + k];
+        const bf16_t h = f32_to_bf16_rne(v);
+        const float r = v - __uint_as_float((unsigned)h << 16);
+        hi[(long)m * K + k] = h;
+        lo[(long)m * K + k] = f32_to_bf16_rne(r);
+    }
+}
+
+#define GEMM_EPI_RESID 0
+#define GEMM_EPI_ROPE 1
+#define GEMM_EPI_SWIGLU 2
+template <int EPI>
+__global__ __launch_bounds__(256) void lm_gemm_mfma_kernel(const LmDevState* __restrict__ stt, const bf16_t* __restrict__ W,
+                                                           const bf16_t* __restrict__ xh, const bf16_t* __restrict__ xl, int N, int K,
+                                                           float* __restrict__ y, int ldy, bf16_t* __restrict__ oh, bf16_t* __restrict__ ol,
+                                                           GemvRope rope) {
+    __shared__ float red[3][16][64];
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x;
+    const int Mv = stt->m;
+    auto n_of = [&](int rr) {
+        if (EPI == GEMM_EPI_ROPE) return (tile >> 1) * 64 + (rr >> 4) * 32 + (tile & 1) * 16 + (rr & 15);
+        return tile * 32 + rr;
+    };
+    const int Kw = K >> 2;                     // this wave's K slice
+    const int k0 = wave * Kw;
+    const int nsteps = Kw >> 4;
+    const bf16_t* wrow = W + (long)n_of(lane & 31) * K + k0 + 8 * half;
+    const bf16_t* hrow = xh + (long)(lane & 31) * K + k0 + 8 * half;
+    const bf16_t* lrow = xl + (long)(lane & 31) * K + k0 + 8 * half;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    constexpr int U = 4;
+    uint4 a[U], bh[U], bl[U];
+    auto load = [&](int s0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int st = min(s0 + u, nsteps - 1);
+            a[u] = *reinterpret_cast<const uint4*>(wrow + st * 16);
+            bh[u] = *reinterpret_cast<const uint4*>(hrow + st * 16);
+            bl[u] = *reinterpret_cast<const uint4*>(lrow + st * 16);
+        }
+    };
+    load(0);
+    for (int s0 = 0; s0 < nsteps; s0 += U) {
+        uint4 ca[U], cbh[U], cbl[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { ca[u] = a[u]; cbh[u] = bh[u]; cbl[u] = bl[u]; }
+        if (s0 + U < nsteps) load(s0 + U);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (s0 + u < nsteps) {
+                const bf16x8 av = __builtin_bit_cast(bf16x8, ca[u]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, cbh[u]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, cbl[u]), acc, 0, 0, 0);
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] += red[0][r][lane]; acc[r] += red[1][r][lane]; acc[r] += red[2][r][lane]; }
+    const int tok = lane & 31;
+    if (tok >= Mv) return;
+    if (EPI == GEMM_EPI_RESID) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n_of((r & 3) + 8 * (r >> 2) + 4 * half);
+            if (n < N) y[(long)tok * ldy + n] = y[(long)tok * ldy + n] + acc[r];
+        }
+    } else if (EPI == GEMM_EPI_ROPE) {
+        const int pos = stt->n_tokens + tok;
+        if (pos >= rope.n_ctx) return;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {   // registers r and r+8 hold rows d and d+32 of one head
+            const int n1 = n_of((r & 3) + 8 * (r >> 2) + 4 * half);
+            const int head = n1 >> 6, d = n1 & 63;   // d < 32
+            const float x1 = acc[r], x2 = acc[r + 8];
+            if (head < rope.nh + rope.nkv) {
+                const float c = rope.cos_t[(long)pos * 32 + d], sn = rope.sin_t[(long)pos * 32 + d];
+                const float o1 = x1 * c + (-x2) * sn;
+                const float o2 = x2 * c + x1 * sn;
+                if (head < rope.nh) {
+                    y[(long)tok * ldy + n1] = o1;
+                    y[(long)tok * ldy + n1 + 32] = o2;
+                } else {
+                    f16_t* kp = rope.kc + ((long)pos * rope.nkv + (head - rope.nh)) * 64;
+                    kp[d] = (f16_t)o1;
+                    kp[d + 32] = (f16_t)o2;
+                }
+            } else {
+                f16_t* vp = rope.vc + ((long)pos * rope.nkv + (head - rope.nh - rope.nkv)) * 64;
+                vp[d] = (f16_t)x1;
+                vp[d + 32] = (f16_t)x2;
+            }
+        }
+    } else {  // SwiGLU: rows (2i, 2i+1) = (gate_i, up_i) sit in registers (2j, 2j+1)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int rr = ((2 * j) & 3) + 8 * ((2 * j) >> 2) + 4 * half;
+            const int i = (tile * 32 + rr) >> 1;
+            const float g = acc[2 * j], u = acc[2 * j + 1];
+            const float hv = (g / (1.0f + __expf(-g))) * u;
+            const bf16_t hb = f32_to_bf16_rne(hv);
+            oh[(long)tok * ldy + i] = hb;
+            ol[(long)tok * ldy + i] = f32_to_bf16_rne(hv - __uint_as_float((unsigned)hb << 16));
+        }
+    }
+}
+
 // advance the device-side KV position after a pass
 __global__ void lm_advance_kernel(LmDevState* stt) { stt->n_tokens += stt->m; }
 // steady-state step: next pass's first id is the token just sampled (realtime_agent_v2.py:355-363)
@@ -896,11 +1033,6 @@ __global__ __launch_bounds__(1024) void lm_token_probs_kernel(const float* __res
 // ------------------------------------------------------------------------- random init (bench)
 // value(tensor_id, i) = std * 1.7320508 * (sum of four 16-bit uniforms - 131070) / 65535 ~ N(0, std^2)
 // (Irwin-Hall, integer arithmetic only, reproduced by oracle/lm_ref.py), rounded to bf16 (RNE).
-__device__ __forceinline__ bf16_t f32_to_bf16_rne(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
 __global__ __launch_bounds__(256) void lm_random_bf16_kernel(bf16_t* __restrict__ out, long n, unsigned long long seed,
                                                              unsigned long long tensor_id, float scale) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -956,6 +1088,7 @@ struct rca_lm {
     float *x = nullptr, *x2 = nullptr, *xn = nullptr, *qkv = nullptr, *attn = nullptr, *part_o = nullptr, *hbuf = nullptr, *part_d = nullptr,
           *att_part = nullptr, *logits = nullptr, *probs_dev = nullptr;
     int* probe_ids_dev = nullptr;
+    bf16_t *xh = nullptr, *xl = nullptr;   // prefill: bf16 hi / lo split of the current GEMM input [LM_MAXM][max K]
     long logits_rows_cap = 0;   // rows allocated in `logits` (1, or more when logits_all)
     int logits_rows = 0;        // rows valid from the last eval
     LmDevState* stt = nullptr;  // device
@@ -968,6 +1101,7 @@ struct rca_lm {
     // captured steady-state steps (n = 1, 2)
     hipGraphExec_t graph[3] = {nullptr, nullptr, nullptr};
     bool graphs_enabled = true;
+    bool mfma_prefill = true;   // evals longer than LM_GEMV_M tokens use the bf16 MFMA tiles
 };
 
 static int lm_alloc(void** p, size_t bytes) {
@@ -987,7 +1121,7 @@ extern "C" int rca_lm_destroy(rca_lm_t* h) {
             if (p) (void)hipFree(p);
     for (void* p : {(void*)h->embed, (void*)h->head, (void*)h->final_norm, (void*)h->cos_t, (void*)h->sin_t, (void*)h->kc, (void*)h->vc,
                     (void*)h->x, (void*)h->x2, (void*)h->xn, (void*)h->qkv, (void*)h->attn, (void*)h->part_o, (void*)h->hbuf, (void*)h->part_d,
-                    (void*)h->att_part, (void*)h->logits, (void*)h->probs_dev, (void*)h->probe_ids_dev, (void*)h->stt, (void*)h->samp, (void*)h->swork})
+                    (void*)h->att_part, (void*)h->logits, (void*)h->probs_dev, (void*)h->probe_ids_dev, (void*)h->xh, (void*)h->xl, (void*)h->stt, (void*)h->samp, (void*)h->swork})
         if (p) (void)hipFree(p);
     if (h->h_stt) (void)hipHostFree(h->h_stt);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1111,6 +1245,13 @@ static int lm_common_init(rca_lm* h, const rca_tensor_t* ts, int nt) {
     if ((rc = lm_alloc((void**)&h->logits, (size_t)h->logits_rows_cap * c.vocab_size * 4)) != RCA_OK) return rc;
     if ((rc = lm_alloc((void**)&h->probs_dev, 64 * 4)) != RCA_OK) return rc;
     if ((rc = lm_alloc((void**)&h->probe_ids_dev, 64 * 4)) != RCA_OK) return rc;
+    {
+        const size_t kmax = (size_t)std::max(std::max(H, AO), c.ffn);
+        if ((rc = lm_alloc((void**)&h->xh, (size_t)LM_MAXM * kmax * 2)) != RCA_OK) return rc;
+        if ((rc = lm_alloc((void**)&h->xl, (size_t)LM_MAXM * kmax * 2)) != RCA_OK) return rc;
+        RCA_HIP(hipMemsetAsync(h->xh, 0, (size_t)LM_MAXM * kmax * 2, h->stream));
+        RCA_HIP(hipMemsetAsync(h->xl, 0, (size_t)LM_MAXM * kmax * 2, h->stream));
+    }
     if ((rc = lm_alloc((void**)&h->stt, sizeof(LmDevState))) != RCA_OK) return rc;
     if ((rc = lm_alloc((void**)&h->samp, sizeof(SamplerDev))) != RCA_OK) return rc;
     RCA_HIP(hipMemsetAsync(h->stt, 0, sizeof(LmDevState), h->stream));
@@ -1223,7 +1364,7 @@ static void launch_gemv_t(rca_lm* h, const bf16_t* W, const float* x, float* y, 
     // rows per workgroup: aim at ~512 workgroups (2 per CU).  KW kernels take 2 rows per iteration.
     const int gran = 8;
     const int groups = KW ? 1 : nsl;
-    static const int tgt = getenv("RCA_GEMV_WGS") ? atoi(getenv("RCA_GEMV_WGS")) : 512;  // experiment knob
+    const int tgt = 512;
     long want = ((long)N * groups + tgt - 1) / tgt;
     int rpw = (int)std::min<long>(64, std::max<long>(gran, (want + gran - 1) / gran * gran));
     dim3 grid(cdiv(N, rpw), groups);
@@ -1263,8 +1404,7 @@ static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st) {
     float* nxt = h->x2;
     // decode passes (M <= 2) reduce the down projection's K inside the workgroup; needs ffn % 32 == 0 and
     // [M][ffn] f32 in LDS
-    static const int kwmode = getenv("RCA_LM_KW") ? atoi(getenv("RCA_LM_KW")) : 1;  // experiment knob
-    const bool in_wg_ksplit = kwmode && Mt <= 2 && h->ksplit_down == 4 && (F % 32) == 0;
+    const bool in_wg_ksplit = Mt <= 2 && h->ksplit_down == 4 && (F % 32) == 0;
     lm_embed_kernel<<<M, 256, 0, st>>>(h->stt, h->embed, cur, H, c.vocab_size);
     for (int l = 0; l < c.n_layers; ++l) {
         const LmLayer& L = h->layers[l];
@@ -1319,6 +1459,56 @@ static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st) {
     return RCA_OK;
 }
 
+// One prefill tile (M <= 32 tokens already described by h->stt): projections on bf16 MFMA with hi/lo-split
+// activations, attention through the same split-KV kernels.  Leaves the residual stream in h->x.
+static bool lm_can_mfma_prefill(const rca_lm* h) {
+    const rca_lm_config_t& c = h->cfg;
+    const int AO = c.n_heads * c.head_dim;
+    return c.hidden % 64 == 0 && AO % 64 == 0 && c.ffn % 64 == 0 && (2 * c.ffn) % 32 == 0;
+}
+static int lm_enqueue_prefill_tile(rca_lm* h, int M, hipStream_t st) {
+    const rca_lm_config_t& c = h->cfg;
+    const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim, F = c.ffn;
+    const int G = c.n_heads / c.n_kv_heads;
+    const float scale = 1.0f / sqrtf((float)c.head_dim);
+    GemvRope rope{h->cos_t, h->sin_t, nullptr, nullptr, c.n_heads, c.n_kv_heads, c.n_ctx};
+    const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    float* x = h->x;
+    lm_embed_kernel<<<M, 256, 0, st>>>(h->stt, h->embed, x, H, c.vocab_size);
+    for (int l = 0; l < c.n_layers; ++l) {
+        const LmLayer& L = h->layers[l];
+        f16_t* kc = h->kc + (long)l * h->kv_layer_stride;
+        f16_t* vc = h->vc + (long)l * h->kv_layer_stride;
+        rope.kc = kc; rope.vc = vc;
+        lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.attn_norm, h->xn, H, c.rms_eps);
+        lm_split_bf16_kernel<<<dim3(cdiv(H, 256), M), 256, 0, st>>>(h->stt, h->xn, h->xh, h->xl, H);
+        lm_gemm_mfma_kernel<GEMM_EPI_ROPE><<<QKV / 32, 256, 0, st>>>(h->stt, L.wqkv, h->xh, h->xl, QKV, H, h->qkv, QKV, nullptr, nullptr, rope);
+        dim3 ag(c.n_kv_heads, h->n_splits, (M + 1) / 2);
+        if (G == 4) {
+            lm_attn_kernel<4><<<ag, 256, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale);
+            lm_attn_combine_kernel<4><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
+        } else if (G == 2) {
+            lm_attn_kernel<2><<<ag, 256, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale);
+            lm_attn_combine_kernel<2><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
+        } else {
+            lm_attn_kernel<1><<<ag, 256, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale);
+            lm_attn_combine_kernel<1><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
+        }
+        lm_split_bf16_kernel<<<dim3(cdiv(AO, 256), M), 256, 0, st>>>(h->stt, h->attn, h->xh, h->xl, AO);
+        lm_gemm_mfma_kernel<GEMM_EPI_RESID><<<H / 32, 256, 0, st>>>(h->stt, L.wo, h->xh, h->xl, H, AO, x, H, nullptr, nullptr, norope);
+        lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.ffn_norm, h->xn, H, c.rms_eps);
+        lm_split_bf16_kernel<<<dim3(cdiv(H, 256), M), 256, 0, st>>>(h->stt, h->xn, h->xh, h->xl, H);
+        // SwiGLU epilogue writes the hi/lo split of h straight into the (ffn-wide) split buffers of the down projection:
+        // it reads xh/xl [M][H] and writes [M][F] -- distinct regions are needed, so h goes to the second half of hbuf
+        bf16_t* hh = reinterpret_cast<bf16_t*>(h->hbuf);
+        bf16_t* hl = hh + (long)LM_MAXM * F;
+        lm_gemm_mfma_kernel<GEMM_EPI_SWIGLU><<<2 * F / 32, 256, 0, st>>>(h->stt, L.wgu, h->xh, h->xl, 2 * F, H, nullptr, F, hh, hl, norope);
+        lm_gemm_mfma_kernel<GEMM_EPI_RESID><<<H / 32, 256, 0, st>>>(h->stt, L.wdown, hh, hl, H, F, x, H, nullptr, nullptr, norope);
+    }
+    RCA_LAUNCH_CHECK();
+    return RCA_OK;
+}
+
 static int lm_push_state(rca_lm* h, const int32_t* ids, int m, hipStream_t st) {
     h->h_stt->n_tokens = h->n_tokens;
     h->h_stt->m = m;
@@ -1368,17 +1558,36 @@ extern "C" int rca_lm_eval(rca_lm_t* h, const int32_t* ids, int32_t n) {
         if ((rc = lm_alloc((void**)&h->logits, (size_t)n * h->cfg.vocab_size * 4)) != RCA_OK) return rc;
     }
     float* logits_base = h->logits;
-    for (int off = 0; off < n; off += LM_MAXM) {
-        const int m = std::min(LM_MAXM, n - off);
-        const bool last = off + m >= n;
-        if ((rc = lm_push_state(h, ids + off, m, st)) != RCA_OK) return rc;
-        if (all) h->logits = logits_base + (long)off * h->cfg.vocab_size;
-        rc = lm_enqueue_pass(h, m, all ? 2 : (last ? 1 : 0), st);
-        h->logits = logits_base;
-        if (rc != RCA_OK) return rc;
-        h->n_tokens += m;
-        // the pinned staging block is reused by the next chunk: wait until this one's copy has been consumed
-        if (!last) RCA_HIP(hipStreamSynchronize(st));
+    if (!all && n > LM_GEMV_M && h->mfma_prefill && lm_can_mfma_prefill(h)) {
+        // long evals (session prefill, recompute_kv_cache): 32-token tiles on the bf16 MFMA path
+        for (int off = 0; off < n; off += LM_MAXM) {
+            const int m = std::min(LM_MAXM, n - off);
+            const bool last = off + m >= n;
+            if ((rc = lm_push_state(h, ids + off, m, st)) != RCA_OK) return rc;
+            if ((rc = lm_enqueue_prefill_tile(h, m, st)) != RCA_OK) return rc;
+            if (last) {   // logits of the final token: final norm + head on the register GEMV path
+                const rca_lm_config_t& c = h->cfg;
+                const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+                GemvPro pf{h->x, nullptr, nullptr, 0, 0, h->final_norm, c.rms_eps, 1};
+                launch_gemv<1, 0>(h, 1, h->head, nullptr, h->logits, c.vocab_size, c.hidden, c.hidden, 1, 0, c.vocab_size, pf, norope, st);
+                RCA_LAUNCH_CHECK();
+            }
+            h->n_tokens += m;
+            if (!last) RCA_HIP(hipStreamSynchronize(st));
+        }
+    } else {
+        for (int off = 0; off < n; off += LM_GEMV_M) {
+            const int m = std::min(LM_GEMV_M, n - off);
+            const bool last = off + m >= n;
+            if ((rc = lm_push_state(h, ids + off, m, st)) != RCA_OK) return rc;
+            if (all) h->logits = logits_base + (long)off * h->cfg.vocab_size;
+            rc = lm_enqueue_pass(h, m, all ? 2 : (last ? 1 : 0), st);
+            h->logits = logits_base;
+            if (rc != RCA_OK) return rc;
+            h->n_tokens += m;
+            // the pinned staging block is reused by the next chunk: wait until this one's copy has been consumed
+            if (!last) RCA_HIP(hipStreamSynchronize(st));
+        }
     }
     h->logits_rows = all ? n : 1;
     RCA_HIP(hipStreamSynchronize(st));
@@ -1528,5 +1737,12 @@ extern "C" int rca_lm_mask_head_rows(rca_lm_t* h, int32_t row_begin, int32_t row
     if (n > 0) lm_zero_rows_kernel<<<2048, 256, 0, h->stream>>>(h->head + (long)row_begin * h->cfg.hidden, n);
     RCA_LAUNCH_CHECK();
     RCA_HIP(hipStreamSynchronize(h->stream));
+    return RCA_OK;
+}
+
+// test / bench knob: route long evals through the exact GEMV chunks (0) or the bf16 MFMA prefill tiles (1, default)
+extern "C" int rca_lm_set_mfma_prefill(rca_lm_t* h, int32_t enable) {
+    if (!h) return fail(RCA_ERR_ARG, "null");
+    h->mfma_prefill = enable != 0;
     return RCA_OK;
 }

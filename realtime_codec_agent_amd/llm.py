@@ -405,6 +405,10 @@ class LlamaForAlternatingCodeChannels:
         """Zero lm_head rows (random-init models: keep sampling on codec tokens like a trained model in audio mode)."""
         N.check(self._lib.rca_lm_mask_head_rows(self._h, int(row_begin), int(row_end)), "rca_lm_mask_head_rows")
 
+    def set_mfma_prefill(self, enable: bool) -> None:
+        """Long evals on bf16 MFMA tiles (default) or on the exact 8-token GEMV chunks."""
+        N.check(self._lib.rca_lm_set_mfma_prefill(self._h, 1 if enable else 0), "rca_lm_set_mfma_prefill")
+
     def set_graphs(self, enable: bool) -> None:
         N.check(self._lib.rca_lm_set_graphs(self._h, 1 if enable else 0), "rca_lm_set_graphs")
 

@@ -46,6 +46,8 @@ def test_trim_recompute_matches_fresh_prefill():
     """After the sliding-window eviction (realtime_agent_v2.py:187-190,725-733) the LM state equals a
     fresh prefill of header + surviving suffix: next-step logits are identical."""
     agent, res = make_agent(chunk=0.1, max_context_secs=1.0, trim_by_secs=0.4)
+    res.llm.set_mfma_prefill(False)   # exact mode: recompute and fresh prefill then agree bit for bit
+    agent.reset()                     # re-prefill the header in exact mode too
     sig = rich_signal(16000 * 2, 9)
     for s in range(0, len(sig) - 1599, 1600):
         agent.process_audio(sig[s:s + 1600])
