@@ -24,6 +24,7 @@ using namespace rca;
 typedef unsigned short bf16_t;
 typedef _Float16 f16_t;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 #define LM_MAXM 32         // tokens per forward pass (activation buffers); prefill tiles use all 32
@@ -31,6 +32,10 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #define LM_KSLICE 2048     // K handled by one workgroup pass of the GEMV
 #define LM_MAXSPLIT 4      // K splits (ffn 8192 / 2048)
 #define ATT_KEYS 256       // keys per attention workgroup
+#define ATT_WAVES 8        // waves per attention workgroup
+#define ATT_NIT 4          // groups of 8 keys per wave: ATT_WAVES * ATT_NIT * 8 == ATT_KEYS
+#define ATT_THREADS (64 * ATT_WAVES)
+#define LM_GRAPH_BUCKETS 8  // 4, 8, ..., 256 splits, the last bucket = all of them
 #define SAMP_MAXK 256
 
 struct LmDevState {
@@ -59,15 +64,39 @@ __device__ __forceinline__ bf16_t f32_to_bf16_rne(float f) {
 }
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// Cross-lane butterflies without the LDS crossbar: xor 32 / 16 through the gfx950 permlane swaps, xor 8..1 through
+// DPP.  Pairing order is 32,16,8,4,2,1 exactly like a __shfl_xor loop, so sums keep the same bits.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+#define DPP_XOR1 0xB1          // quad_perm [1,0,3,2]
+#define DPP_XOR2 0x4E          // quad_perm [2,3,0,1]
+#define DPP_ROR4 0x124         // row_ror:4  (== xor 4 once lanes i and i^8 agree)
+#define DPP_ROR8 0x128         // row_ror:8  (== xor 8 inside a row of 16)
+#define DPP_HALF_MIRROR 0x141  // i -> 7-i inside 8 lanes (== xor 4 once the quads are uniform)
+template <typename OP>
+__device__ __forceinline__ float wave_butterfly(float v, OP op) {
+    // v_permlane{32,16}_swap exchange halves / odd-even rows between TWO registers.  Written as asm: this
+    // compiler's builtin mis-assigns the second result.  s_nop covers the VALU-write -> permlane-read hazard
+    // the assembler does not see inside an asm block.
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));   // a = [lo, lo], b = [hi, hi]
+    v = op(a, b);
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));   // a = [r0,r0,r2,r2], b = [r1,r1,r3,r3]
+    v = op(a, b);
+    v = op(v, dpp_mov<DPP_ROR8>(v));
+    v = op(v, dpp_mov<DPP_ROR4>(v));
+    v = op(v, dpp_mov<DPP_XOR2>(v));
+    v = op(v, dpp_mov<DPP_XOR1>(v));
     return v;
 }
+__device__ __forceinline__ float wave_sum(float v) {
+    return wave_butterfly(v, [](float a, float b) { return a + b; });
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    return wave_butterfly(v, [](float a, float b) { return fmaxf(a, b); });
 }
 
 // ------------------------------------------------------------------------------------- embed
@@ -467,120 +496,161 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const LmDevState* __restri
 // grid (nkv, n_splits, ceil(M/2)); workgroup = 4 waves, each wave one 64-key block of this split.
 // Rows r = mi*G + hq (two tokens x G query heads of this kv head), R = 2G <= 8.
 // partial layout: part[((pair*nkv + g)*n_splits + sp)*8 + r][66] = {m, l, o[64]}
+// Split-KV attention for a pair of tokens: grid (kv head, 256-key split, token pair), one wave per 64 keys.
+// lane <-> (key kq of each group of 8, 8-dim chunk dq) in BOTH phases, so K, V and q are each fetched with 16-byte
+// loads that are all in flight before the step state is read, scores are reduced over dq with three cross-lane
+// steps and land exactly where phase B needs the probabilities: no LDS until the 4-wave merge.
+// Split-KV attention for a pair of tokens: grid (kv head, 256-key split, token pair), 8 waves of 32 keys each (the
+// kernel is bound by the instruction stream of a wave, not by bytes: more, shorter waves).
+// lane <-> (key kq of each group of 8, 8-dim chunk dq) in BOTH phases, so K, V and q are each fetched with 16-byte
+// loads that are all in flight before the step state is read, scores are reduced over dq with three cross-lane
+// steps and land exactly where phase B needs the probabilities: no LDS until the 4-wave merge.
 template <int G>
-__global__ __launch_bounds__(256) void lm_attn_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ qkv,
+__global__ __launch_bounds__(ATT_THREADS) void lm_attn_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ qkv,
                                                       const f16_t* __restrict__ kc, const f16_t* __restrict__ vc,
-                                                      float* __restrict__ part, int nh, int nkv, int n_splits, float scale) {
+                                                      float* __restrict__ part, int nh, int nkv, int n_splits, float scale, int n_ctx) {
     constexpr int HD = 64;
     constexpr int R = 2 * G;
     const int g = blockIdx.x, sp = blockIdx.y, pair = blockIdx.z;
-    const int M = stt->m;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kbase = sp * ATT_KEYS;
+    const int kwb = kbase + wave * (8 * ATT_NIT);
+    const int kq = lane & 7, dq = lane >> 3;
     const int m0 = pair * 2;
-    if (m0 >= M) return;
+    const int ld = (nh + 2 * nkv) * HD;
+    // Nothing below depends on the step state: rows past the visible range are clamped to the cache and masked.
+    u32x4 kreg[ATT_NIT], vreg[ATT_NIT];
+    f32x4 qreg[R][2];
+#pragma unroll
+    for (int it = 0; it < ATT_NIT; ++it) {
+        const long row = ((long)min(kwb + it * 8 + kq, n_ctx - 1) * nkv + g) * HD + dq * 8;
+        kreg[it] = *reinterpret_cast<const u32x4*>(kc + row);
+        vreg[it] = *reinterpret_cast<const u32x4*>(vc + row);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const f32x4* q = reinterpret_cast<const f32x4*>(qkv + (long)(m0 + r / G) * ld + (g * G + r % G) * HD + dq * 8);
+        qreg[r][0] = q[0];
+        qreg[r][1] = q[1];
+    }
+    __builtin_amdgcn_sched_barrier(0);   // every load is issued here, not where the scheduler would first need it
+    // a (free) use on the exit paths keeps the optimiser from sinking the loads below the exits
+    auto pin_loads = [&]() {
+#pragma unroll
+        for (int c = 0; c < ATT_NIT; ++c) asm volatile("" ::"v"(kreg[c]), "v"(vreg[c]));
+#pragma unroll
+        for (int r = 0; r < R; ++r) asm volatile("" ::"v"(qreg[r][0]), "v"(qreg[r][1]));
+    };
+    const int M = stt->m;
+    if (m0 >= M) { pin_loads(); return; }
     const int pos0 = stt->n_tokens;
     const int ntok = min(2, M - m0);
     const int kmax = pos0 + m0 + ntok;  // keys [0, kmax) are visible to the last token of the pair
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* pout = part + ((long)(pair * nkv + g) * n_splits + sp) * 8 * 66;
-    const int kbase = sp * ATT_KEYS;
     if (kbase >= kmax) {  // nothing visible in this split
         if (threadIdx.x < R) { pout[threadIdx.x * 66] = -INFINITY; pout[threadIdx.x * 66 + 1] = 0.0f; }
+        pin_loads();
         return;
     }
-    __shared__ __attribute__((aligned(16))) float qs[R][HD];
-    __shared__ float ps[4][R][64];
-    __shared__ float wm[4][R], wl[4][R];
-    __shared__ float wo[4][R][HD];
-    const int ld = (nh + 2 * nkv) * HD;
-    for (int i = threadIdx.x; i < R * HD; i += 256) {
-        const int r = i / HD, d = i - r * HD;
-        const int mi = r / G, hq = r - mi * G;
-        qs[r][d] = (mi < ntok) ? qkv[(long)(m0 + mi) * ld + (g * G + hq) * HD + d] : 0.0f;
-    }
-    __syncthreads();
-    // ---- phase A: lane <-> key
-    const int key = kbase + wave * 64 + lane;
-    float s[R];
+    __shared__ float wm[ATT_WAVES][R], wl[ATT_WAVES][R];
+    __shared__ float wo[ATT_WAVES][R][HD];
+    // ---- phase A: 8-dim partial dot products, then the sum over the 8 dim chunks (lane bits 3..5)
+    float p[ATT_NIT][R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) s[r] = 0.0f;
-    if (key < kmax) {
-        const uint4* kp = reinterpret_cast<const uint4*>(kc + ((long)key * nkv + g) * HD);
+    for (int it = 0; it < ATT_NIT; ++it) {
+        const u32x4 u = kreg[it];
+        const unsigned uw[4] = {u.x, u.y, u.z, u.w};
+        float kv[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const uint4 u = kp[c];
-            const unsigned uw[4] = {u.x, u.y, u.z, u.w};
-            float kv[8];
+        for (int j = 0; j < 4; ++j) {
+            const f16x2 h2 = __builtin_bit_cast(f16x2, uw[j]);
+            kv[2 * j] = (float)h2.x;
+            kv[2 * j + 1] = (float)h2.y;
+        }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f16x2 h2 = __builtin_bit_cast(f16x2, uw[j]);
-                kv[2 * j] = (float)h2.x;
-                kv[2 * j + 1] = (float)h2.y;
-            }
+        for (int r = 0; r < R; ++r) {
+            float a = 0.0f;
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const float4 q0 = *reinterpret_cast<const float4*>(&qs[r][c * 8]);
-                const float4 q1 = *reinterpret_cast<const float4*>(&qs[r][c * 8 + 4]);
-                float a = s[r];
-                a = __builtin_fmaf(q0.x, kv[0], a); a = __builtin_fmaf(q0.y, kv[1], a);
-                a = __builtin_fmaf(q0.z, kv[2], a); a = __builtin_fmaf(q0.w, kv[3], a);
-                a = __builtin_fmaf(q1.x, kv[4], a); a = __builtin_fmaf(q1.y, kv[5], a);
-                a = __builtin_fmaf(q1.z, kv[6], a); a = __builtin_fmaf(q1.w, kv[7], a);
-                s[r] = a;
-            }
+            for (int j = 0; j < 4; ++j) a = __builtin_fmaf(qreg[r][0][j], kv[j], a);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a = __builtin_fmaf(qreg[r][1][j], kv[4 + j], a);
+            p[it][r] = a;
         }
     }
+#pragma unroll
+    for (int it = 0; it < ATT_NIT; ++it)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float a = p[it][r];
+            a += dpp_mov<DPP_ROR8>(a);   // dq ^ 1
+            float b = a, c = a;
+            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(b), "+v"(c));   // dq ^ 2
+            a = b + c;
+            b = a; c = a;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(b), "+v"(c));   // dq ^ 4
+            p[it][r] = b + c;
+        }
+    // ---- softmax statistics of this wave's keys (every lane of a kq column holds the same scores)
     float mrow[R], lrow[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int mi = r / G;
-        const bool vis = (mi < ntok) && (key <= pos0 + m0 + mi);
-        const float sv = vis ? s[r] * scale : -INFINITY;
-        const float mx = wave_max(sv);
-        const float p = (mx == -INFINITY) ? 0.0f : __expf(sv - mx);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int it = 0; it < ATT_NIT; ++it) {
+            const bool vis = (mi < ntok) && (kwb + it * 8 + kq <= pos0 + m0 + mi);
+            p[it][r] = vis ? p[it][r] * scale : -INFINITY;
+            mx = fmaxf(mx, p[it][r]);
+        }
+        mx = fmaxf(mx, dpp_mov<DPP_XOR1>(mx));
+        mx = fmaxf(mx, dpp_mov<DPP_XOR2>(mx));
+        mx = fmaxf(mx, dpp_mov<DPP_HALF_MIRROR>(mx));
+        float l = 0.0f;
+#pragma unroll
+        for (int it = 0; it < ATT_NIT; ++it) {
+            const float e = (mx == -INFINITY) ? 0.0f : __expf(p[it][r] - mx);
+            p[it][r] = e;
+            l += e;
+        }
+        l += dpp_mov<DPP_XOR1>(l);
+        l += dpp_mov<DPP_XOR2>(l);
+        l += dpp_mov<DPP_HALF_MIRROR>(l);
         mrow[r] = mx;
-        lrow[r] = wave_sum(p);
-        ps[wave][r][lane] = p;
+        lrow[r] = l;
     }
-    __syncthreads();
-    // ---- phase B: lane <-> (key group kq of 8, dim chunk dq of 8)
-    const int kq = lane >> 3, dq = lane & 7;
+    // ---- phase B: same lane mapping, the probabilities are already in place
     float o[R][8];
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[r][j] = 0.0f;
-    const int kwb = kbase + wave * 64;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int jj = it * 8 + kq;
-        const int kk = kwb + jj;
-        if (kk < kmax) {
-            const uint4 u = *reinterpret_cast<const uint4*>(vc + ((long)kk * nkv + g) * HD + dq * 8);
-            const unsigned uw[4] = {u.x, u.y, u.z, u.w};
-            float vv[8];
+    for (int it = 0; it < ATT_NIT; ++it) {
+        const bool live = kwb + it * 8 + kq < kmax;   // rows past the visible range may hold anything (p is 0 there): zero them
+        const u32x4 u = vreg[it];
+        const unsigned uw[4] = {live ? u.x : 0u, live ? u.y : 0u, live ? u.z : 0u, live ? u.w : 0u};
+        float vv[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f16x2 h2 = __builtin_bit_cast(f16x2, uw[j]);
-                vv[2 * j] = (float)h2.x;
-                vv[2 * j + 1] = (float)h2.y;
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const float p = ps[wave][r][jj];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[r][j] = __builtin_fmaf(p, vv[j], o[r][j]);
-            }
+        for (int j = 0; j < 4; ++j) {
+            const f16x2 h2 = __builtin_bit_cast(f16x2, uw[j]);
+            vv[2 * j] = (float)h2.x;
+            vv[2 * j + 1] = (float)h2.y;
         }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[r][j] = __builtin_fmaf(p[it][r], vv[j], o[r][j]);
     }
+    // add the 8 keys of a group: butterfly over the low three lane bits
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float v = o[r][j];
-            v += __shfl_xor(v, 8);
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
+            v += dpp_mov<DPP_XOR1>(v);
+            v += dpp_mov<DPP_XOR2>(v);
+            v += dpp_mov<DPP_HALF_MIRROR>(v);
             o[r][j] = v;
         }
     if (kq == 0) {
@@ -594,13 +664,15 @@ __global__ __launch_bounds__(256) void lm_attn_kernel(const LmDevState* __restri
         for (int r = 0; r < R; ++r) { wm[wave][r] = mrow[r]; wl[wave][r] = lrow[r]; }
     }
     __syncthreads();
-    // ---- merge the 4 waves, write the split partial
-    for (int i = threadIdx.x; i < R * HD; i += 256) {
+    // ---- merge the waves, write the split partial
+    for (int i = threadIdx.x; i < R * HD; i += ATT_THREADS) {
         const int r = i / HD, d = i - r * HD;
-        float mx = fmaxf(fmaxf(wm[0][r], wm[1][r]), fmaxf(wm[2][r], wm[3][r]));
+        float mx = wm[0][r];
+#pragma unroll
+        for (int w = 1; w < ATT_WAVES; ++w) mx = fmaxf(mx, wm[w][r]);
         float L = 0.0f, O = 0.0f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < ATT_WAVES; ++w) {
             const float f = (wm[w][r] == -INFINITY) ? 0.0f : __expf(wm[w][r] - mx);
             L = __builtin_fmaf(wl[w][r], f, L);
             O = __builtin_fmaf(wo[w][r][d], f, O);
@@ -609,8 +681,10 @@ __global__ __launch_bounds__(256) void lm_attn_kernel(const LmDevState* __restri
         if (d == 0) { pout[r * 66] = mx; pout[r * 66 + 1] = L; }
     }
 }
-
-// attn[m][head*64 + d] = sum_sp o * exp(m_sp - mx) / sum_sp l * exp(m_sp - mx); one wave per (m, head)
+// One wave per (token, head): lane <-> dim.  Split statistics are fetched lane <-> split (one round trip), the
+// accumulations run in split order like a serial loop, the O rows are fetched four splits at a time.
+// (Folding this into the attention kernel -- last-arriving workgroup merges -- was measured and rejected: the
+// agent-scope release/acquire it needs costs an L2 write-back + invalidate per workgroup, 17 us vs 9.6 + 4.7.)
 template <int G>
 __global__ __launch_bounds__(64) void lm_attn_combine_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ part,
                                                              float* __restrict__ attn, int nh, int nkv, int n_splits) {
@@ -623,13 +697,30 @@ __global__ __launch_bounds__(64) void lm_attn_combine_kernel(const LmDevState* _
     const int nsp = min(n_splits, (stt->n_tokens + m) / ATT_KEYS + 1);
     const float* base = part + ((long)(pair * nkv + g) * n_splits) * 8 * 66 + r * 66;
     float mx = -INFINITY;
-    for (int sp = 0; sp < nsp; ++sp) mx = fmaxf(mx, base[(long)sp * 8 * 66]);
+    for (int s0 = 0; s0 < nsp; s0 += 64) {
+        const int sp = s0 + d;
+        mx = fmaxf(mx, sp < nsp ? base[(long)sp * 8 * 66] : -INFINITY);
+    }
+    mx = wave_max(mx);
     float L = 0.0f, O = 0.0f;
-    for (int sp = 0; sp < nsp; ++sp) {
-        const float* p = base + (long)sp * 8 * 66;
-        const float f = (p[0] == -INFINITY) ? 0.0f : __expf(p[0] - mx);
-        L = __builtin_fmaf(p[1], f, L);
-        O = __builtin_fmaf(p[2 + d], f, O);
+    for (int s0 = 0; s0 < nsp; s0 += 64) {
+        const int spl = min(s0 + d, nsp - 1);
+        const float ml = base[(long)spl * 8 * 66], ll = base[(long)spl * 8 * 66 + 1];
+        const float fl = (ml == -INFINITY) ? 0.0f : __expf(ml - mx);
+        const int cnt = min(64, nsp - s0);
+        for (int j0 = 0; j0 < cnt; j0 += 4) {
+            float pv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pv[j] = base[(long)(s0 + min(j0 + j, cnt - 1)) * 8 * 66 + 2 + d];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j0 + j < cnt) {
+                    const float f = __shfl(fl, j0 + j), l = __shfl(ll, j0 + j);
+                    L = __builtin_fmaf(l, f, L);
+                    O = __builtin_fmaf(pv[j], f, O);
+                }
+            }
+        }
     }
     attn[(long)m * nh * 64 + head * 64 + d] = O / L;
 }
@@ -1099,7 +1190,8 @@ struct rca_lm {
     bool sampler_set = false;
     int ksplit_down = 1, kslice_down = 0;
     // captured steady-state steps (n = 1, 2)
-    hipGraphExec_t graph[3] = {nullptr, nullptr, nullptr};
+    // decode-step graphs per (tokens 1..2, context bucket): bucket b launches min(n_splits, 4 << b) attention splits
+    hipGraphExec_t graph[3][LM_GRAPH_BUCKETS] = {};
     bool graphs_enabled = true;
     bool mfma_prefill = true;   // evals longer than LM_GEMV_M tokens use the bf16 MFMA tiles
 };
@@ -1115,7 +1207,8 @@ extern "C" int rca_lm_destroy(rca_lm_t* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int i = 0; i < 3; ++i)
-        if (h->graph[i]) (void)hipGraphExecDestroy(h->graph[i]);
+        for (int b = 0; b < LM_GRAPH_BUCKETS; ++b)
+            if (h->graph[i][b]) (void)hipGraphExecDestroy(h->graph[i][b]);
     for (auto& L : h->layers)
         for (void* p : {(void*)L.wqkv, (void*)L.wo, (void*)L.wgu, (void*)L.wdown, (void*)L.attn_norm, (void*)L.ffn_norm})
             if (p) (void)hipFree(p);
@@ -1387,10 +1480,14 @@ static void launch_gemv(rca_lm* h, int M, const bf16_t* W, const float* x, float
     }
 }
 
+// attention split blocks needed by a pass of m tokens on top of the current context
+static int lm_splits_needed(const rca_lm* h, int m) { return std::min(h->n_splits, (h->n_tokens + m + ATT_KEYS - 1) / ATT_KEYS); }
+
 // Enqueue one pass over the M tokens whose ids / position are already in h->stt (device).
 // want_logits: 0 none, 1 last token only, 2 every token (logits_all).
 // Per layer: [norm+QKV+RoPE/KV-write] -> [split attention] -> [combine] -> [O proj] -> [norm+gate/up+SwiGLU] -> [down]
-static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st) {
+// nsp_launch: attention split blocks to launch (>= ceil((n_tokens + M) / ATT_KEYS); later splits exit at once).
+static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st, int nsp_launch) {
     const rca_lm_config_t& c = h->cfg;
     const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim, F = c.ffn;
     const int G = c.n_heads / c.n_kv_heads;
@@ -1422,15 +1519,15 @@ static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st) {
             launch_gemv<1, 2>(h, Mt, L.wqkv, nullptr, h->qkv, QKV, H, H, 1, 0, QKV, p1, rope, st);
         }
         if (np1) std::swap(cur, nxt);
-        dim3 ag(c.n_kv_heads, h->n_splits, (M + 1) / 2);
+        dim3 ag(c.n_kv_heads, nsp_launch, (M + 1) / 2);
         if (G == 4) {
-            lm_attn_kernel<4><<<ag, 256, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale);
+            lm_attn_kernel<4><<<ag, ATT_THREADS, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
             lm_attn_combine_kernel<4><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
         } else if (G == 2) {
-            lm_attn_kernel<2><<<ag, 256, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale);
+            lm_attn_kernel<2><<<ag, ATT_THREADS, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
             lm_attn_combine_kernel<2><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
         } else {
-            lm_attn_kernel<1><<<ag, 256, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale);
+            lm_attn_kernel<1><<<ag, ATT_THREADS, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
             lm_attn_combine_kernel<1><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
         }
         // O projection adds straight into the residual stream (one K slice: each output has a single writer)
@@ -1466,7 +1563,7 @@ static bool lm_can_mfma_prefill(const rca_lm* h) {
     const int AO = c.n_heads * c.head_dim;
     return c.hidden % 64 == 0 && AO % 64 == 0 && c.ffn % 64 == 0 && (2 * c.ffn) % 32 == 0;
 }
-static int lm_enqueue_prefill_tile(rca_lm* h, int M, hipStream_t st) {
+static int lm_enqueue_prefill_tile(rca_lm* h, int M, hipStream_t st, int nsp_launch) {
     const rca_lm_config_t& c = h->cfg;
     const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim, F = c.ffn;
     const int G = c.n_heads / c.n_kv_heads;
@@ -1483,15 +1580,15 @@ static int lm_enqueue_prefill_tile(rca_lm* h, int M, hipStream_t st) {
         lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.attn_norm, h->xn, H, c.rms_eps);
         lm_split_bf16_kernel<<<dim3(cdiv(H, 256), M), 256, 0, st>>>(h->stt, h->xn, h->xh, h->xl, H);
         lm_gemm_mfma_kernel<GEMM_EPI_ROPE><<<QKV / 32, 256, 0, st>>>(h->stt, L.wqkv, h->xh, h->xl, QKV, H, h->qkv, QKV, nullptr, nullptr, rope);
-        dim3 ag(c.n_kv_heads, h->n_splits, (M + 1) / 2);
+        dim3 ag(c.n_kv_heads, nsp_launch, (M + 1) / 2);
         if (G == 4) {
-            lm_attn_kernel<4><<<ag, 256, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale);
+            lm_attn_kernel<4><<<ag, ATT_THREADS, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
             lm_attn_combine_kernel<4><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
         } else if (G == 2) {
-            lm_attn_kernel<2><<<ag, 256, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale);
+            lm_attn_kernel<2><<<ag, ATT_THREADS, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
             lm_attn_combine_kernel<2><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
         } else {
-            lm_attn_kernel<1><<<ag, 256, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale);
+            lm_attn_kernel<1><<<ag, ATT_THREADS, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
             lm_attn_combine_kernel<1><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
         }
         lm_split_bf16_kernel<<<dim3(cdiv(AO, 256), M), 256, 0, st>>>(h->stt, h->attn, h->xh, h->xl, AO);
@@ -1564,7 +1661,7 @@ extern "C" int rca_lm_eval(rca_lm_t* h, const int32_t* ids, int32_t n) {
             const int m = std::min(LM_MAXM, n - off);
             const bool last = off + m >= n;
             if ((rc = lm_push_state(h, ids + off, m, st)) != RCA_OK) return rc;
-            if ((rc = lm_enqueue_prefill_tile(h, m, st)) != RCA_OK) return rc;
+            if ((rc = lm_enqueue_prefill_tile(h, m, st, lm_splits_needed(h, m))) != RCA_OK) return rc;
             if (last) {   // logits of the final token: final norm + head on the register GEMV path
                 const rca_lm_config_t& c = h->cfg;
                 const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
@@ -1581,7 +1678,7 @@ extern "C" int rca_lm_eval(rca_lm_t* h, const int32_t* ids, int32_t n) {
             const bool last = off + m >= n;
             if ((rc = lm_push_state(h, ids + off, m, st)) != RCA_OK) return rc;
             if (all) h->logits = logits_base + (long)off * h->cfg.vocab_size;
-            rc = lm_enqueue_pass(h, m, all ? 2 : (last ? 1 : 0), st);
+            rc = lm_enqueue_pass(h, m, all ? 2 : (last ? 1 : 0), st, lm_splits_needed(h, m));
             h->logits = logits_base;
             if (rc != RCA_OK) return rc;
             h->n_tokens += m;
@@ -1678,12 +1775,16 @@ extern "C" int rca_lm_step(rca_lm_t* h, const int32_t* ids, int32_t n, int32_t* 
     h->h_stt->n_tokens = h->n_tokens;
     h->h_stt->m = n;
     for (int i = 0; i < n; ++i) h->h_stt->ids[i] = ids[i];
-    if (!h->graph[n]) {
+    int bucket = 0;
+    const int need = lm_splits_needed(h, n);
+    while (bucket + 1 < LM_GRAPH_BUCKETS && (4 << bucket) < need) ++bucket;
+    const int nsp_launch = bucket + 1 == LM_GRAPH_BUCKETS ? h->n_splits : std::min(h->n_splits, 4 << bucket);
+    if (!h->graph[n][bucket]) {
         hipGraph_t g = nullptr;
         RCA_HIP(hipStreamSynchronize(st));
         RCA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         hipError_t e = hipMemcpyAsync(h->stt, h->h_stt, 8 + 4 * LM_MAXM, hipMemcpyHostToDevice, st);
-        rc = e == hipSuccess ? lm_enqueue_pass(h, n, 1, st) : fail(RCA_ERR_HIP, "capture memcpy: %s", hipGetErrorString(e));
+        rc = e == hipSuccess ? lm_enqueue_pass(h, n, 1, st, nsp_launch) : fail(RCA_ERR_HIP, "capture memcpy: %s", hipGetErrorString(e));
         if (rc == RCA_OK) {
             lm_enqueue_sample(h, h->logits, st);
             e = hipMemcpyAsync(&h->h_stt->out_token, &h->stt->out_token, 4, hipMemcpyDeviceToHost, st);
@@ -1692,11 +1793,11 @@ extern "C" int rca_lm_step(rca_lm_t* h, const int32_t* ids, int32_t n, int32_t* 
         hipError_t e2 = hipStreamEndCapture(st, &g);
         if (rc != RCA_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
         if (e2 != hipSuccess) return fail(RCA_ERR_HIP, "end capture: %s", hipGetErrorString(e2));
-        e2 = hipGraphInstantiate(&h->graph[n], g, nullptr, nullptr, 0);
+        e2 = hipGraphInstantiate(&h->graph[n][bucket], g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
-        if (e2 != hipSuccess) { h->graph[n] = nullptr; return fail(RCA_ERR_HIP, "graph instantiate: %s", hipGetErrorString(e2)); }
+        if (e2 != hipSuccess) { h->graph[n][bucket] = nullptr; return fail(RCA_ERR_HIP, "graph instantiate: %s", hipGetErrorString(e2)); }
     }
-    RCA_HIP(hipGraphLaunch(h->graph[n], st));
+    RCA_HIP(hipGraphLaunch(h->graph[n][bucket], st));
     RCA_HIP(hipStreamSynchronize(st));
     h->n_tokens += n;
     h->logits_rows = 1;
