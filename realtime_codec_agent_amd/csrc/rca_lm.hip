@@ -269,10 +269,25 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const LmDevState* __restri
     if (rb0 < row_end) load_rows(rb0);
 
     float xr[XR ? M : 1][4][8];
+    // RoPE rows of this step's positions (EPI 2): lane l holds cos/sin[pos0 + m][l & 31], fetched now and read with
+    // a lane broadcast in the epilogue instead of a dependent load at the tail of the kernel
+    float cosv[EPI == 2 ? M : 1], sinv[EPI == 2 ? M : 1];
+    int ep_m = M, ep_pos0 = 0;
+    if (EPI == 2) {
+        ep_m = stt->m; ep_pos0 = stt->n_tokens;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const long pos = min(ep_pos0 + m, rope.n_ctx - 1);
+            cosv[m] = rope.cos_t[pos * 32 + (lane & 31)];
+            sinv[m] = rope.sin_t[pos * 32 + (lane & 31)];
+        }
+    }
+    if (EPI == 3) ep_m = stt->m;
     if (XR) {
         if (PRO == 1) {
-            const int Mv = stt->m;
-            const int mbase = pro.only_last ? Mv - 1 : 0;
+            // decode passes carry exactly M live rows: only the last-row head pass has to wait for the step state
+            int Mv = M, mbase = 0;
+            if (pro.only_last) { Mv = stt->m; mbase = Mv - 1; }
 #pragma unroll
             for (int m = 0; m < M; ++m) {
                 const int mr = mbase + m;
@@ -395,6 +410,24 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const LmDevState* __restri
             fb[it][4] = bf16_lo(b.z); fb[it][5] = bf16_hi(b.z); fb[it][6] = bf16_lo(b.w); fb[it][7] = bf16_hi(b.w);
         }
         if (rb + rstep < row_end) load_rows(rb + rstep);
+        // residual values this pair is added to (EPI 3): fetched under the FMA block, not after the reduction
+        float yv[2][M];
+        float ykw = 0.0f;
+        if (EPI == 3) {
+            if (KW) {
+                if (threadIdx.x < 2 * M) {
+                    const int rr = threadIdx.x / M, m = threadIdx.x % M;
+                    const int r = rr ? r1 : r0;
+                    if (r < N && m < ep_m) ykw = y[(long)m * ldy + r];
+                }
+            } else if (lane == 0) {
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    yv[0][m] = m < ep_m ? y[(long)m * ldy + r0] : 0.0f;
+                    yv[1][m] = (m < ep_m && has2) ? y[(long)m * ldy + r1] : 0.0f;
+                }
+            }
+        }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int c = lane + 64 * it;
@@ -433,8 +466,8 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const LmDevState* __restri
             if (threadIdx.x < 2 * M) {
                 const int rr = threadIdx.x / M, m = threadIdx.x % M;
                 const int r = rr ? r1 : r0;
-                if (r < N && m < stt->m) {
-                    float v = y[(long)m * ldy + r];
+                if (r < N && m < ep_m) {
+                    float v = ykw;
                     v += kred[0][rr][m]; v += kred[1][rr][m]; v += kred[2][rr][m]; v += kred[3][rr][m];
                     y[(long)m * ldy + r] = v;
                 }
@@ -449,14 +482,20 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const LmDevState* __restri
                 }
             } else if (EPI == 2) {
                 const int head = r0 >> 6, d = r0 & 63;  // d < 32
-                const int Mv = stt->m, pos0 = stt->n_tokens;
+                float cs[M], sn_[M];
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    cs[m] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cosv[m]), __builtin_amdgcn_readfirstlane(d)));
+                    sn_[m] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sinv[m]), __builtin_amdgcn_readfirstlane(d)));
+                }
+                const int Mv = ep_m, pos0 = ep_pos0;
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
                     const int pos = pos0 + m;
                     if (m >= Mv || pos >= rope.n_ctx) continue;
                     const float x1 = acc[0][m], x2 = acc[1][m];
                     if (head < rope.nh + rope.nkv) {
-                        const float c = rope.cos_t[(long)pos * 32 + d], sn = rope.sin_t[(long)pos * 32 + d];
+                        const float c = cs[m], sn = sn_[m];
                         const float o1 = x1 * c + (-x2) * sn;
                         const float o2 = x2 * c + x1 * sn;
                         if (head < rope.nh) {
@@ -474,12 +513,11 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const LmDevState* __restri
                     }
                 }
             } else if (EPI == 3) {  // residual add in place (single K slice)
-                const int Mv = stt->m;
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
-                    if (m >= Mv) continue;
-                    y[(long)m * ldy + r0] = y[(long)m * ldy + r0] + acc[0][m];
-                    if (has2) y[(long)m * ldy + r1] = y[(long)m * ldy + r1] + acc[1][m];
+                    if (m >= ep_m) continue;
+                    y[(long)m * ldy + r0] = yv[0][m] + acc[0][m];
+                    if (has2) y[(long)m * ldy + r1] = yv[1][m] + acc[1][m];
                 }
             } else {
 #pragma unroll
