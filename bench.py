@@ -140,6 +140,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # SURVEY 8f-1 leg (reported beside the headline, never as `value`): the same steps with every window cut down
+    # to the receptive field of its kept frames -- identical codes (checked), ~10x less encoder work
+    codes_full = codes.clone()
+    hip.set_window_trim(True)
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total_steps):
+        step(i)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    elapsed_trim = time.perf_counter() - t0
+    hip.set_window_trim(False)
+    if dist is not None:
+        t = torch.tensor([elapsed_trim], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_trim = float(t.item())
+    trim_identical = bool(torch.equal(codes, codes_full))
+    assert trim_identical, "window-trimmed batch encode produced different codes"
+
     prof = {k: hip.profile_read(k) for k in (0, 1, 2, 3)}
     audio_secs = args.steps * chunks_per_step * chunk / cfg.sample_rate  # per rank, stereo seconds
     value = world * audio_secs / elapsed
@@ -170,6 +194,12 @@ def main():
             "codebook": f"{cfg.codebook_size}x{cfg.codebook_dim}",
             "encoder_gflop_per_window": cfg.encoder_flops_per_sample() * ctx / 1e9,
             "sharding": "chunk ranges per rank, no collective (replicas only)",
+            "receptive_field_trimmed": {
+                "value": world * audio_secs / elapsed_trim, "unit": "audio-hours/hour", "ms_per_step": 1e3 * elapsed_trim / args.steps,
+                "codes_identical_to_full_windows": trim_identical,
+                "note": "same steps with rca_codec_set_window_trim(1): each window cut to the kept frames + their receptive "
+                        "field (SURVEY 8f-1); valid for this build's conv codec only, so it is not the headline value",
+            },
         },
         "roofline": {
             "kernel": "conv1d_mfma_kernel (implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",

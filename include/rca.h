@@ -115,6 +115,27 @@ int rca_codec_encode_chunk_range_dev(rca_codec_t* h, const float* audio_dev, int
                                      int64_t chunk_begin, int64_t chunk_end, int64_t* codes_dev,
                                      int64_t codes_per_channel, void* stream);
 
+/* Streaming tail of the encoder.  AudioTokenizer.tokenize_audio re-encodes the whole rolling
+ * window for every chunk and keeps only the last int(secs*framerate) codes (audio_tokenizer.py:72-74,98-101).
+ * This returns exactly those codes -- bit-identical to the last n_keep columns of rca_codec_encode_dev(pcm, B, T) --
+ * but runs the encoder only over the frames whose receptive field reaches them (n_keep + enc_left_frames whole
+ * frames; the frame grid and the right edge of the window are unchanged).  Valid because this build's codec is a
+ * finite-receptive-field conv stack; rca_codec_receptive_field reports the margins derived from the geometry.
+ * pcm [B,T] f32 (row stride T) -> codes [B,n_keep] int64. */
+int rca_codec_encode_tail_dev(rca_codec_t* h, const float* pcm_dev, int32_t B, int32_t T, int32_t n_keep,
+                              int64_t* codes_dev, void* stream);
+/* Streaming tail of the decoder: the last n_samples of rca_codec_decode_dev(codes, B, F), bit-identical
+ * (AudioTokenizer.detokenize_audio keeps int(secs*sr)+preroll samples of a 100-code window,
+ * audio_tokenizer.py:113,141-145).  codes [B,F] int64 (row stride F) -> pcm [B,n_samples] f32. */
+int rca_codec_decode_tail_dev(rca_codec_t* h, const int64_t* codes_dev, int32_t B, int32_t F, int32_t n_samples,
+                              float* pcm_dev, void* stream);
+/* whole frames a kept code / a kept sample can see to its left */
+int rca_codec_receptive_field(const rca_codec_t* h, int32_t* enc_left_frames, int32_t* dec_left_frames);
+/* Batch windows (rca_codec_encode_windows_dev / _chunk_range_dev): when enabled, each window is cut down to the
+ * frames its kept codes can see -- same codes for any ctx_samples >= the receptive field, ~10x less work at
+ * 2.0 s context.  Off by default: the default path computes every window in full, as the reference does. */
+int rca_codec_set_window_trim(rca_codec_t* h, int32_t enable);
+
 /* AudioTokenizer._magicodec_decode (audio_tokenizer.py:196-201):
  * embedding(codes, codebook_proj(codebook.weight)) -> decoder -> f32 PCM.
  * codes [B,F] int64 -> pcm [B,F*hop] f32. */

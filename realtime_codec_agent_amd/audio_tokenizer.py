@@ -56,6 +56,11 @@ class AudioTokenizer:
             codec_model, _, _ = load_magicodec_model(codec_model, self.device)
         self.codec_model = codec_model.eval().to(self.device)
 
+        # Streaming shortcut: when the codec model offers encode_tail / decode_tail, each call computes
+        # only the frames / samples that are kept (their receptive field), not the whole rolling window.  Output is
+        # bit-identical; set to False to run every window in full like the reference (:74,:113).
+        self.streaming_tail = True
+
         self.num_channels = num_channels
         self.num_codebooks = 1
         self.codebook_size = self.codec_model.codebook_size
@@ -100,8 +105,15 @@ class AudioTokenizer:
         self.tokenize_context = self.tokenize_context[..., -max(audio.shape[-1], self.context_samples):]
 
         input_audio = torch.from_numpy(np.ascontiguousarray(self.tokenize_context)).to(self.device)
+        audio_secs = audio.shape[-1] / self.sampling_rate
+        audio_frames = int(audio_secs * self.framerate * self.num_channels)
         # every channel is one row of a single batched launch (the reference loops channels, :84)
-        encoder_outputs = self._magicodec_encode(input_audio)  # [C, 1, F]
+        if self.streaming_tail and audio_frames > 0 and hasattr(self.codec_model, "encode_tail"):
+            # only the last audio_frames characters survive below: ask the codec for exactly those frames.  Same
+            # codes, bit for bit; the encoder runs over their receptive field instead of the whole window.
+            encoder_outputs = self.codec_model.encode_tail(input_audio, -(-audio_frames // self.num_channels)).unsqueeze(1)
+        else:
+            encoder_outputs = self._magicodec_encode(input_audio)  # [C, 1, F]
 
         channels_chars = [
             codes_to_chars(ch_codes, self.codebook_size, unicode_offset=self.unicode_offset) for ch_codes in encoder_outputs.cpu().numpy()
@@ -109,8 +121,6 @@ class AudioTokenizer:
         audio_codes_str = "".join(list(itertools.chain.from_iterable(zip(*channels_chars))))
 
         # discard context codes that come before the audio we are tokenizing (reference :98-101)
-        audio_secs = audio.shape[-1] / self.sampling_rate
-        audio_frames = int(audio_secs * self.framerate * self.num_channels)
         audio_codes_str = audio_codes_str[-audio_frames:]
         return audio_codes_str
 
@@ -128,12 +138,15 @@ class AudioTokenizer:
         ]
         input_audio_codes = torch.stack(input_audio_codes).to(self.device)  # [C, 1, F]
 
-        output_audio = self._magicodec_decode(input_audio_codes)  # [C, 1, T]
-        output_audio = output_audio.transpose(0, 1)  # [1, C, T] == cat(dim=1) of the per-channel [1,1,T] (reference :136-139)
-
         # discard context audio that comes before the codes we are detokenizing (reference :141-145)
         audio_secs = self.get_audio_codes_str_secs(audio_codes_str)
         audio_samples = int(audio_secs * self.sampling_rate) + preroll_samples
+        if self.streaming_tail and audio_samples > 0 and hasattr(self.codec_model, "decode_tail"):
+            # the same samples, bit for bit, decoded from the codes they depend on instead of the whole context
+            output_audio = self.codec_model.decode_tail(input_audio_codes.squeeze(1), audio_samples).float()
+        else:
+            output_audio = self._magicodec_decode(input_audio_codes)  # [C, 1, T]
+        output_audio = output_audio.transpose(0, 1)  # [1, C, T] == cat(dim=1) of the per-channel [1,1,T] (reference :136-139)
         output_audio = output_audio[..., -audio_samples:]
         preroll_samples = max(0, preroll_samples - audio_samples + output_audio.shape[-1])
 

@@ -103,6 +103,26 @@ class HipCodec:
     def decode_dev(self, codes_ptr: int, B: int, F: int, pcm_ptr: int, stream: int = 0) -> None:
         N.check(self._lib.rca_codec_decode_dev(self._h, C.c_void_p(codes_ptr), B, F, C.c_void_p(pcm_ptr), C.c_void_p(stream)), "rca_codec_decode_dev")
 
+    def encode_tail_dev(self, pcm_ptr: int, B: int, T: int, n_keep: int, codes_ptr: int, stream: int = 0) -> None:
+        """Last n_keep codes of encode_dev(pcm), computed over their receptive field only (bit-identical)."""
+        N.check(self._lib.rca_codec_encode_tail_dev(self._h, C.c_void_p(pcm_ptr), B, T, n_keep, C.c_void_p(codes_ptr), C.c_void_p(stream)),
+                "rca_codec_encode_tail_dev")
+
+    def decode_tail_dev(self, codes_ptr: int, B: int, F: int, n_samples: int, pcm_ptr: int, stream: int = 0) -> None:
+        """Last n_samples of decode_dev(codes), computed from the codes they depend on only (bit-identical)."""
+        N.check(self._lib.rca_codec_decode_tail_dev(self._h, C.c_void_p(codes_ptr), B, F, n_samples, C.c_void_p(pcm_ptr), C.c_void_p(stream)),
+                "rca_codec_decode_tail_dev")
+
+    def receptive_field(self) -> Tuple[int, int]:
+        """(encoder, decoder) whole frames a kept code / sample can see to its left."""
+        a, b = C.c_int32(), C.c_int32()
+        N.check(self._lib.rca_codec_receptive_field(self._h, C.byref(a), C.byref(b)), "rca_codec_receptive_field")
+        return a.value, b.value
+
+    def set_window_trim(self, enable: bool) -> None:
+        """Batch windows encode only what their kept codes can see (same codes, ~10x less work at 2 s context)."""
+        N.check(self._lib.rca_codec_set_window_trim(self._h, int(bool(enable))), "rca_codec_set_window_trim")
+
     def encode_windows_dev(self, audio_ptr: int, Cn: int, Nsamp: int, chunk: int, ctx: int, batch_windows: int, codes_ptr: int,
                            codes_per_channel: int, stream: int = 0) -> None:
         N.check(self._lib.rca_codec_encode_windows_dev(self._h, C.c_void_p(audio_ptr), Cn, C.c_int64(Nsamp), chunk, ctx, batch_windows,
@@ -261,6 +281,28 @@ class MagiCodecHIP:
         codes = torch.empty((B, self.hip.num_frames(T)), dtype=torch.int64, device=x.device)
         self.hip.encode_dev(x.data_ptr(), B, T, codes.data_ptr(), _stream_of(x))
         return codes
+
+    def encode_tail(self, x, n_keep: int):
+        """The last n_keep columns of encode_codes(x), bit-identical, at the cost of n_keep + margin frames:
+        what tokenize_audio keeps of each rolling window (audio_tokenizer.py:98-101).  [B,T] f32 -> [B,n_keep] int64."""
+        torch = _torch()
+        x = x.contiguous().float()
+        B, T = x.shape
+        n_keep = min(int(n_keep), self.hip.num_frames(T))
+        codes = torch.empty((B, n_keep), dtype=torch.int64, device=x.device)
+        self.hip.encode_tail_dev(x.data_ptr(), B, T, n_keep, codes.data_ptr(), _stream_of(x))
+        return codes
+
+    def decode_tail(self, codes, n_samples: int):
+        """The last n_samples of decode_codes(codes), bit-identical (audio_tokenizer.py:141-145).
+        [B,F] int64 -> [B,1,min(n_samples, F*hop)] f32."""
+        torch = _torch()
+        codes = codes.contiguous().to(torch.int64)
+        B, F = codes.shape
+        n = min(int(n_samples), F * self.hop)
+        pcm = torch.empty((B, 1, n), dtype=torch.float32, device=codes.device)
+        self.hip.decode_tail_dev(codes.data_ptr(), B, F, n, pcm.data_ptr(), _stream_of(codes))
+        return pcm
 
     def decode_codes(self, codes):
         """embedding(codes, projected codebook) -> decoder in one C-ABI call: [B,F] int64 -> [B,1,T] f32."""

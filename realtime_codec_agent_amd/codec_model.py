@@ -66,6 +66,21 @@ class CodecConfig:
         out.append(dict(name="dec.conv_out", cin=self.channels[0], cout=1, k=self.k_in, s=1, pre=True, tr=False))
         return out
 
+    def receptive_field(self) -> Tuple[int, int]:
+        """(encoder, decoder) whole frames a kept code / a kept sample can see to its LEFT, from the layer geometry
+        (padL = (k - s + 1) // 2 everywhere).  Mirrors csrc/rca_codec.hip::codec_receptive_field: the streaming tail
+        entry points recompute only this margin plus the kept frames."""
+        lo = 0
+        for layer in reversed(self.encoder_layers()):
+            lo = lo * layer["s"] - (layer["k"] - layer["s"] + 1) // 2
+        enc_left = -(lo // self.hop)          # ceil(-lo / hop)
+        u = 0
+        for layer in reversed(self.decoder_layers()):
+            k, s = layer["k"], layer["s"]
+            pad = (k - s + 1) // 2
+            u = -((-(u + pad - (k - 1))) // s) if layer["tr"] else u - pad     # ceil division / plain shift
+        return enc_left, -u
+
     def encoder_flops_per_sample(self) -> float:
         """Multiply-add FLOPs (2 per MAC) of the encoder stack per input sample."""
         rate = 1.0

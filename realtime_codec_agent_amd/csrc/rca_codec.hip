@@ -881,7 +881,7 @@ __global__ __launch_bounds__(256) void vq_finalize_kernel(unsigned long long* __
 }
 
 // zq[b][j][f] = cb[codes[b][f]][j]
-__global__ __launch_bounds__(256) void embed_codes_kernel(const int64_t* __restrict__ codes, const float* __restrict__ cb,
+__global__ __launch_bounds__(256) void embed_codes_kernel(const int64_t* __restrict__ codes, long ldc, const float* __restrict__ cb,
                                                           float* __restrict__ zq, int B, int F, int J, int N,
                                                           int* __restrict__ err) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -890,7 +890,7 @@ __global__ __launch_bounds__(256) void embed_codes_kernel(const int64_t* __restr
     const long r = idx / F;
     const int j = (int)(r % J);
     const int b = (int)(r / J);
-    int64_t c = codes[(long)b * F + f];
+    int64_t c = codes[(long)b * ldc + f];
     if (c < 0 || c >= N) { atomicExch(err, 1); c = 0; }
     zq[idx] = cb[c * J + j];
 }
@@ -956,10 +956,13 @@ struct rca_codec {
     hipStream_t stream = nullptr;
     int hop = 1;
     int variant = 1;
+    // receptive-field margins (whole frames) left of a kept frame / sample, derived from the layer geometry
+    int enc_left_frames = 0, dec_left_frames = 0;
+    bool window_trim = false;   // batch windows: encode only what the kept frames can see (same codes)
     std::vector<ConvLayer> enc, dec;
     float *q_in_w = nullptr, *q_in_b = nullptr;
     float *cb = nullptr, *hc = nullptr, *cbp = nullptr;
-    DevBuf act[2], zbuf, keys, io_a, io_b;
+    DevBuf act[2], zbuf, keys, io_a, io_b, tail;
     int* err_flag = nullptr;
     hipStream_t last_stream = nullptr;
     bool last_stream_valid = false;
@@ -1083,13 +1086,34 @@ extern "C" int rca_codec_destroy(rca_codec_t* h) {
     for (float* p : {h->q_in_w, h->q_in_b, h->cb, h->hc, h->cbp})
         if (p) (void)hipFree(p);
     if (h->err_flag) (void)hipFree(h->err_flag);
-    h->act[0].release(); h->act[1].release(); h->zbuf.release(); h->keys.release(); h->io_a.release(); h->io_b.release();
+    h->act[0].release(); h->act[1].release(); h->zbuf.release(); h->keys.release(); h->io_a.release(); h->io_b.release(); h->tail.release();
     for (auto* v : {&h->prof, &h->prof_pool})
         for (auto& p : *v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (h->xev) (void)hipEventDestroy(h->xev);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return RCA_OK;
+}
+
+// How far to the left a kept output can see, in whole frames.
+//  encoder: output t of a conv (k, s, padL = (k-s+1)/2) reads inputs [t*s - padL, t*s + k-1 - padL]; chaining the
+//           lower bound from the last layer down to the PCM gives frame f -> sample f*hop - reach.
+//  decoder: output u of a transposed conv reads inputs t >= ceil((u + padL - (k-1)) / s); a plain conv reads
+//           t >= u - padL; chaining from the PCM up to the code sequence gives sample f*hop -> frame f - reach
+//           (the bound is hop-periodic, so the frame boundary is the worst case).
+static void codec_receptive_field(const rca_codec_config_t& c, int hop, int* enc_left, int* dec_left) {
+    const int n = c.n_stages;
+    long lo = 0;
+    lo = lo - (c.k_latent - 1 + 1) / 2;                                        // conv_out (s = 1)
+    for (int i = n - 1; i >= 0; --i) { const int s = c.strides[i], k = 2 * s; lo = lo * s - (k - s + 1) / 2; }
+    lo = lo - (c.k_in - 1 + 1) / 2;                                            // conv_in (s = 1)
+    *enc_left = (int)((-lo + hop - 1) / hop);
+    auto ceil_div = [](long a, long b) { return a >= 0 ? (a + b - 1) / b : -((-a) / b); };
+    long u = 0;
+    u = u - (c.k_in - 1 + 1) / 2;                                              // dec.conv_out (s = 1)
+    for (int i = 0; i < n; ++i) { const int s = c.strides[i], k = 2 * s; u = ceil_div(u + (k - s + 1) / 2 - (k - 1), s); }   // up stages, last first
+    u = u - (c.k_latent - 1 + 1) / 2;                                          // dec.conv_in (s = 1)
+    *dec_left = (int)(-u);
 }
 
 extern "C" int rca_codec_create(const rca_codec_config_t* cfg, const rca_tensor_t* ts, int32_t nt, int32_t device,
@@ -1110,6 +1134,7 @@ extern "C" int rca_codec_create(const rca_codec_config_t* cfg, const rca_tensor_
     const int n = cfg->n_stages;
     h->hop = 1;
     for (int i = 0; i < n; ++i) h->hop *= cfg->strides[i];
+    codec_receptive_field(*cfg, h->hop, &h->enc_left_frames, &h->dec_left_frames);
 
     auto add = [&](std::vector<ConvLayer>& v, const std::string& name, int cin, int cout, int k, int s, int pre, int tr,
                    bool pack) -> int {
@@ -1431,6 +1456,38 @@ extern "C" int rca_codec_encode_dev(rca_codec_t* h, const float* pcm, int32_t B,
     return run_quantize(h, ze, 0, B, F, 0, F, dst, st, nullptr);
 }
 
+// Frames that can be dropped from the left of a window of F frames when only the last `keep` are wanted.
+static int trimmable_frames(const rca_codec* h, int F, int keep) { return std::max(0, F - keep - h->enc_left_frames); }
+
+extern "C" int rca_codec_encode_tail_dev(rca_codec_t* h, const float* pcm, int32_t B, int32_t T, int32_t n_keep, int64_t* codes,
+                                         void* stream) {
+    if (!h || !pcm || !codes || B < 1 || T < 1 || n_keep < 1) return fail(RCA_ERR_ARG, "encode_tail: bad argument (B=%d T=%d keep=%d)", B, T, n_keep);
+    const int F = (T + h->hop - 1) / h->hop;
+    if (n_keep > F) return fail(RCA_ERR_ARG, "encode_tail: %d frames wanted, the window holds %d", n_keep, F);
+    RCA_HIP(hipSetDevice(h->device));
+    hipStream_t st = pick_stream(h, stream);
+    // frames are counted from the window start: drop whole frames so the grid (and the right edge) stay put
+    const int j = trimmable_frames(h, F, n_keep);
+    RowSrc src{pcm + (long)j * h->hop, B, (long)T, 0, T - j * h->hop};
+    float* ze; int Ft, rc;
+    if ((rc = run_encoder(h, src, B, st, &ze, &Ft, -1, nullptr)) != RCA_OK) return rc;
+    RowDst dst{codes, B, (long)n_keep, 0, n_keep};
+    return run_quantize(h, ze, 0, B, Ft, Ft - n_keep, n_keep, dst, st, nullptr);
+}
+
+extern "C" int rca_codec_receptive_field(const rca_codec_t* h, int32_t* enc_left_frames, int32_t* dec_left_frames) {
+    if (!h || !enc_left_frames || !dec_left_frames) return fail(RCA_ERR_ARG, "null");
+    *enc_left_frames = h->enc_left_frames;
+    *dec_left_frames = h->dec_left_frames;
+    return RCA_OK;
+}
+
+extern "C" int rca_codec_set_window_trim(rca_codec_t* h, int32_t enable) {
+    if (!h) return fail(RCA_ERR_ARG, "null");
+    h->window_trim = enable != 0;
+    return RCA_OK;
+}
+
 extern "C" int rca_codec_encode(rca_codec_t* h, const float* pcm_host, int32_t B, int32_t T, int64_t* codes_host) {
     if (!h || !pcm_host || !codes_host || B < 1 || T < 1) return fail(RCA_ERR_ARG, "encode: bad argument (B=%d T=%d)", B, T);
     RCA_HIP(hipSetDevice(h->device));
@@ -1506,8 +1563,10 @@ extern "C" int rca_codec_encode_chunk_range_dev(rca_codec_t* h, const float* aud
     long i = chunk_begin;
     // warm-up: the rolling context is still shorter than ctx (audio_tokenizer.py:72-74)
     for (; i < chunk_end && (i + 1) * (long)chunk < W; ++i) {
-        const int T = (int)((i + 1) * chunk);
-        RowSrc src{audio, C, (long)N, 0, T};
+        const int Tfull = (int)((i + 1) * chunk);
+        const int jw = h->window_trim ? trimmable_frames(h, (Tfull + h->hop - 1) / h->hop, fpc) : 0;
+        const int T = Tfull - jw * h->hop;
+        RowSrc src{audio + (long)jw * h->hop, C, (long)N, 0, T};
         float* ze; int F;
         if ((rc = run_encoder(h, src, C, st, &ze, &F, -1, nullptr)) != RCA_OK) return rc;
         if (F < fpc) return fail(RCA_ERR_STATE, "window of %d samples has %d frames < %d kept", T, F, fpc);
@@ -1518,8 +1577,10 @@ extern "C" int rca_codec_encode_chunk_range_dev(rca_codec_t* h, const float* aud
     const int wins_per_pass = std::max(1, batch_windows / C);
     while (i < chunk_end) {
         const int nw = (int)std::min<long>(wins_per_pass, chunk_end - i);
-        const long start0 = (i + 1) * (long)chunk - W;
-        RowSrc src{audio + start0, C, (long)N, (long)chunk, W};
+        // window_trim: the kept frames see at most enc_left_frames to their left -- drop the whole frames before that
+        const int jw = h->window_trim ? trimmable_frames(h, (W + h->hop - 1) / h->hop, fpc) : 0;
+        const long start0 = (i + 1) * (long)chunk - W + (long)jw * h->hop;
+        RowSrc src{audio + start0, C, (long)N, (long)chunk, W - jw * h->hop};
         float* ze; int F;
         if ((rc = run_encoder(h, src, nw * C, st, &ze, &F, -1, nullptr)) != RCA_OK) return rc;
         if (F < fpc) return fail(RCA_ERR_STATE, "window has %d frames < %d kept", F, fpc);
@@ -1596,9 +1657,33 @@ extern "C" int rca_codec_decode_dev(rca_codec_t* h, const int64_t* codes, int32_
     if ((rc = decoder_workspace(h, B, F)) != RCA_OK) return rc;
     const int J = h->cfg.codebook_dim;
     float* zq = h->act[0].as<float>();
-    embed_codes_kernel<<<cdiv((long)B * J * F, 256), 256, 0, st>>>(codes, h->cb, zq, B, F, J, h->cfg.codebook_size, h->err_flag);
+    embed_codes_kernel<<<cdiv((long)B * J * F, 256), 256, 0, st>>>(codes, (long)F, h->cb, zq, B, F, J, h->cfg.codebook_size, h->err_flag);
     RCA_LAUNCH_CHECK();
     return run_decoder(h, zq, B, F, pcm, st);
+}
+
+extern "C" int rca_codec_decode_tail_dev(rca_codec_t* h, const int64_t* codes, int32_t B, int32_t F, int32_t n_samples, float* pcm,
+                                         void* stream) {
+    if (!h || !codes || !pcm || B < 1 || F < 1 || n_samples < 1) return fail(RCA_ERR_ARG, "decode_tail: bad argument (B=%d F=%d n=%d)", B, F, n_samples);
+    if ((long)n_samples > (long)F * h->hop) return fail(RCA_ERR_ARG, "decode_tail: %d samples wanted, %d codes give %ld", n_samples, F, (long)F * h->hop);
+    RCA_HIP(hipSetDevice(h->device));
+    hipStream_t st = pick_stream(h, stream);
+    // first frame any kept sample belongs to, minus what the decoder sees to its left
+    const int f0 = (int)(((long)F * h->hop - n_samples) / h->hop);
+    const int j = std::max(0, f0 - h->dec_left_frames);
+    const int Ft = F - j;
+    int rc;
+    if ((rc = decoder_workspace(h, B, Ft)) != RCA_OK) return rc;
+    const long Tt = (long)Ft * h->hop;
+    if ((rc = h->tail.ensure((size_t)B * Tt * 4)) != RCA_OK) return rc;
+    const int J = h->cfg.codebook_dim;
+    float* zq = h->act[0].as<float>();
+    embed_codes_kernel<<<cdiv((long)B * J * Ft, 256), 256, 0, st>>>(codes + j, (long)F, h->cb, zq, B, Ft, J, h->cfg.codebook_size, h->err_flag);
+    RCA_LAUNCH_CHECK();
+    if ((rc = run_decoder(h, zq, B, Ft, h->tail.as<float>(), st)) != RCA_OK) return rc;
+    RCA_HIP(hipMemcpy2DAsync(pcm, (size_t)n_samples * 4, h->tail.as<float>() + (Tt - n_samples), (size_t)Tt * 4, (size_t)n_samples * 4, B,
+                             hipMemcpyDeviceToDevice, st));
+    return RCA_OK;
 }
 
 extern "C" int rca_codec_decoder_dev(rca_codec_t* h, const float* zq_bfj, int32_t B, int32_t F, float* pcm, void* stream) {

@@ -167,3 +167,37 @@ def test_tokenizer_int16_and_stereo_downmix(tiny_oracle):
     assert len(d) == 5
     assert abs(tok.get_audio_codes_str_secs(a) - 0.1) < 1e-12
     assert len(tok.chunked_tokenize_audio(np.zeros(4800, np.float32), 0.1)) == 15
+
+
+# --------------------------------------------------------------------- receptive field
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_receptive_field_margins_hold_on_the_oracle(tag, tiny_oracle, full_oracle):
+    """The streaming tail rests on one claim about the codec DEFINITION: the last n codes of a window, and the last
+    n samples of a decode, do not depend on anything further left than CodecConfig.receptive_field() frames.
+    Checked on the CPU oracle itself: a window cut down to kept + margin frames gives the same codes / PCM bit for
+    bit, and one frame less of margin does not (the margin is tight for the decoder, whose output is not quantised)."""
+    oc = tiny_oracle if tag == "tiny" else full_oracle
+    enc_left, dec_left = oc.cfg.receptive_field()
+    hop = oc.cfg.hop
+    T = 6400 if tag == "full" else 16000
+    x = np.stack([rich_signal(T, 31), bench_signal(T, 32)])
+    full = oc.encode(x)
+    F = full.shape[1]
+    for keep in (1, 4, 5, 7):
+        j = max(0, F - keep - enc_left)
+        assert np.array_equal(oc.encode(x[:, j * hop:])[:, -keep:], full[:, -keep:]), keep
+    # ragged window (not a hop multiple: frames are counted from the window start, so whole frames are dropped)
+    xr = x[:, : T - 100]
+    fr = oc.encode(xr)
+    j = max(0, fr.shape[1] - 5 - enc_left)
+    assert np.array_equal(oc.encode(xr[:, j * hop:])[:, -5:], fr[:, -5:])
+    rng = np.random.default_rng(5)
+    codes = rng.integers(0, oc.cfg.codebook_size, (2, 20 if tag == "full" else 40))
+    pcm = oc.decode(codes)
+    Fd = codes.shape[1]
+    for n in (320, 1920, 1600, 1000):
+        f0 = (Fd * hop - n) // hop
+        j = max(0, f0 - dec_left)
+        assert np.array_equal(oc.decode(codes[:, j:])[:, -n:], pcm[:, -n:]), n
+        if j > 0 and n % hop == 0:   # tight when the first kept sample sits on a frame boundary
+            assert not np.array_equal(oc.decode(codes[:, j + 1:])[:, -n:], pcm[:, -n:]), f"decoder margin not tight for n={n}"

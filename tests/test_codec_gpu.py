@@ -164,3 +164,88 @@ def test_audio_tokenizer_streaming_on_gpu(full_codec, full_oracle):
     assert np.array_equal(rec.cpu().numpy()[:, 0], full_oracle.decode(idx.cpu().numpy()))
     emb = tok.get_codec_embeddings()
     assert np.array_equal(emb.cpu().numpy(), full_oracle.codebook())
+
+
+# --------------------------------------------------------------------- streaming tail / window trim
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_tail_entry_points_equal_full_window(tag, hip_tiny, hip_full, tiny_oracle, full_oracle):
+    """rca_codec_encode_tail_dev / rca_codec_decode_tail_dev return exactly the tail of the full-window calls (and of
+    the oracle), for frame-aligned and ragged windows, every keep count the agent uses and a few it does not."""
+    import torch
+    hip, oc = _pair(tag, hip_tiny, hip_full, tiny_oracle, full_oracle)
+    hip.set_variant(1)
+    assert hip.receptive_field() == oc.cfg.receptive_field()
+    st = torch.cuda.current_stream().cuda_stream
+    for T, B in ((32000, 2), (1600, 1), (3200, 3), (31900, 1), (960, 2)):
+        x = np.stack([rich_signal(T, 41 + b) for b in range(B)])
+        want = oc.encode(x) if (tag == "tiny" or T <= 3200) else hip.encode(x)
+        if tag == "full" and T > 3200:
+            assert np.array_equal(hip.encode(x[:, -6400:])[:, -5:], oc.encode(x[:, -6400:])[:, -5:])
+        dev = torch.from_numpy(x).cuda()
+        F = want.shape[1]
+        for keep in (1, 4, 5, min(F, 9), F):
+            if keep > F:
+                continue
+            out = torch.full((B, keep), -1, dtype=torch.int64, device="cuda")
+            hip.encode_tail_dev(dev.data_ptr(), B, T, keep, out.data_ptr(), st)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want[:, -keep:]), (T, B, keep)
+    rng = np.random.default_rng(2)
+    for F, B in ((100, 2), (6, 1), (3, 2), (1, 1)):
+        codes = rng.integers(0, oc.cfg.codebook_size, (B, F))
+        want = hip.decode(codes)
+        if F <= 6 or tag == "tiny":
+            assert np.array_equal(want, oc.decode(codes))
+        cdev = torch.from_numpy(codes).cuda()
+        for n in (1920, 1600, 1280 + 320, 320, 1000, F * 320):
+            if n > F * 320:
+                continue
+            out = torch.zeros((B, n), dtype=torch.float32, device="cuda")
+            hip.decode_tail_dev(cdev.data_ptr(), B, F, n, out.data_ptr(), st)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want[:, -n:]), (F, B, n)
+
+
+def test_window_trim_gives_identical_codes(hip_full, full_oracle):
+    """Batch windows with the trim switch on: same codes as the full 2 s windows (incl. the warm-up windows)."""
+    import torch
+    hip_full.set_variant(1)
+    audio = np.stack([bench_signal(64000, 1), rich_signal(64000, 2)])
+    dev = torch.from_numpy(audio).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    for chunk in (1600, 1280):
+        n_chunks = 64000 // chunk
+        fpc = hip_full.frames_per_chunk(chunk)
+        outs = []
+        for trim in (False, True):
+            hip_full.set_window_trim(trim)
+            out = torch.full((2, n_chunks * fpc), -1, dtype=torch.int64, device="cuda")
+            hip_full.encode_windows_dev(dev.data_ptr(), 2, 64000, chunk, 32000, 16, out.data_ptr(), n_chunks * fpc, st)
+            torch.cuda.synchronize()
+            outs.append(out.cpu().numpy())
+        hip_full.set_window_trim(False)
+        assert np.array_equal(outs[0], outs[1]), chunk
+        assert np.array_equal(outs[1], full_oracle.encode_windows(audio, chunk, 32000))
+
+
+def test_audio_tokenizer_streaming_tail_is_invisible(full_codec):
+    """AudioTokenizer with and without the streaming shortcut: identical code strings and identical audio, chunk by
+    chunk, mono and stereo, for both agent chunk sizes."""
+    from realtime_codec_agent_amd.audio_tokenizer import AudioTokenizer
+    from realtime_codec_agent_amd.codec import MagiCodecHIP
+    cfg, w = full_codec
+    model = MagiCodecHIP(cfg, w, device="cuda:0")
+    for channels, chunk in ((1, 1600), (1, 1280), (2, 1600)):
+        toks = [AudioTokenizer(codec_model=model, num_channels=channels, device="cuda:0") for _ in range(2)]
+        toks[0].streaming_tail, toks[1].streaming_tail = True, False
+        sig = np.stack([rich_signal(40000, 50 + c) for c in range(channels)])
+        sig = sig[0] if channels == 1 else sig
+        pre = [320, 320]
+        for i in range(0, 40000, chunk):
+            a = [t.tokenize_audio(sig[..., i:i + chunk]) for t in toks]
+            assert a[0] == a[1] and len(a[0]) == channels * (min(chunk, 40000 - i) // 320)
+            outs = []
+            for k, t in enumerate(toks):
+                (sr, pcm), hang, pre[k] = t.detokenize_audio(a[k], preroll_samples=pre[k])
+                outs.append(pcm)
+            assert outs[0].shape == outs[1].shape and np.array_equal(outs[0], outs[1]) and pre[0] == pre[1]
