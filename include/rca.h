@@ -129,6 +129,13 @@ int rca_codec_encode_tail_dev(rca_codec_t* h, const float* pcm_dev, int32_t B, i
  * audio_tokenizer.py:113,141-145).  codes [B,F] int64 (row stride F) -> pcm [B,n_samples] f32. */
 int rca_codec_decode_tail_dev(rca_codec_t* h, const int64_t* codes_dev, int32_t B, int32_t F, int32_t n_samples,
                               float* pcm_dev, void* stream);
+/* The same two calls with host buffers, as the streaming tokenizer makes them once per frame: H2D of the window,
+ * the tail kernels, D2H of the result, one synchronisation.  Shapes repeat frame after frame, so from the second
+ * call of a shape on the whole sequence replays as one hipGraph over pinned staging buffers
+ * (rca_codec_set_stream_graphs(h, 0) switches the replay off).  Error behaviour as rca_codec_encode / _decode. */
+int rca_codec_encode_tail(rca_codec_t* h, const float* pcm_host, int32_t B, int32_t T, int32_t n_keep, int64_t* codes_host);
+int rca_codec_decode_tail(rca_codec_t* h, const int64_t* codes_host, int32_t B, int32_t F, int32_t n_samples, float* pcm_host);
+int rca_codec_set_stream_graphs(rca_codec_t* h, int32_t enable);
 /* whole frames a kept code / a kept sample can see to its left */
 int rca_codec_receptive_field(const rca_codec_t* h, int32_t* enc_left_frames, int32_t* dec_left_frames);
 /* Batch windows (rca_codec_encode_windows_dev / _chunk_range_dev): when enabled, each window is cut down to the

@@ -104,20 +104,20 @@ class AudioTokenizer:
         self.tokenize_context = np.concatenate((self.tokenize_context, audio.reshape(self.num_channels, -1)), axis=-1)
         self.tokenize_context = self.tokenize_context[..., -max(audio.shape[-1], self.context_samples):]
 
-        input_audio = torch.from_numpy(np.ascontiguousarray(self.tokenize_context)).to(self.device)
         audio_secs = audio.shape[-1] / self.sampling_rate
         audio_frames = int(audio_secs * self.framerate * self.num_channels)
         # every channel is one row of a single batched launch (the reference loops channels, :84)
-        if self.streaming_tail and audio_frames > 0 and hasattr(self.codec_model, "encode_tail"):
+        if self.streaming_tail and audio_frames > 0 and hasattr(self.codec_model, "encode_tail_np"):
             # only the last audio_frames characters survive below: ask the codec for exactly those frames.  Same
-            # codes, bit for bit; the encoder runs over their receptive field instead of the whole window.
-            encoder_outputs = self.codec_model.encode_tail(input_audio, -(-audio_frames // self.num_channels)).unsqueeze(1)
+            # codes, bit for bit; the encoder runs over their receptive field instead of the whole window, and the
+            # call (copies included) replays as one captured graph.
+            n_keep = -(-audio_frames // self.num_channels)
+            encoder_outputs = self.codec_model.encode_tail_np(np.ascontiguousarray(self.tokenize_context), n_keep)[:, None, :]
         else:
-            encoder_outputs = self._magicodec_encode(input_audio)  # [C, 1, F]
+            input_audio = torch.from_numpy(np.ascontiguousarray(self.tokenize_context)).to(self.device)
+            encoder_outputs = self._magicodec_encode(input_audio).cpu().numpy()  # [C, 1, F]
 
-        channels_chars = [
-            codes_to_chars(ch_codes, self.codebook_size, unicode_offset=self.unicode_offset) for ch_codes in encoder_outputs.cpu().numpy()
-        ]
+        channels_chars = [codes_to_chars(ch_codes, self.codebook_size, unicode_offset=self.unicode_offset) for ch_codes in encoder_outputs]
         audio_codes_str = "".join(list(itertools.chain.from_iterable(zip(*channels_chars))))
 
         # discard context codes that come before the audio we are tokenizing (reference :98-101)
@@ -132,26 +132,31 @@ class AudioTokenizer:
         self.detokenize_context = self.detokenize_context[-max(len(audio_codes_str), self.context_frames):]
 
         input_audio_codes_str = [self.detokenize_context[i::self.num_channels] for i in range(self.num_channels)]
-        input_audio_codes = [
-            chars_to_codes(ch_chars, self.num_codebooks, self.codebook_size, return_tensors="pt", unicode_offset=self.unicode_offset)
-            for ch_chars in input_audio_codes_str
-        ]
-        input_audio_codes = torch.stack(input_audio_codes).to(self.device)  # [C, 1, F]
 
         # discard context audio that comes before the codes we are detokenizing (reference :141-145)
         audio_secs = self.get_audio_codes_str_secs(audio_codes_str)
         audio_samples = int(audio_secs * self.sampling_rate) + preroll_samples
-        if self.streaming_tail and audio_samples > 0 and hasattr(self.codec_model, "decode_tail"):
+        if self.streaming_tail and audio_samples > 0 and len(input_audio_codes_str[0]) > 0 and hasattr(self.codec_model, "decode_tail_np"):
             # the same samples, bit for bit, decoded from the codes they depend on instead of the whole context
-            output_audio = self.codec_model.decode_tail(input_audio_codes.squeeze(1), audio_samples).float()
+            codes_np = np.stack([
+                chars_to_codes(ch_chars, self.num_codebooks, self.codebook_size, unicode_offset=self.unicode_offset)[0]
+                for ch_chars in input_audio_codes_str
+            ])  # [C, F]
+            output_audio = self.codec_model.decode_tail_np(codes_np, audio_samples)[None]  # [1, C, n]
         else:
+            input_audio_codes = [
+                chars_to_codes(ch_chars, self.num_codebooks, self.codebook_size, return_tensors="pt", unicode_offset=self.unicode_offset)
+                for ch_chars in input_audio_codes_str
+            ]
+            input_audio_codes = torch.stack(input_audio_codes).to(self.device)  # [C, 1, F]
             output_audio = self._magicodec_decode(input_audio_codes)  # [C, 1, T]
-        output_audio = output_audio.transpose(0, 1)  # [1, C, T] == cat(dim=1) of the per-channel [1,1,T] (reference :136-139)
+            # [1, C, T] == cat(dim=1) of the per-channel [1,1,T] (reference :136-139)
+            output_audio = output_audio.transpose(0, 1).cpu().numpy()
         output_audio = output_audio[..., -audio_samples:]
         preroll_samples = max(0, preroll_samples - audio_samples + output_audio.shape[-1])
 
         output_audio = output_audio[0, 0] if self.num_channels == 1 else output_audio[0]
-        return (self.sampling_rate, output_audio.cpu().numpy()), end_hanging, preroll_samples
+        return (self.sampling_rate, output_audio), end_hanging, preroll_samples
 
     @torch.inference_mode()
     def get_codec_embeddings(self) -> torch.Tensor:

@@ -70,6 +70,33 @@ class HipCodec:
         N.check(self._lib.rca_codec_decode(self._h, C.c_void_p(codes.ctypes.data), B, F, C.c_void_p(pcm.ctypes.data)), "rca_codec_decode")
         return pcm
 
+    def encode_tail(self, pcm: np.ndarray, n_keep: int) -> np.ndarray:
+        """Last n_keep codes of encode(pcm), host buffers, graph-replayed per shape (rca_codec_encode_tail)."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        if pcm.ndim != 2:
+            raise ValueError("pcm must be [B,T]")
+        B, T = pcm.shape
+        n_keep = min(int(n_keep), self.num_frames(T))
+        codes = np.empty((B, n_keep), np.int64)
+        N.check(self._lib.rca_codec_encode_tail(self._h, C.c_void_p(pcm.ctypes.data), B, T, n_keep, C.c_void_p(codes.ctypes.data)),
+                "rca_codec_encode_tail")
+        return codes
+
+    def decode_tail(self, codes: np.ndarray, n_samples: int) -> np.ndarray:
+        """Last n_samples of decode(codes), host buffers, graph-replayed per shape (rca_codec_decode_tail)."""
+        codes = np.ascontiguousarray(codes, dtype=np.int64)
+        if codes.ndim != 2:
+            raise ValueError("codes must be [B,F]")
+        B, F = codes.shape
+        n = min(int(n_samples), F * self.hop)
+        pcm = np.empty((B, n), np.float32)
+        N.check(self._lib.rca_codec_decode_tail(self._h, C.c_void_p(codes.ctypes.data), B, F, n, C.c_void_p(pcm.ctypes.data)),
+                "rca_codec_decode_tail")
+        return pcm
+
+    def set_stream_graphs(self, enable: bool) -> None:
+        N.check(self._lib.rca_codec_set_stream_graphs(self._h, int(bool(enable))), "rca_codec_set_stream_graphs")
+
     def codebook(self) -> np.ndarray:
         out = np.empty((self.cfg.codebook_size, self.cfg.codebook_dim), np.float32)
         N.check(self._lib.rca_codec_codebook(self._h, C.c_void_p(out.ctypes.data)), "rca_codec_codebook")
@@ -292,6 +319,14 @@ class MagiCodecHIP:
         codes = torch.empty((B, n_keep), dtype=torch.int64, device=x.device)
         self.hip.encode_tail_dev(x.data_ptr(), B, T, n_keep, codes.data_ptr(), _stream_of(x))
         return codes
+
+    def encode_tail_np(self, x: np.ndarray, n_keep: int) -> np.ndarray:
+        """encode_tail on host arrays, no torch in the loop: what AudioTokenizer calls once per frame."""
+        return self.hip.encode_tail(x, n_keep)
+
+    def decode_tail_np(self, codes: np.ndarray, n_samples: int) -> np.ndarray:
+        """decode_tail on host arrays: [B,F] int64 -> [B,min(n_samples, F*hop)] f32."""
+        return self.hip.decode_tail(codes, n_samples)
 
     def decode_tail(self, codes, n_samples: int):
         """The last n_samples of decode_codes(codes), bit-identical (audio_tokenizer.py:141-145).

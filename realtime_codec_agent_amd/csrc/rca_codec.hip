@@ -15,7 +15,9 @@
 #include <stdarg.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
+#include <map>
 
 #include "rca_common.h"
 
@@ -963,6 +965,11 @@ struct rca_codec {
     float *q_in_w = nullptr, *q_in_b = nullptr;
     float *cb = nullptr, *hc = nullptr, *cbp = nullptr;
     DevBuf act[2], zbuf, keys, io_a, io_b, tail;
+    // streaming host calls: pinned staging + one captured graph per call shape (see rca_codec_encode_tail)
+    void* pin = nullptr; size_t pin_cap = 0;
+    struct StreamGraph { hipGraphExec_t exec = nullptr; int seen = 0; unsigned long long sig = 0; };
+    std::map<std::array<int, 5>, StreamGraph> sgraphs;
+    bool stream_graphs = true;
     int* err_flag = nullptr;
     hipStream_t last_stream = nullptr;
     bool last_stream_valid = false;
@@ -1086,6 +1093,9 @@ extern "C" int rca_codec_destroy(rca_codec_t* h) {
     for (float* p : {h->q_in_w, h->q_in_b, h->cb, h->hc, h->cbp})
         if (p) (void)hipFree(p);
     if (h->err_flag) (void)hipFree(h->err_flag);
+    for (auto& kv : h->sgraphs)
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    if (h->pin) (void)hipHostFree(h->pin);
     h->act[0].release(); h->act[1].release(); h->zbuf.release(); h->keys.release(); h->io_a.release(); h->io_b.release(); h->tail.release();
     for (auto* v : {&h->prof, &h->prof_pool})
         for (auto& p : *v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -1683,6 +1693,100 @@ extern "C" int rca_codec_decode_tail_dev(rca_codec_t* h, const int64_t* codes, i
     if ((rc = run_decoder(h, zq, B, Ft, h->tail.as<float>(), st)) != RCA_OK) return rc;
     RCA_HIP(hipMemcpy2DAsync(pcm, (size_t)n_samples * 4, h->tail.as<float>() + (Tt - n_samples), (size_t)Tt * 4, (size_t)n_samples * 4, B,
                              hipMemcpyDeviceToDevice, st));
+    return RCA_OK;
+}
+
+// ---- streaming host calls.  One duplex frame makes one encode-tail and one decode-tail call of the same shape as
+// the frame before: H2D of the window, ~10 short kernels, D2H of the tail, one sync.  From the second call of a
+// shape on, the whole sequence (copies included) is a hipGraph over pinned staging buffers.  A captured graph holds
+// workspace pointers, so it is keyed by a signature of them and re-captured when any buffer has been reallocated.
+static unsigned long long workspace_signature(const rca_codec* h) {
+    unsigned long long sig = 1469598103934665603ull;
+    for (const void* p : {h->act[0].p, h->act[1].p, h->zbuf.p, h->keys.p, h->io_a.p, h->io_b.p, h->tail.p, (void*)h->pin}) {
+        sig ^= (unsigned long long)(uintptr_t)p;
+        sig *= 1099511628211ull;
+    }
+    return sig;
+}
+static int ensure_pinned(rca_codec* h, size_t bytes) {
+    if (bytes <= h->pin_cap) return RCA_OK;
+    if (h->pin) (void)hipHostFree(h->pin);
+    h->pin = nullptr; h->pin_cap = 0;
+    RCA_HIP(hipHostMalloc(&h->pin, bytes + (bytes >> 2), hipHostMallocDefault));
+    h->pin_cap = bytes + (bytes >> 2);
+    return RCA_OK;
+}
+// kind 0: encode tail (a=T, b=n_keep), kind 1: decode tail (a=F, b=n_samples).  Pinned layout: [input | output | err].
+static int stream_call(rca_codec* h, int kind, int B, int a, int b, const void* in_host, size_t in_bytes, void* out_host, size_t out_bytes) {
+    RCA_HIP(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    int rc;
+    const size_t in_pad = (in_bytes + 255) & ~(size_t)255, out_pad = (out_bytes + 255) & ~(size_t)255;
+    if ((rc = ensure_pinned(h, in_pad + out_pad + 256)) != RCA_OK) return rc;
+    if ((rc = h->io_a.ensure(in_pad)) != RCA_OK) return rc;
+    if ((rc = h->io_b.ensure(out_pad)) != RCA_OK) return rc;
+    char* pin = (char*)h->pin;
+    int* perr = (int*)(pin + in_pad + out_pad);
+    memcpy(pin, in_host, in_bytes);
+    auto enqueue = [&]() -> int {
+        hipError_t e = hipMemcpyAsync(h->io_a.p, pin, in_bytes, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return fail(RCA_ERR_HIP, "stream h2d: %s", hipGetErrorString(e));
+        int r = kind == 0 ? rca_codec_encode_tail_dev(h, h->io_a.as<float>(), B, a, b, h->io_b.as<int64_t>(), st)
+                          : rca_codec_decode_tail_dev(h, h->io_a.as<int64_t>(), B, a, b, h->io_b.as<float>(), st);
+        if (r != RCA_OK) return r;
+        e = hipMemcpyAsync(pin + in_pad, h->io_b.p, out_bytes, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(perr, h->err_flag, 4, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) return fail(RCA_ERR_HIP, "stream d2h: %s", hipGetErrorString(e));
+        return RCA_OK;
+    };
+    (void)pick_stream(h, st);
+    rca_codec::StreamGraph& g = h->sgraphs[{kind, B, a, b, h->variant}];
+    const bool want_graph = h->stream_graphs && !h->profile && g.seen >= 1;
+    if (want_graph && g.exec && g.sig != workspace_signature(h)) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+    if (want_graph && !g.exec) {
+        // the eager call before this one sized every workspace buffer for this shape: nothing allocates under capture
+        hipGraph_t graph = nullptr;
+        RCA_HIP(hipStreamSynchronize(st));
+        RCA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        rc = enqueue();
+        hipError_t e = hipStreamEndCapture(st, &graph);
+        if (rc != RCA_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess) return fail(RCA_ERR_HIP, "stream capture: %s", hipGetErrorString(e));
+        e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { g.exec = nullptr; return fail(RCA_ERR_HIP, "stream graph instantiate: %s", hipGetErrorString(e)); }
+        g.sig = workspace_signature(h);
+    }
+    if (want_graph) {
+        RCA_HIP(hipGraphLaunch(g.exec, st));
+    } else if ((rc = enqueue()) != RCA_OK) {
+        return rc;
+    }
+    ++g.seen;
+    RCA_HIP(hipStreamSynchronize(st));
+    if (*perr) {
+        RCA_HIP(hipMemsetAsync(h->err_flag, 0, 4, st));
+        return fail(RCA_ERR_ARG, "decode: code out of range [0, %d)", h->cfg.codebook_size);
+    }
+    memcpy(out_host, pin + in_pad, out_bytes);
+    return RCA_OK;
+}
+
+extern "C" int rca_codec_encode_tail(rca_codec_t* h, const float* pcm_host, int32_t B, int32_t T, int32_t n_keep, int64_t* codes_host) {
+    if (!h || !pcm_host || !codes_host || B < 1 || T < 1 || n_keep < 1) return fail(RCA_ERR_ARG, "encode_tail: bad argument (B=%d T=%d keep=%d)", B, T, n_keep);
+    if (n_keep > (T + h->hop - 1) / h->hop) return fail(RCA_ERR_ARG, "encode_tail: %d frames wanted, the window holds %d", n_keep, (T + h->hop - 1) / h->hop);
+    return stream_call(h, 0, B, T, n_keep, pcm_host, (size_t)B * T * 4, codes_host, (size_t)B * n_keep * 8);
+}
+
+extern "C" int rca_codec_decode_tail(rca_codec_t* h, const int64_t* codes_host, int32_t B, int32_t F, int32_t n_samples, float* pcm_host) {
+    if (!h || !codes_host || !pcm_host || B < 1 || F < 1 || n_samples < 1) return fail(RCA_ERR_ARG, "decode_tail: bad argument (B=%d F=%d n=%d)", B, F, n_samples);
+    if ((long)n_samples > (long)F * h->hop) return fail(RCA_ERR_ARG, "decode_tail: %d samples wanted, %d codes give %ld", n_samples, F, (long)F * h->hop);
+    return stream_call(h, 1, B, F, n_samples, codes_host, (size_t)B * F * 8, pcm_host, (size_t)B * n_samples * 4);
+}
+
+extern "C" int rca_codec_set_stream_graphs(rca_codec_t* h, int32_t enable) {
+    if (!h) return fail(RCA_ERR_ARG, "null");
+    h->stream_graphs = enable != 0;
     return RCA_OK;
 }
 

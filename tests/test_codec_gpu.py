@@ -249,3 +249,30 @@ def test_audio_tokenizer_streaming_tail_is_invisible(full_codec):
                 (sr, pcm), hang, pre[k] = t.detokenize_audio(a[k], preroll_samples=pre[k])
                 outs.append(pcm)
             assert outs[0].shape == outs[1].shape and np.array_equal(outs[0], outs[1]) and pre[0] == pre[1]
+
+
+def test_host_tail_calls_replay_as_graphs_and_survive_reallocation(hip_full, full_oracle):
+    """rca_codec_encode_tail / rca_codec_decode_tail (host buffers): the first call of a shape runs eagerly, later ones
+    replay a captured graph -- every call must equal the full-window result on fresh data.  A larger call in between
+    reallocates the workspace the graph points into: the graph has to be re-captured, not replayed."""
+    hip_full.set_variant(1)
+    rng = np.random.default_rng(11)
+    for rep in range(5):
+        x = np.stack([rich_signal(32000, 70 + rep)])
+        want = hip_full.encode(x)[:, -4:]
+        assert np.array_equal(hip_full.encode_tail(x, 4), want), rep
+        codes = rng.integers(0, 131072, (1, 100))
+        assert np.array_equal(hip_full.decode_tail(codes, 1600), hip_full.decode(codes)[:, -1600:]), rep
+        if rep == 2:   # grow every workspace buffer
+            big = np.stack([rich_signal(64000, 90 + b) for b in range(8)])
+            assert hip_full.encode(big).shape == (8, 200)
+            assert hip_full.decode(rng.integers(0, 131072, (4, 300))).shape == (4, 96000)
+    x = np.stack([rich_signal(32000, 99)])
+    assert np.array_equal(hip_full.encode_tail(x[:, :6400], 5), full_oracle.encode(x[:, :6400])[:, -5:])
+    hip_full.set_stream_graphs(False)
+    assert np.array_equal(hip_full.encode_tail(x, 4), hip_full.encode(x)[:, -4:])
+    hip_full.set_stream_graphs(True)
+    from realtime_codec_agent_amd._native import RcaError
+    with pytest.raises(RcaError):
+        hip_full.decode_tail(np.array([[0, 131072, 5]]), 320)
+    assert hip_full.decode_tail(np.array([[0, 1, 5]]), 320).shape == (1, 320)
