@@ -33,6 +33,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   src + (r % C) * chan_stride + (r / C) * win_stride,  T valid samples (zero beyond).
 // Plain encode: C = B, chan_stride = T, win_stride = 0.  Window mode (batch encode): rows are
 // (window, channel) pairs cut out of a long [C][N] signal on the fly -- no window copy in HBM.
+#define RCA_LAT_MAX_FRAMES 64   // streaming tail calls of at most this many (row x frame) pairs run on the latency kernels
+#define RCA_LDS_BUDGET (152 * 1024)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 struct RowSrc {
     const float* base;
     int C;
@@ -682,6 +687,222 @@ __global__ __launch_bounds__(512) void conv1d_ws_kernel(const float* __restrict_
 
 // ------------------------------------------------------------------------------- quantizer pieces
 // z[row][j] = b[j] + sum_d w[j][d] * ze[b][d][f]   for rows (b, f in [f0, f0+fc)); row = b*fc + (f-f0)
+// ------------------------------------------------------------------ latency-oriented kernels (streaming tail)
+// A streaming tail call is a handful of columns with reduction chains up to 4096 long whose order is fixed (bias
+// first, channel-major, tap-minor: the oracle's order).  On the MFMA path every pair of k-steps is one 64-cycle
+// instruction and every chunk of channels a round trip to HBM; as a scalar chain a step is one dependent v_fma
+// (~8 cycles).  These kernels take everything else off that chain.  The workgroup first pulls its whole input tile
+// (zero-filled outside the signal, LeakyReLU already applied) and the weight rows of its NW output channels into LDS
+// with every load in flight at once; then each wave (one output channel x up to 64 columns) walks its chain:
+//   x  from a sample-major tile xs[j][CP] (CP = Cin + 4): one 16-byte read fetches 4 channels of one tap, whatever
+//      the stride / alignment of the layer, double-buffered one channel group ahead;
+//   w  wave-uniform: one coalesced read puts the 4*K weights of a channel group in 4*K lanes, each step takes its
+//      weight with v_readlane into an SGPR operand -- no LDS traffic per step.
+template <int K, int S, int NW>
+__global__ __launch_bounds__(64 * NW) void conv1d_lds_kernel(const float* __restrict__ x, long x_batch_stride, int Lvalid,
+                                                             const float* __restrict__ w, const float* __restrict__ bias,
+                                                             float* __restrict__ y, int Cin, int Lin, int Cout, int Lout, int NC, int W,
+                                                             float slope, int pre, int clamp_out) {
+    extern __shared__ __attribute__((aligned(16))) float lds_sm[];
+    const int CP = Cin + 4;
+    float* xs = lds_sm;                   // [W][CP]
+    float* ws = lds_sm + (long)W * CP;    // [NW][Cin*K], natural order
+    constexpr int padL = (K - S + 1) / 2;
+    constexpr int NT = 64 * NW;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col0 = blockIdx.x * NC;
+    const int co0 = blockIdx.y * NW;
+    const int b = blockIdx.z;
+    // the tile starts on a multiple of 4 samples at or before the first tap, so whole 16-byte groups are in or out
+    const int i_first = col0 * S - padL;
+    const int i_base = i_first & ~3;
+    const int d0 = i_first - i_base;       // 0..3: where column 0's first tap sits in the tile
+    const float* xb = x + (long)b * x_batch_stride;
+    if ((Lin & 3) == 0 && Lvalid == Lin && (x_batch_stride & 3) == 0 && (Cin & 3) == 0) {
+        // one thread = 4 channels x 4 samples: four 16-byte loads, transposed in registers, four 16-byte LDS stores;
+        // consecutive threads take consecutive channel groups, so a wave's stores are one contiguous run per row
+        const int W4 = W >> 2, C4 = Cin >> 2;      // Cin % 4 == 0 on this path
+        const int nblk = W4 * C4;
+#pragma unroll 4
+        for (int e = tid; e < nblk; e += NT) {
+            const int jg = e / C4, cg = e - jg * C4;
+            const int j = jg << 2, ci = cg << 2;
+            const int i = i_base + j;
+            f32x4 v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                v[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (i >= 0 && i < Lin) v[c] = *reinterpret_cast<const f32x4*>(xb + (long)(ci + c) * Lin + i);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 o = {v[0][q], v[1][q], v[2][q], v[3][q]};
+                if (pre) { o[0] = lrelu(o[0], slope); o[1] = lrelu(o[1], slope); o[2] = lrelu(o[2], slope); o[3] = lrelu(o[3], slope); }
+                *reinterpret_cast<f32x4*>(xs + (long)(j + q) * CP + ci) = o;
+            }
+        }
+    } else {
+        const int nx = Cin * W;
+        if (Cin >= 64) {
+#pragma unroll 8
+            for (int e = tid; e < nx; e += NT) {   // short rows (a few frames): consecutive threads -> consecutive channels
+                const int j = e / Cin, ci = e - j * Cin;
+                const int i = i_base + j;
+                float v = (i >= 0 && i < Lvalid) ? xb[(long)ci * Lin + i] : 0.0f;
+                if (pre) v = lrelu(v, slope);
+                xs[j * CP + ci] = v;
+            }
+        } else {
+#pragma unroll 8
+            for (int e = tid; e < nx; e += NT) {   // consecutive threads -> consecutive samples of one channel (coalesced)
+                const int ci = e / W, j = e - ci * W;
+                const int i = i_base + j;
+                float v = (i >= 0 && i < Lvalid) ? xb[(long)ci * Lin + i] : 0.0f;
+                if (pre) v = lrelu(v, slope);
+                xs[j * CP + ci] = v;
+            }
+        }
+    }
+    const int nwe = Cin * K;
+    if ((nwe & 3) == 0) {
+        const int nw4 = nwe >> 2;
+#pragma unroll 16
+        for (int e = tid; e < NW * nw4; e += NT) {
+            const int wv = e / nw4, q = e - wv * nw4;
+            const int co = min(co0 + wv, Cout - 1);
+            reinterpret_cast<float4*>(ws)[e] = reinterpret_cast<const float4*>(w + (long)co * nwe)[q];
+        }
+    } else {
+        for (int e = tid; e < NW * nwe; e += NT) {
+            const int wv = e / nwe, r = e - wv * nwe;
+            ws[e] = w[(long)min(co0 + wv, Cout - 1) * nwe + r];
+        }
+    }
+    __syncthreads();
+    const int co = co0 + wave;
+    if (co >= Cout) return;
+    const int col = col0 + lane;
+    const bool valid = lane < NC && col < Lout;
+    const float* xl = xs + (long)((valid ? lane * S : 0) + d0) * CP;
+    const float* wl = ws + (long)wave * nwe;
+    float acc = bias[co];
+    if ((Cin & 7) != 0) {   // conv_in (Cin = 1): a chain of K steps
+        for (int ci = 0; ci < Cin; ++ci)
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk) acc = __builtin_fmaf(wl[ci * K + kk], xl[kk * CP + ci], acc);
+    } else {
+        constexpr int G = 4;
+        f32x4 xa[K], xb2[K];
+        float wa, wb;
+        auto ld = [&](f32x4(&xq)[K], float& wr, int ci) {
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk) xq[kk] = *reinterpret_cast<const f32x4*>(xl + kk * CP + ci);
+            wr = wl[ci * K + min(lane, G * K - 1)];
+        };
+        // the weight of step n+2 is broadcast (v_readlane -> SGPR) in the shadow of the dependent fma of step n; the
+        // scheduling barriers keep that interleave (left alone the compiler batches all broadcasts before the chain)
+        auto chain = [&](const f32x4(&xq)[K], float wr) {
+            const int wi = __builtin_bit_cast(int, wr);
+            float wq[G * K];
+            wq[0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(wi, 0));
+            wq[1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(wi, 1));
+#pragma unroll
+            for (int n = 0; n < G * K; ++n) {
+                if (n + 2 < G * K) wq[n + 2] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(wi, n + 2));
+                acc = __builtin_fmaf(wq[n], xq[n % K][n / K], acc);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        ld(xa, wa, 0);
+        for (int ci = 0; ci < Cin; ci += 2 * G) {
+            ld(xb2, wb, ci + G);
+            chain(xa, wa);
+            if (ci + 2 * G < Cin) ld(xa, wa, ci + 2 * G);
+            chain(xb2, wb);
+        }
+    }
+    if (clamp_out) acc = acc > 1.0f ? 1.0f : (acc < -1.0f ? -1.0f : acc);
+    if (valid) y[((long)b * Cout + co) * Lout + col] = acc;
+}
+
+// ConvTranspose1d (k = 2S): output u takes taps kk0 = (u + padL) % S (input t0) and kk0 + S (input t0 - 1), in that
+// order.  Both the frames and the taps a lane needs depend on u, so weights are read from a tap-major tile
+// ws[kk][CP] like the input: four 16-byte reads per four channels (eight steps).
+template <int S, int NW>
+__global__ __launch_bounds__(64 * NW) void convtr1d_lds_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ y, int Cin,
+                                                               int Lin, int Cout, int NC, int NTI, float slope, int pre) {
+    extern __shared__ __attribute__((aligned(16))) float lds_sm[];
+    constexpr int K = 2 * S;
+    constexpr int padL = (K - S + 1) / 2;
+    constexpr int NT = 64 * NW;
+    const int CP = Cin + 4;
+    float* xs = lds_sm;                      // [NTI][CP] input frames t_base .. t_base + NTI - 1
+    float* ws = lds_sm + (long)NTI * CP;     // [NW][K][CP]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Lout = Lin * S;
+    const int u0 = blockIdx.x * NC;
+    const int co0 = blockIdx.y * NW;
+    const int b = blockIdx.z;
+    const int t_base = (u0 + padL) / S - 1;
+    const float* xb = x + (long)b * Cin * Lin;
+    const int nx = Cin * NTI;
+#pragma unroll 8
+    for (int e = tid; e < nx; e += NT) {   // consecutive threads -> consecutive channels: conflict-free LDS stores
+        const int j = e / Cin, ci = e - j * Cin;
+        const int t = t_base + j;
+        float v = (t >= 0 && t < Lin) ? xb[(long)ci * Lin + t] : 0.0f;
+        if (pre) v = lrelu(v, slope);
+        xs[j * CP + ci] = v;
+    }
+    const int nwe = Cin * K;
+    constexpr int VW = (K % 4 == 0) ? 4 : 2;      // the K = 2S taps of one (ci, co) are contiguous: 16- or 8-byte loads
+    constexpr int KV = K / VW;
+    typedef float fvw __attribute__((ext_vector_type(VW)));
+    const int nwv = Cin * KV;
+#pragma unroll 8
+    for (int e = tid; e < NW * nwv; e += NT) {   // consecutive threads -> consecutive channels of one tap group
+        const int wv = e / nwv, r = e - wv * nwv;
+        const int kq = (r / Cin) * VW, ci = r - (r / Cin) * Cin;
+        const int co = min(co0 + wv, Cout - 1);
+        const fvw v = *reinterpret_cast<const fvw*>(w + ((long)ci * Cout + co) * K + kq);
+#pragma unroll
+        for (int q = 0; q < VW; ++q) ws[((long)wv * K + kq + q) * CP + ci] = v[q];
+    }
+    __syncthreads();
+    const int co = co0 + wave;
+    if (co >= Cout) return;
+    const int u = u0 + lane;
+    const bool valid = lane < NC && u < Lout;
+    const int uc = valid ? u : u0;
+    const int kk0 = (uc + padL) % S;
+    const int j0 = (uc + padL - kk0) / S - t_base;   // >= 1
+    const float* x0 = xs + (long)j0 * CP;
+    const float* x1 = x0 - CP;
+    const float* w0 = ws + ((long)wave * K + kk0) * CP;
+    const float* w1 = w0 + (long)S * CP;
+    float acc = bias[co];
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(x0), a1 = *reinterpret_cast<const f32x4*>(x1);
+    f32x4 b0 = *reinterpret_cast<const f32x4*>(w0), b1 = *reinterpret_cast<const f32x4*>(w1);
+    for (int ci = 0; ci < Cin; ci += 4) {
+        const f32x4 ca0 = a0, ca1 = a1, cb0 = b0, cb1 = b1;
+        if (ci + 4 < Cin) {
+            a0 = *reinterpret_cast<const f32x4*>(x0 + ci + 4); a1 = *reinterpret_cast<const f32x4*>(x1 + ci + 4);
+            b0 = *reinterpret_cast<const f32x4*>(w0 + ci + 4); b1 = *reinterpret_cast<const f32x4*>(w1 + ci + 4);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            acc = __builtin_fmaf(cb0[g], ca0[g], acc);
+            acc = __builtin_fmaf(cb1[g], ca1[g], acc);
+        }
+    }
+    if (valid) y[((long)b * Cout + co) * Lout + u] = acc;
+}
+
 __global__ __launch_bounds__(256) void in_proj_kernel(const float* __restrict__ ze, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ z, int B,
                                                       int D, int F, int f0, int fc, int J, int ze_is_rows) {
@@ -697,7 +918,15 @@ __global__ __launch_bounds__(256) void in_proj_kernel(const float* __restrict__ 
         for (int d = 0; d < D; ++d) acc = __builtin_fmaf(w[j * D + d], zr[d], acc);
     } else {  // encoder-native [B][D][F]
         const float* zr = ze + (long)b * D * F + f;
-        for (int d = 0; d < D; ++d) acc = __builtin_fmaf(w[j * D + d], zr[(long)d * F], acc);
+        int d = 0;
+        for (; d + 16 <= D; d += 16) {   // 16 strided loads in flight per step of the chain
+            float zv[16], wv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { zv[i] = zr[(long)(d + i) * F]; wv[i] = w[j * D + d + i]; }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc = __builtin_fmaf(wv[i], zv[i], acc);
+        }
+        for (; d < D; ++d) acc = __builtin_fmaf(w[j * D + d], zr[(long)d * F], acc);
     }
     z[idx] = acc;
 }
@@ -958,6 +1187,7 @@ struct rca_codec {
     hipStream_t stream = nullptr;
     int hop = 1;
     int variant = 1;
+    bool lat_mode = false;      // streaming tail: LDS-staged scalar-chain kernels (set per call)
     // receptive-field margins (whole frames) left of a kept frame / sample, derived from the layer geometry
     int enc_left_frames = 0, dec_left_frames = 0;
     bool window_trim = false;   // batch windows: encode only what the kept frames can see (same codes)
@@ -1297,8 +1527,64 @@ static bool try_conv_ws(const ConvLayer& L, const float* x, float* y, int B, int
     return true;
 }
 
+// Streaming tail: launch the LDS-staged chain kernel for one layer.  Returns false when the shape is not covered.
+template <int K, int S, int NW>
+static void launch_conv_lds(const ConvLayer& L, const float* x, long xbs, int Lvalid, float* y, int B, int Lin, int Lout, int NC, int W, int pre,
+                            float slope, int clamp_out, hipStream_t st) {
+    const size_t lds = ((size_t)W * (L.cin + 4) + (size_t)NW * L.cin * K) * 4;
+    auto kern = conv1d_lds_kernel<K, S, NW>;
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, RCA_LDS_BUDGET); attr_done = true; }
+    dim3 grid(cdiv(Lout, NC), cdiv(L.cout, NW), B);
+    kern<<<grid, 64 * NW, lds, st>>>(x, xbs, Lvalid, L.w, L.b, y, L.cin, Lin, L.cout, Lout, NC, W, slope, pre, clamp_out);
+}
+template <int S, int NW>
+static void launch_convtr_lds(const ConvLayer& L, const float* x, float* y, int B, int Lin, int NC, int NTI, float slope, hipStream_t st) {
+    const size_t lds = ((size_t)NTI * (L.cin + 4) + (size_t)NW * 2 * S * (L.cin + 4)) * 4;
+    auto kern = convtr1d_lds_kernel<S, NW>;
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, RCA_LDS_BUDGET); attr_done = true; }
+    dim3 grid(cdiv((long)Lin * S, NC), cdiv(L.cout, NW), B);
+    kern<<<grid, 64 * NW, lds, st>>>(x, L.w, L.b, y, L.cin, Lin, L.cout, NC, NTI, slope, L.pre);
+}
+static bool try_conv_lds(rca_codec* h, const ConvLayer& L, const float* x, long xbs, int Lvalid, float* y, int B, int Lin, int clamp_out, hipStream_t st) {
+    const float slope = h->cfg.leaky_slope;
+    if (L.tr) {
+        if (L.k != 2 * L.s) return false;
+        const int Lout = Lin * L.s;
+        const int NC = std::min(64, Lout);
+        const int NTI = NC / L.s + 3;
+        if (L.cin % 4 != 0) return false;
+        auto fits = [&](int nw) { return ((size_t)NTI * (L.cin + 4) + (size_t)nw * L.k * (L.cin + 4)) * 4 <= RCA_LDS_BUDGET; };
+#define RCA_TR(SS) if (L.s == SS) { if (fits(4)) launch_convtr_lds<SS, 4>(L, x, y, B, Lin, NC, NTI, slope, st); \
+                                   else if (fits(2)) launch_convtr_lds<SS, 2>(L, x, y, B, Lin, NC, NTI, slope, st); \
+                                   else if (fits(1)) launch_convtr_lds<SS, 1>(L, x, y, B, Lin, NC, NTI, slope, st); else return false; return true; }
+        RCA_TR(2) RCA_TR(4) RCA_TR(5) RCA_TR(8)
+#undef RCA_TR
+        return false;
+    }
+    const int Lout = Lin / L.s;
+    // columns per workgroup: as many as fit beside the weight rows (NW waves = NW output channels share the tile)
+    const int nw = L.cout >= 4 ? 4 : 1;
+    int NC = std::min(64, Lout);
+    auto W_of = [&](int nc) { return (nc * L.s + L.k - L.s + 3 + 3) & ~3; };   // + up to 3 samples of alignment shift, multiple of 4
+    auto lds_of = [&](int nc) { return ((size_t)W_of(nc) * (L.cin + 4) + (size_t)nw * L.cin * L.k) * 4; };
+    while (NC > 1 && lds_of(NC) > RCA_LDS_BUDGET) NC = (NC + 1) / 2;
+    if (lds_of(NC) > RCA_LDS_BUDGET || (L.cin >= 8 && 4 * L.k > 64)) return false;
+    const int W = W_of(NC);
+#define RCA_CV(KK, SS) if (L.k == KK && L.s == SS) { if (nw == 4) launch_conv_lds<KK, SS, 4>(L, x, xbs, Lvalid, y, B, Lin, Lout, NC, W, L.pre, slope, clamp_out, st); \
+                                   else launch_conv_lds<KK, SS, 1>(L, x, xbs, Lvalid, y, B, Lin, Lout, NC, W, L.pre, slope, clamp_out, st); return true; }
+    RCA_CV(4, 2) RCA_CV(8, 4) RCA_CV(10, 5) RCA_CV(16, 8) RCA_CV(3, 1) RCA_CV(7, 1)
+#undef RCA_CV
+    return false;
+}
+
 static int run_conv(rca_codec* h, const ConvLayer& L, const float* x, float* y, int B, int Lin, int clamp_out, hipStream_t st) {
     const float slope = h->cfg.leaky_slope;
+    if (h->lat_mode && try_conv_lds(h, L, x, (long)L.cin * Lin, Lin, y, B, Lin, clamp_out, st)) {
+        RCA_LAUNCH_CHECK();
+        return RCA_OK;
+    }
     if (L.tr && h->variant >= 1 && L.wp_tr && (double)B * L.cin * Lin < 4.0e9) return launch_convtr_mfma(L, x, y, B, Lin, slope, st);
     if (L.tr) {
         const long total = (long)B * L.cout * Lin * L.s;
@@ -1349,7 +1635,7 @@ static int run_encoder(rca_codec* h, RowSrc src, int B, hipStream_t st, float** 
     const ConvLayer& E0 = h->enc[0];
     const ConvLayer& E1 = h->enc[1];
     // conv_in fused into the first strided layer (MFMA variant, 7-tap conv_in, layer 0 not tapped)
-    const bool fuse01 = h->variant >= 1 && tap_layer != 0 && E0.k == 7 && E1.wp && E1.k == 2 * E1.s && (double)B * E1.cin * L < 4.0e9 &&
+    const bool fuse01 = !h->lat_mode && h->variant >= 1 && tap_layer != 0 && E0.k == 7 && E1.wp && E1.k == 2 * E1.s && (double)B * E1.cin * L < 4.0e9 &&
                         ((E1.k == 4 && E1.s == 2) || (E1.k == 8 && E1.s == 4) || (E1.k == 16 && E1.s == 8));
     if (fuse01) {
         float* y = h->act[cur].as<float>();
@@ -1368,6 +1654,9 @@ static int run_encoder(rca_codec* h, RowSrc src, int B, hipStream_t st, float** 
         L = Lout;
         first = 2;
         if (tap_layer == 1) RCA_HIP(hipMemcpyAsync(tap_dev, y, (size_t)B * E1.cout * L * 4, hipMemcpyDeviceToDevice, st));
+    } else if (h->lat_mode && src.win_stride == 0 && src.C == B &&
+               try_conv_lds(h, h->enc[0], src.base, src.chan_stride, src.T, h->act[cur].as<float>(), B, L, 0, st)) {
+        RCA_LAUNCH_CHECK();   // streaming tail: conv_in through the same latency kernel (rows straight from the caller's window)
     } else {
         const ConvLayer& L0 = h->enc[0];
         const long total = (long)B * L;
@@ -1480,7 +1769,11 @@ extern "C" int rca_codec_encode_tail_dev(rca_codec_t* h, const float* pcm, int32
     const int j = trimmable_frames(h, F, n_keep);
     RowSrc src{pcm + (long)j * h->hop, B, (long)T, 0, T - j * h->hop};
     float* ze; int Ft, rc;
-    if ((rc = run_encoder(h, src, B, st, &ze, &Ft, -1, nullptr)) != RCA_OK) return rc;
+    // a handful of frames: the chains, not the FLOPs, set the time -> LDS-staged scalar-chain kernels (same bits)
+    h->lat_mode = h->variant >= 1 && (long)B * (F - j) <= RCA_LAT_MAX_FRAMES;
+    rc = run_encoder(h, src, B, st, &ze, &Ft, -1, nullptr);
+    h->lat_mode = false;
+    if (rc != RCA_OK) return rc;
     RowDst dst{codes, B, (long)n_keep, 0, n_keep};
     return run_quantize(h, ze, 0, B, Ft, Ft - n_keep, n_keep, dst, st, nullptr);
 }
@@ -1690,7 +1983,10 @@ extern "C" int rca_codec_decode_tail_dev(rca_codec_t* h, const int64_t* codes, i
     float* zq = h->act[0].as<float>();
     embed_codes_kernel<<<cdiv((long)B * J * Ft, 256), 256, 0, st>>>(codes + j, (long)F, h->cb, zq, B, Ft, J, h->cfg.codebook_size, h->err_flag);
     RCA_LAUNCH_CHECK();
-    if ((rc = run_decoder(h, zq, B, Ft, h->tail.as<float>(), st)) != RCA_OK) return rc;
+    h->lat_mode = h->variant >= 1 && (long)B * Ft <= RCA_LAT_MAX_FRAMES;
+    rc = run_decoder(h, zq, B, Ft, h->tail.as<float>(), st);
+    h->lat_mode = false;
+    if (rc != RCA_OK) return rc;
     RCA_HIP(hipMemcpy2DAsync(pcm, (size_t)n_samples * 4, h->tail.as<float>() + (Tt - n_samples), (size_t)Tt * 4, (size_t)n_samples * 4, B,
                              hipMemcpyDeviceToDevice, st));
     return RCA_OK;
