@@ -940,6 +940,7 @@ __device__ __forceinline__ unsigned long long sample_key(float v, unsigned idx) 
 //                   the counter RNG.  Falls back to scanning the whole vocabulary if the list overflowed.
 #define SAMP_BINS 2048
 #define SAMP_CAND_CAP 4096
+#define SAMP_FAST_CAP 1024   // candidate lists up to this size are ranked by counting in samp_final_kernel
 struct SampWork {
     unsigned hist[SAMP_BINS];
     unsigned ncand;
@@ -1028,64 +1029,90 @@ __global__ __launch_bounds__(1024) void samp_final_kernel(const float* __restric
     auto key_at = [&](int i) -> unsigned long long {
         return full ? sample_key(samp_value(logits, sp, i), (unsigned)i) : w->cand[i];
     };
-    if (tid == 0) { sel_prefix = 0ull; sel_shift = 0; need = (unsigned)min(k, NN); ncand = 0; }
-    __syncthreads();
-    // radix select: afterwards the keys >= threshold are exactly the k largest
-    for (int pass = 0; pass < 8; ++pass) {
-        if (tid < 256) hist[tid] = 0;
+    __shared__ unsigned long long ck[SAMP_FAST_CAP];
+    __shared__ float e_plain[SAMP_MAXK], e_temp[SAMP_MAXK];
+    int n;
+    if (!full && NN <= SAMP_FAST_CAP) {
+        // the usual case, a few hundred candidates: every thread ranks its own key by counting the larger ones
+        // (keys are unique), the k best land in sorted order -- two barriers instead of a radix select, a compaction
+        // and a bitonic sort
+        if (tid < NN) ck[tid] = w->cand[tid];
         __syncthreads();
-        const int shift = 56 - 8 * pass;
-        const unsigned long long prefix = sel_prefix;
-        const int fixed = sel_shift;
-        for (int i = tid; i < NN; i += 1024) {
-            const unsigned long long key = key_at(i);
-            const bool match = fixed == 0 ? true : ((key >> (64 - fixed)) == (prefix >> (64 - fixed)));
-            if (match) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+        if (tid < NN) {
+            const unsigned long long key = ck[tid];
+            int rank = 0;
+#pragma unroll 8
+            for (int j = 0; j < NN; ++j) rank += ck[j] > key ? 1 : 0;
+            if (rank < SAMP_MAXK) cand[rank] = key;
         }
         __syncthreads();
-        if (tid == 0) {
-            unsigned acc = 0;
-            int d = 255;
-            for (; d > 0; --d) {
-                if (acc + hist[d] >= need) break;
-                acc += hist[d];
-            }
-            need -= acc;  // keys in higher digits are all taken
-            sel_prefix = prefix | ((unsigned long long)d << shift);
-            sel_shift = fixed + 8;
-            if (hist[d] == need) need = 0xFFFFFFFFu;  // whole bucket taken: threshold fixed, stop refining
-        }
+        n = min(NN, SAMP_MAXK);
+    } else {
+        if (tid == 0) { sel_prefix = 0ull; sel_shift = 0; need = (unsigned)min(k, NN); ncand = 0; }
         __syncthreads();
-        if (need == 0xFFFFFFFFu) break;
-    }
-    const unsigned long long thr = sel_prefix;  // unfixed low bits are zero
-    for (int i = tid; i < NN; i += 1024) {
-        const unsigned long long key = key_at(i);
-        if (key >= thr) {
-            const unsigned slot = atomicAdd(&ncand, 1u);
-            if (slot < SAMP_MAXK) cand[slot] = key;
-        }
-    }
-    __syncthreads();
-    const int n = min((int)ncand, SAMP_MAXK);
-    if (tid < SAMP_MAXK && tid >= n) cand[tid] = 0ull;
-    __syncthreads();
-    for (int size = 2; size <= SAMP_MAXK; size <<= 1) {  // bitonic sort, descending; padding (0) sinks
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            if (tid < SAMP_MAXK) {
-                const int j = tid ^ stride;
-                if (j > tid) {
-                    const unsigned long long a = cand[tid], b = cand[j];
-                    const bool desc = (tid & size) == 0;
-                    if (desc ? (a < b) : (a > b)) { cand[tid] = b; cand[j] = a; }
-                }
+        // radix select: afterwards the keys >= threshold are exactly the k largest
+        for (int pass = 0; pass < 8; ++pass) {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const int shift = 56 - 8 * pass;
+            const unsigned long long prefix = sel_prefix;
+            const int fixed = sel_shift;
+            for (int i = tid; i < NN; i += 1024) {
+                const unsigned long long key = key_at(i);
+                const bool match = fixed == 0 ? true : ((key >> (64 - fixed)) == (prefix >> (64 - fixed)));
+                if (match) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
             }
             __syncthreads();
+            if (tid == 0) {
+                unsigned acc = 0;
+                int d = 255;
+                for (; d > 0; --d) {
+                    if (acc + hist[d] >= need) break;
+                    acc += hist[d];
+                }
+                need -= acc;  // keys in higher digits are all taken
+                sel_prefix = prefix | ((unsigned long long)d << shift);
+                sel_shift = fixed + 8;
+                if (hist[d] == need) need = 0xFFFFFFFFu;  // whole bucket taken: threshold fixed, stop refining
+            }
+            __syncthreads();
+            if (need == 0xFFFFFFFFu) break;
+        }
+        const unsigned long long thr = sel_prefix;  // unfixed low bits are zero
+        for (int i = tid; i < NN; i += 1024) {
+            const unsigned long long key = key_at(i);
+            if (key >= thr) {
+                const unsigned slot = atomicAdd(&ncand, 1u);
+                if (slot < SAMP_MAXK) cand[slot] = key;
+            }
+        }
+        __syncthreads();
+        n = min((int)ncand, SAMP_MAXK);
+        if (tid < SAMP_MAXK && tid >= n) cand[tid] = 0ull;
+        __syncthreads();
+        for (int size = 2; size <= SAMP_MAXK; size <<= 1) {  // bitonic sort, descending; padding (0) sinks
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                if (tid < SAMP_MAXK) {
+                    const int j = tid ^ stride;
+                    if (j > tid) {
+                        const unsigned long long a = cand[tid], b = cand[j];
+                        const bool desc = (tid & size) == 0;
+                        if (desc ? (a < b) : (a > b)) { cand[tid] = b; cand[j] = a; }
+                    }
+                }
+                __syncthreads();
+            }
         }
     }
     if (tid < n) {
         const unsigned idx = 0xFFFFFFFFu - (unsigned)(cand[tid] & 0xFFFFFFFFull);
         cval[tid] = samp_value(logits, sp, (int)idx);
+    }
+    __syncthreads();
+    if (tid < n && !greedy) {   // the exponentials in parallel; the sums below stay serial (their order is the definition)
+        const float mx = cval[0];
+        e_plain[tid] = rca_expf(cval[tid] - mx);
+        e_temp[tid] = rca_expf((cval[tid] - mx) * (1.0f / sp->temp));
     }
     __syncthreads();
     if (tid == 0) {
@@ -1095,11 +1122,11 @@ __global__ __launch_bounds__(1024) void samp_final_kernel(const float* __restric
             const float mx = cval[0];
             if (sp->top_p < 1.0f) {  // smallest prefix whose probability mass reaches top_p
                 float tot = 0.0f;
-                for (int i = 0; i < cnt; ++i) tot += rca_expf(cval[i] - mx);
+                for (int i = 0; i < cnt; ++i) tot += e_plain[i];
                 float cum = 0.0f;
                 int keep = cnt;
                 for (int i = 0; i < cnt; ++i) {
-                    cum += rca_expf(cval[i] - mx);
+                    cum += e_plain[i];
                     if (cum >= sp->top_p * tot) { keep = i + 1; break; }
                 }
                 cnt = keep;
@@ -1107,19 +1134,18 @@ __global__ __launch_bounds__(1024) void samp_final_kernel(const float* __restric
             if (sp->min_p > 0.0f) {  // keep p_i >= min_p * p_max
                 int keep = 1;
                 for (int i = 1; i < cnt; ++i)
-                    if (rca_expf(cval[i] - mx) >= sp->min_p) keep = i + 1; else break;
+                    if (e_plain[i] >= sp->min_p) keep = i + 1; else break;
                 cnt = keep;
             }
-            const float inv_t = 1.0f / sp->temp;
             float tot = 0.0f;
-            for (int i = 0; i < cnt; ++i) tot += rca_expf((cval[i] - mx) * inv_t);
+            for (int i = 0; i < cnt; ++i) tot += e_temp[i];
             const unsigned long long z = splitmix(sp->seed, stt->rng_counter);
             const float u = (float)(unsigned)(z >> 40) * 5.9604644775390625e-08f;  // 2^-24
             const float target = u * tot;
             float cum = 0.0f;
             pick = cnt - 1;
             for (int i = 0; i < cnt; ++i) {
-                cum += rca_expf((cval[i] - mx) * inv_t);
+                cum += e_temp[i];
                 if (cum > target) { pick = i; break; }
             }
         }
