@@ -115,7 +115,12 @@ def save_npz(path: str, cfg: LMConfig, weights: Dict[str, np.ndarray]) -> None:
 
 
 def load_weights(model_path: str):
-    """-> (LMConfig, {name: ndarray}) from an .npz (save_npz) or an HF directory with safetensors."""
+    """-> (LMConfig, {name: ndarray}) from an .npz (save_npz), a llama-architecture .gguf (the reference's format,
+    realtime_agent_resources.py:12,19-25) or an HF directory with safetensors."""
+    if model_path.endswith(".gguf"):
+        from .gguf import load_llama_gguf
+        cfg, weights, _meta = load_llama_gguf(model_path)
+        return cfg, weights
     if model_path.endswith(".npz"):
         z = np.load(model_path)
         cfg = LMConfig(**json.loads(str(z["__config__"])))
@@ -205,7 +210,7 @@ class LlamaForAlternatingCodeChannels:
                     "rca_lm_create_random")
         else:
             w = dict(weights)
-            w["rope.inv_freq"] = rope_inv_freq(config)
+            w.setdefault("rope.inv_freq", rope_inv_freq(config))   # a GGUF brings the file's own frequencies
             tensors, keep = N.make_tensors(w)
             N.check(self._lib.rca_lm_create(C.byref(c), tensors, len(w), device, C.byref(self._h)), "rca_lm_create")
             del keep

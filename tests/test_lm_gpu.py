@@ -234,3 +234,28 @@ def test_full_size_1b_properties():
     assert outs[0] == outs[1]
     want = lm_ref.sample(llm._scores[-1], 100, 1.0, 0.0, 1.0, 42, 5)
     assert outs[1][-1] == want
+
+
+@pytest.mark.parametrize("rope", ["default", "llama3"])
+def test_gguf_model_path_gives_the_same_logits(tmp_path, rope):
+    """A GGUF written the way convert_hf_to_gguf.py writes a Llama (permuted Q/K rows, rope_freqs for llama3 scaling)
+    and loaded through model_path= runs to the same logits, bit for bit, as the Hugging Face tensors it was made from."""
+    import gguf_writer as gw
+    from realtime_codec_agent_amd.llm import LMConfig, LlamaForAlternatingCodeChannels, bf16_bits_to_f32, rope_inv_freq
+    llm, w, ids = make_llm(rope)
+    llm.set_mfma_prefill(False)
+    cfg = tiny_cfg(rope)
+    wf = {k: (bf16_bits_to_f32(v) if v.dtype == np.uint16 else v.astype(np.float32)) for k, v in w.items()}
+    factors = None
+    if rope == "llama3":
+        factors = rope_inv_freq(LMConfig(**{**cfg.__dict__, "rope_scaling": None})) / rope_inv_freq(cfg)
+    path = str(tmp_path / "tiny.gguf")
+    gw.write_llama_gguf(path, cfg, wf, matrix_type=gw.BF16, rope_freqs=factors)
+    g = LlamaForAlternatingCodeChannels(model_path=path, n_ctx=512, device=0)
+    g.set_mfma_prefill(False)
+    llm.eval(ids.tolist()); g.eval(ids.tolist())
+    a, b = llm._scores[-1], g._scores[-1]
+    if rope == "default":
+        assert np.array_equal(a, b)
+    else:   # inv_freq goes through one extra divide/multiply: last-bit differences in the RoPE table
+        assert np.abs(a - b).max() < 1e-4
