@@ -40,11 +40,15 @@ class RealtimeAgentResources:
             raise NotImplementedError("whisper.cpp transcription is out of scope; pass a model object or None")
         self.whisper_model = whisper_model
         self.audio_tokenizer = AudioTokenizer(codec_model=codec_model, device=codec_device)
+        if tokenizer is None and self.llm_model_dir and os.path.exists(os.path.join(self.llm_model_dir, "tokenizer.json")):
+            # the reference keeps the trained HF fast tokenizer next to the model file (realtime_agent_resources.py:34)
+            from transformers import AutoTokenizer
+            tokenizer = AutoTokenizer.from_pretrained(self.llm_model_dir, local_files_only=True)
         if tokenizer is None:
             tokenizer = CodecTokenizer(codebook_size=self.audio_tokenizer.codebook_size, unicode_offset=self.audio_tokenizer.unicode_offset)
         self.tokenizer = tokenizer
-        if self.tokenizer.vocab_size > self.llm.n_vocab():
-            raise ValueError(f"tokenizer has {self.tokenizer.vocab_size} ids but the LM has {self.llm.n_vocab()} logits")
+        if len(self.tokenizer) > self.llm.n_vocab():
+            raise ValueError(f"tokenizer has {len(self.tokenizer)} ids but the LM has {self.llm.n_vocab()} logits")
         if llm_model_path.startswith("random:"):
             # A trained codec LM in audio mode puts its probability mass on codec tokens.  Random-init weights
             # do not, so the text / padding rows of lm_head are zeroed: the top-k then holds codec tokens only
