@@ -27,7 +27,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-#define LM_MAXM 32         // tokens per forward pass (activation buffers); prefill tiles use all 32
+#define LM_MAXM 128        // tokens per forward pass (activation buffers); the 128-token prefill tiles use all of them
+#define LM_TILE32 32       // token tile of the small-model prefill kernels (lm_gemm_mfma_kernel)
 #define LM_GEMV_M 8        // largest pass served by the GEMV kernels; longer evals go through the MFMA prefill path
 #define LM_KSLICE 2048     // K handled by one workgroup pass of the GEMV
 #define LM_MAXSPLIT 4      // K splits (ffn 8192 / 2048)
@@ -1244,6 +1245,7 @@ struct rca_lm {
           *att_part = nullptr, *logits = nullptr, *probs_dev = nullptr;
     int* probe_ids_dev = nullptr;
     bf16_t *xh = nullptr, *xl = nullptr;   // prefill: bf16 hi / lo split of the current GEMM input [LM_MAXM][max K]
+    float* gpart = nullptr;                // prefill: k-split partial sums of the narrow projections [8][LM_MAXM][hidden]
     long logits_rows_cap = 0;   // rows allocated in `logits` (1, or more when logits_all)
     int logits_rows = 0;        // rows valid from the last eval
     LmDevState* stt = nullptr;  // device
@@ -1278,7 +1280,7 @@ extern "C" int rca_lm_destroy(rca_lm_t* h) {
             if (p) (void)hipFree(p);
     for (void* p : {(void*)h->embed, (void*)h->head, (void*)h->final_norm, (void*)h->cos_t, (void*)h->sin_t, (void*)h->kc, (void*)h->vc,
                     (void*)h->x, (void*)h->x2, (void*)h->xn, (void*)h->qkv, (void*)h->attn, (void*)h->part_o, (void*)h->hbuf, (void*)h->part_d,
-                    (void*)h->att_part, (void*)h->logits, (void*)h->probs_dev, (void*)h->probe_ids_dev, (void*)h->xh, (void*)h->xl, (void*)h->stt, (void*)h->samp, (void*)h->swork})
+                    (void*)h->att_part, (void*)h->logits, (void*)h->probs_dev, (void*)h->probe_ids_dev, (void*)h->xh, (void*)h->xl, (void*)h->gpart, (void*)h->stt, (void*)h->samp, (void*)h->swork})
         if (p) (void)hipFree(p);
     if (h->h_stt) (void)hipHostFree(h->h_stt);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1408,6 +1410,8 @@ static int lm_common_init(rca_lm* h, const rca_tensor_t* ts, int nt) {
         if ((rc = lm_alloc((void**)&h->xl, (size_t)LM_MAXM * kmax * 2)) != RCA_OK) return rc;
         RCA_HIP(hipMemsetAsync(h->xh, 0, (size_t)LM_MAXM * kmax * 2, h->stream));
         RCA_HIP(hipMemsetAsync(h->xl, 0, (size_t)LM_MAXM * kmax * 2, h->stream));
+        // k-split partial sums: splits x N stays below 1024 x 128 for every GEMM (see lm_enqueue_prefill_tile128)
+        if ((rc = lm_alloc((void**)&h->gpart, (size_t)LM_MAXM * 1024 * 128 * 4)) != RCA_OK) return rc;
     }
     if ((rc = lm_alloc((void**)&h->stt, sizeof(LmDevState))) != RCA_OK) return rc;
     if ((rc = lm_alloc((void**)&h->samp, sizeof(SamplerDev))) != RCA_OK) return rc;
@@ -1622,6 +1626,241 @@ static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st, in
 
 // One prefill tile (M <= 32 tokens already described by h->stt): projections on bf16 MFMA with hi/lo-split
 // activations, attention through the same split-KV kernels.  Leaves the residual stream in h->x.
+// ------------------------------------------------------------------ prefill GEMM, 128 weight rows x 128 tokens
+// Y[tok][n] = sum_k W[n][k] * (xh + xl)[tok][k] on v_mfma_f32_32x32x16_bf16, LDS-staged and double-buffered.
+// Workgroup = 4 waves in a 2 x 2 grid, each wave 64 rows x 64 tokens (2 x 2 MFMA tiles, hi and lo passes share the
+// weight fragment).  A stage is 32 k: three 128 x 32 bf16 tiles (W, xh, xl) fetched with 16-byte loads one stage
+// ahead and kept in LDS rows of 40 bf16 (80 B: the 16-byte fragment reads of 8 consecutive rows hit 8 distinct
+// 4-bank groups).  Weights are read from HBM once per 128 tokens instead of once per 32.
+// grid (N / 128, k splits): with one split the epilogue is fused (RoPE + KV write, SwiGLU + hi/lo split, residual
+// add); with several (the narrow N = hidden projections, to put more than 16 workgroups on the chip) each split
+// stores its partial sums and lm_gemm128_epilogue_kernel adds them in split order and runs the epilogue -- deterministic.
+#define G128_PITCH 40
+#define G128_LDS (2 * 3 * 128 * G128_PITCH * 2)
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __restrict__ stt, const bf16_t* __restrict__ W,
+                                                            const bf16_t* __restrict__ xh, const bf16_t* __restrict__ xl, int N, int K,
+                                                            int kslice, float* __restrict__ y, int ldy, bf16_t* __restrict__ oh,
+                                                            bf16_t* __restrict__ ol, float* __restrict__ part, GemvRope rope) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t g128_lds[];   // [2 buffers][W, xh, xl][128 rows][G128_PITCH]
+    typedef bf16_t tile_t[3][128 * G128_PITCH];
+    tile_t* sm = reinterpret_cast<tile_t*>(g128_lds);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int n0 = blockIdx.x * 128;
+    const int ks = blockIdx.y * kslice;
+    const int nstage = kslice >> 5;
+    // staging role: two 16-byte chunks per tile and thread: rows c >> 2, k offset (c & 3) * 8
+    const int srow0 = tid >> 2, skc = (tid & 3) * 8;
+    const bf16_t* gW = W + (long)(n0 + srow0) * K + ks + skc;
+    const bf16_t* gH = xh + (long)srow0 * K + ks + skc;
+    const bf16_t* gL = xl + (long)srow0 * K + ks + skc;
+    const long rstep = 64L * K;     // second chunk: row + 64
+    const int soff0 = srow0 * G128_PITCH + skc, soff1 = soff0 + 64 * G128_PITCH;
+    // Software pipeline.  A workgroup's stage needs 8 KB of weights straight from HBM (~2 us away) and 16 KB of
+    // activations from L2 (~0.7 us): weight chunks are requested DW stages ahead, activation chunks DX stages ahead,
+    // both held in registers until their LDS buffer is free.
+    constexpr int DW = 1, DX = 1;   // measured: deeper register prefetch (4 / 2) is slower at 2 workgroups per CU
+    uint4 rw[DW][2], rh[DX][2], rl[DX][2];
+    auto gload_w = [&](int slot, int s) {
+        const int k = min(s, nstage - 1) << 5;
+        rw[slot][0] = *reinterpret_cast<const uint4*>(gW + k); rw[slot][1] = *reinterpret_cast<const uint4*>(gW + rstep + k);
+    };
+    auto gload_x = [&](int slot, int s) {
+        const int k = min(s, nstage - 1) << 5;
+        rh[slot][0] = *reinterpret_cast<const uint4*>(gH + k); rh[slot][1] = *reinterpret_cast<const uint4*>(gH + rstep + k);
+        rl[slot][0] = *reinterpret_cast<const uint4*>(gL + k); rl[slot][1] = *reinterpret_cast<const uint4*>(gL + rstep + k);
+    };
+    auto swrite = [&](int buf, int ws, int xs) {
+        *reinterpret_cast<uint4*>(&sm[buf][0][soff0]) = rw[ws][0]; *reinterpret_cast<uint4*>(&sm[buf][0][soff1]) = rw[ws][1];
+        *reinterpret_cast<uint4*>(&sm[buf][1][soff0]) = rh[xs][0]; *reinterpret_cast<uint4*>(&sm[buf][1][soff1]) = rh[xs][1];
+        *reinterpret_cast<uint4*>(&sm[buf][2][soff0]) = rl[xs][0]; *reinterpret_cast<uint4*>(&sm[buf][2][soff1]) = rl[xs][1];
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    // fragment read offsets: row (lane & 31) of the 32-row tile, k offset 8 * half inside a 16-k substep
+    const int fa = (wr * 64 + (lane & 31)) * G128_PITCH + 8 * half;
+    const int fb = (wc * 64 + (lane & 31)) * G128_PITCH + 8 * half;
+#pragma unroll
+    for (int d = 0; d < DW; ++d) gload_w(d, d);
+#pragma unroll
+    for (int d = 0; d < DX; ++d) gload_x(d, d);
+    swrite(0, 0, 0);
+    __syncthreads();
+    // stage s: weights in slot s % DW, activations in slot s % DX; the loop is unrolled by DW (a multiple of DX)
+    for (int s0 = 0; s0 < nstage; s0 += DW) {
+#pragma unroll
+        for (int d = 0; d < DW; ++d) {
+            const int s = s0 + d;
+            if (s >= nstage) break;
+            const int buf = s & 1;
+            // slots of stage s are in LDS: refill them with the stages DW / DX ahead
+            gload_w(d, s + DW);
+            gload_x(d % DX, s + DX);
+#pragma unroll
+            for (int ksub = 0; ksub < 2; ++ksub) {
+                bf16x8 a[2], bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[i] = *reinterpret_cast<const bf16x8*>(&sm[buf][0][fa + i * 32 * G128_PITCH + ksub * 16]);
+                    bh[i] = *reinterpret_cast<const bf16x8*>(&sm[buf][1][fb + i * 32 * G128_PITCH + ksub * 16]);
+                    bl[i] = *reinterpret_cast<const bf16x8*>(&sm[buf][2][fb + i * 32 * G128_PITCH + ksub * 16]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+            if (s + 1 < nstage) swrite(buf ^ 1, (d + 1) % DW, (d + 1) % DX);
+            __syncthreads();
+        }
+    }
+    // epilogue.  C layout: token = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * half inside a 32 x 32 tile
+    const int Mv = stt->m;
+    const int nsplit = gridDim.y;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int tok = wc * 64 + j * 32 + (lane & 31);
+        if (tok >= Mv) continue;
+        if (nsplit > 1) {   // partial sums of this k slice, token-contiguous [split][n][LM_MAXM]: lanes are tokens -> 128-byte runs
+            float* p = part + ((long)blockIdx.y * N + n0 + wr * 64) * LM_MAXM + tok;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[(long)(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LM_MAXM] = acc[i][j][r];
+        } else if (EPI == GEMM_EPI_RESID) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    y[(long)tok * ldy + n] = y[(long)tok * ldy + n] + acc[i][j][r];
+                }
+        } else if (EPI == GEMM_EPI_ROPE) {
+            // the wave's 64 rows are one head: rows d (tile 0) and d + 32 (tile 1) sit in the same register slot
+            const int pos = stt->n_tokens + tok;
+            if (pos >= rope.n_ctx) continue;
+            const int head = (n0 + wr * 64) >> 6;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = (r & 3) + 8 * (r >> 2) + 4 * half;   // < 32
+                const float x1 = acc[0][j][r], x2 = acc[1][j][r];
+                if (head < rope.nh + rope.nkv) {
+                    const float c = rope.cos_t[(long)pos * 32 + d], sn = rope.sin_t[(long)pos * 32 + d];
+                    const float o1 = x1 * c + (-x2) * sn;
+                    const float o2 = x2 * c + x1 * sn;
+                    if (head < rope.nh) {
+                        y[(long)tok * ldy + head * 64 + d] = o1;
+                        y[(long)tok * ldy + head * 64 + d + 32] = o2;
+                    } else {
+                        f16_t* kp = rope.kc + ((long)pos * rope.nkv + (head - rope.nh)) * 64;
+                        kp[d] = (f16_t)o1;
+                        kp[d + 32] = (f16_t)o2;
+                    }
+                } else {
+                    f16_t* vp = rope.vc + ((long)pos * rope.nkv + (head - rope.nh - rope.nkv)) * 64;
+                    vp[d] = (f16_t)x1;
+                    vp[d + 32] = (f16_t)x2;
+                }
+            }
+        } else {   // SwiGLU: rows (2i, 2i+1) = (gate_i, up_i) sit in registers (2q, 2q+1)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int rr = ((2 * q) & 3) + 8 * ((2 * q) >> 2) + 4 * half;
+                    const int fi = (n0 + wr * 64 + i * 32 + rr) >> 1;
+                    const float g = acc[i][j][2 * q], u = acc[i][j][2 * q + 1];
+                    const float hv = (g / (1.0f + __expf(-g))) * u;
+                    const bf16_t hb = f32_to_bf16_rne(hv);
+                    oh[(long)tok * ldy + fi] = hb;
+                    ol[(long)tok * ldy + fi] = f32_to_bf16_rne(hv - __uint_as_float((unsigned)hb << 16));
+                }
+        }
+    }
+}
+// Epilogue over the k-split partial sums part[split][n][LM_MAXM] (added in split order, starting from 0).  A block
+// takes 64 rows x 32 tokens: it sums the splits with token-contiguous reads, turns the tile through LDS and runs the
+// fused epilogue with row-contiguous writes -- residual add, RoPE + KV write (the 64 rows are one head), or SwiGLU +
+// hi/lo split (the 64 rows are 32 interleaved gate/up pairs).
+template <int EPI>
+__global__ __launch_bounds__(256) void lm_gemm128_epilogue_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ part, int nsplit, int N,
+                                                                  float* __restrict__ y, bf16_t* __restrict__ oh, bf16_t* __restrict__ ol,
+                                                                  GemvRope rope) {
+    __shared__ float tile[64][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // ty 0..7
+    const int n0 = blockIdx.x * 64, t0 = blockIdx.y * 32;
+    const int Mv = stt->m;
+    if (t0 >= Mv) return;
+    {
+        float v[8];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) v[rr] = 0.0f;
+        const float* p0 = part + ((long)n0 + ty) * LM_MAXM + t0 + tx;
+#pragma unroll 4
+        for (int s = 0; s < nsplit; ++s) {   // eight independent row sums per thread: eight loads in flight per split
+            const float* ps = p0 + (long)s * N * LM_MAXM;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) v[rr] += ps[(long)rr * 8 * LM_MAXM];
+        }
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) tile[rr * 8 + ty][tx] = v[rr];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        const int tl = tt * 8 + ty;
+        const int tok = t0 + tl;
+        if (tok >= Mv) continue;
+        if (EPI == GEMM_EPI_RESID) {
+            float* yr = y + (long)tok * N + n0;
+            yr[tx] = yr[tx] + tile[tx][tl];
+            yr[tx + 32] = yr[tx + 32] + tile[tx + 32][tl];
+        } else if (EPI == GEMM_EPI_ROPE) {
+            const int pos = stt->n_tokens + tok;
+            if (pos >= rope.n_ctx) continue;
+            const int head = n0 >> 6, d = tx;
+            const float x1 = tile[d][tl], x2 = tile[d + 32][tl];
+            if (head < rope.nh + rope.nkv) {
+                const float c = rope.cos_t[(long)pos * 32 + d], sn = rope.sin_t[(long)pos * 32 + d];
+                const float o1 = x1 * c + (-x2) * sn;
+                const float o2 = x2 * c + x1 * sn;
+                if (head < rope.nh) {
+                    y[(long)tok * N + n0 + d] = o1;
+                    y[(long)tok * N + n0 + d + 32] = o2;
+                } else {
+                    f16_t* kp = rope.kc + ((long)pos * rope.nkv + (head - rope.nh)) * 64;
+                    kp[d] = (f16_t)o1;
+                    kp[d + 32] = (f16_t)o2;
+                }
+            } else {
+                f16_t* vp = rope.vc + ((long)pos * rope.nkv + (head - rope.nh - rope.nkv)) * 64;
+                vp[d] = (f16_t)x1;
+                vp[d + 32] = (f16_t)x2;
+            }
+        } else {   // rows (2i, 2i+1) = (gate_i, up_i)
+            const int F = N >> 1;
+            const int fi = (n0 >> 1) + tx;
+            const float g = tile[2 * tx][tl], u = tile[2 * tx + 1][tl];
+            const float hv = (g / (1.0f + __expf(-g))) * u;
+            const bf16_t hb = f32_to_bf16_rne(hv);
+            oh[(long)tok * F + fi] = hb;
+            ol[(long)tok * F + fi] = f32_to_bf16_rne(hv - __uint_as_float((unsigned)hb << 16));
+        }
+    }
+}
+
 static bool lm_can_mfma_prefill(const rca_lm* h) {
     const rca_lm_config_t& c = h->cfg;
     const int AO = c.n_heads * c.head_dim;
@@ -1665,6 +1904,65 @@ static int lm_enqueue_prefill_tile(rca_lm* h, int M, hipStream_t st, int nsp_lau
         bf16_t* hl = hh + (long)LM_MAXM * F;
         lm_gemm_mfma_kernel<GEMM_EPI_SWIGLU><<<2 * F / 32, 256, 0, st>>>(h->stt, L.wgu, h->xh, h->xl, 2 * F, H, nullptr, F, hh, hl, norope);
         lm_gemm_mfma_kernel<GEMM_EPI_RESID><<<H / 32, 256, 0, st>>>(h->stt, L.wdown, hh, hl, H, F, x, H, nullptr, nullptr, norope);
+    }
+    RCA_LAUNCH_CHECK();
+    return RCA_OK;
+}
+static bool lm_can_gemm128(const rca_lm* h) {
+    const rca_lm_config_t& c = h->cfg;
+    const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim, F = c.ffn;
+    return c.head_dim == 64 && H % 128 == 0 && QKV % 128 == 0 && (2 * F) % 128 == 0 && AO % 32 == 0 && F % 32 == 0;
+}
+static int lm_enqueue_prefill_tile128(rca_lm* h, int M, hipStream_t st, int nsp_launch) {
+    const rca_lm_config_t& c = h->cfg;
+    const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim, F = c.ffn;
+    const int G = c.n_heads / c.n_kv_heads;
+    const float scale = 1.0f / sqrtf((float)c.head_dim);
+    GemvRope rope{h->cos_t, h->sin_t, nullptr, nullptr, c.n_heads, c.n_kv_heads, c.n_ctx};
+    const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    // Every GEMM is cut along k until ~512 workgroups are in flight (a workgroup's stage is one exposed HBM round
+    // trip: parallel slices are what hides it), slices of >= 256 k, powers of two so they divide K / 32.
+    auto splits = [](int N, int K) {
+        int ns = 1;
+        while (ns * (N / 128) < 512 && K % (ns * 2 * 32) == 0 && K / (ns * 2) >= 256) ns *= 2;
+        return ns;
+    };
+    const int sq = splits(QKV, H), so = splits(H, AO), sg = splits(2 * F, H), sd = splits(H, F);
+    float* x = h->x;
+    lm_embed_kernel<<<M, 256, 0, st>>>(h->stt, h->embed, x, H, c.vocab_size);
+    for (int l = 0; l < c.n_layers; ++l) {
+        const LmLayer& L = h->layers[l];
+        f16_t* kc = h->kc + (long)l * h->kv_layer_stride;
+        f16_t* vc = h->vc + (long)l * h->kv_layer_stride;
+        rope.kc = kc; rope.vc = vc;
+        lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.attn_norm, h->xn, H, c.rms_eps);
+        lm_split_bf16_kernel<<<dim3(cdiv(H, 256), M), 256, 0, st>>>(h->stt, h->xn, h->xh, h->xl, H);
+        lm_gemm128_kernel<GEMM_EPI_ROPE><<<dim3(QKV / 128, sq), 256, G128_LDS, st>>>(h->stt, L.wqkv, h->xh, h->xl, QKV, H, H / sq, h->qkv, QKV, nullptr, nullptr, h->gpart, rope);
+        if (sq > 1) lm_gemm128_epilogue_kernel<GEMM_EPI_ROPE><<<dim3(QKV / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sq, QKV, h->qkv, nullptr, nullptr, rope);
+        dim3 ag(c.n_kv_heads, nsp_launch, (M + 1) / 2);
+        if (G == 4) {
+            lm_attn_kernel<4><<<ag, ATT_THREADS, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
+            lm_attn_combine_kernel<4><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
+        } else if (G == 2) {
+            lm_attn_kernel<2><<<ag, ATT_THREADS, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
+            lm_attn_combine_kernel<2><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
+        } else {
+            lm_attn_kernel<1><<<ag, ATT_THREADS, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
+            lm_attn_combine_kernel<1><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
+        }
+        lm_split_bf16_kernel<<<dim3(cdiv(AO, 256), M), 256, 0, st>>>(h->stt, h->attn, h->xh, h->xl, AO);
+        lm_gemm128_kernel<GEMM_EPI_RESID><<<dim3(H / 128, so), 256, G128_LDS, st>>>(h->stt, L.wo, h->xh, h->xl, H, AO, AO / so, x, H, nullptr, nullptr, h->gpart, norope);
+        if (so > 1) lm_gemm128_epilogue_kernel<GEMM_EPI_RESID><<<dim3(H / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, so, H, x, nullptr, nullptr, norope);
+        lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.ffn_norm, h->xn, H, c.rms_eps);
+        lm_split_bf16_kernel<<<dim3(cdiv(H, 256), M), 256, 0, st>>>(h->stt, h->xn, h->xh, h->xl, H);
+        // SwiGLU epilogue writes the hi/lo split of h straight into the (ffn-wide) split buffers of the down projection:
+        // it reads xh/xl [M][H] and writes [M][F] -- distinct regions are needed, so h goes to the second half of hbuf
+        bf16_t* hh = reinterpret_cast<bf16_t*>(h->hbuf);
+        bf16_t* hl = hh + (long)LM_MAXM * F;
+        lm_gemm128_kernel<GEMM_EPI_SWIGLU><<<dim3(2 * F / 128, sg), 256, G128_LDS, st>>>(h->stt, L.wgu, h->xh, h->xl, 2 * F, H, H / sg, nullptr, F, hh, hl, h->gpart, norope);
+        if (sg > 1) lm_gemm128_epilogue_kernel<GEMM_EPI_SWIGLU><<<dim3(2 * F / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sg, 2 * F, nullptr, hh, hl, norope);
+        lm_gemm128_kernel<GEMM_EPI_RESID><<<dim3(H / 128, sd), 256, G128_LDS, st>>>(h->stt, L.wdown, hh, hl, H, F, F / sd, x, H, nullptr, nullptr, h->gpart, norope);
+        if (sd > 1) lm_gemm128_epilogue_kernel<GEMM_EPI_RESID><<<dim3(H / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sd, H, x, nullptr, nullptr, norope);
     }
     RCA_LAUNCH_CHECK();
     return RCA_OK;
@@ -1721,11 +2019,14 @@ extern "C" int rca_lm_eval(rca_lm_t* h, const int32_t* ids, int32_t n) {
     float* logits_base = h->logits;
     if (!all && n > LM_GEMV_M && h->mfma_prefill && lm_can_mfma_prefill(h)) {
         // long evals (session prefill, recompute_kv_cache): 32-token tiles on the bf16 MFMA path
-        for (int off = 0; off < n; off += LM_MAXM) {
-            const int m = std::min(LM_MAXM, n - off);
+        const bool big = lm_can_gemm128(h);
+        const int tile = big ? LM_MAXM : LM_TILE32;
+        for (int off = 0; off < n; off += tile) {
+            const int m = std::min(tile, n - off);
             const bool last = off + m >= n;
             if ((rc = lm_push_state(h, ids + off, m, st)) != RCA_OK) return rc;
-            if ((rc = lm_enqueue_prefill_tile(h, m, st, lm_splits_needed(h, m))) != RCA_OK) return rc;
+            rc = big ? lm_enqueue_prefill_tile128(h, m, st, lm_splits_needed(h, m)) : lm_enqueue_prefill_tile(h, m, st, lm_splits_needed(h, m));
+            if (rc != RCA_OK) return rc;
             if (last) {   // logits of the final token: final norm + head on the register GEMV path
                 const rca_lm_config_t& c = h->cfg;
                 const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
