@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--context-secs", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-duplex", action="store_true")
+    ap.add_argument("--no-trim-leg", action="store_true", help="skip the receptive-field-trimmed batch leg (profiling runs: keeps per-kernel averages to the headline path)")
     ap.add_argument("--duplex-secs", type=float, default=20.0)
     ap.add_argument("--variant", type=int, default=1)
     args = ap.parse_args()
@@ -143,7 +144,7 @@ def main():
     # SURVEY 8f-1 leg (reported beside the headline, never as `value`): the same steps with every window cut down
     # to the receptive field of its kept frames -- identical codes (checked), ~10x less encoder work
     codes_full = codes.clone()
-    hip.set_window_trim(True)
+    hip.set_window_trim(not args.no_trim_leg)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize(dev)
@@ -163,6 +164,8 @@ def main():
         elapsed_trim = float(t.item())
     trim_identical = bool(torch.equal(codes, codes_full))
     assert trim_identical, "window-trimmed batch encode produced different codes"
+    if args.no_trim_leg:
+        elapsed_trim = 1.0
 
     prof = {k: hip.profile_read(k) for k in (0, 1, 2, 3)}
     audio_secs = args.steps * chunks_per_step * chunk / cfg.sample_rate  # per rank, stereo seconds
@@ -194,7 +197,7 @@ def main():
             "codebook": f"{cfg.codebook_size}x{cfg.codebook_dim}",
             "encoder_gflop_per_window": cfg.encoder_flops_per_sample() * ctx / 1e9,
             "sharding": "chunk ranges per rank, no collective (replicas only)",
-            "receptive_field_trimmed": {
+            "receptive_field_trimmed": None if args.no_trim_leg else {
                 "value": world * audio_secs / elapsed_trim, "unit": "audio-hours/hour", "ms_per_step": 1e3 * elapsed_trim / args.steps,
                 "codes_identical_to_full_windows": trim_identical,
                 "note": "same steps with rca_codec_set_window_trim(1): each window cut to the kept frames + their receptive "

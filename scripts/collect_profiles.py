@@ -1,0 +1,23 @@
+"""Copies the judged summaries of a scripts/profile_round.sh run from gpurun_out/prof_<tag>/ into profiles/<tag>/.
+usage: collect_profiles.py <tag>"""
+import collections, csv, glob, os, shutil, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src, dst = f"gpurun_out/prof_{tag}", f"profiles/{tag}"
+os.makedirs(dst, exist_ok=True)
+shutil.copy(f"{src}/SUMMARY.txt", f"{dst}/SUMMARY.txt")
+for sub in ("bench", "lm"):
+    shutil.copy(glob.glob(f"{src}/{sub}/*/*kernel_stats.csv")[0], f"{dst}/{sub}_kernel_stats.csv")
+    lines = [l for l in open(f"{src}/{sub}_stdout.log") if l.startswith("{") or l.startswith("ctx=")]
+    open(f"{dst}/{sub}_stdout.log", "w").writelines(lines)
+for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
+    rows = list(csv.DictReader(open(glob.glob(f"{src}/{sub}/*/*counter_collection.csv")[0])))
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in rows:
+        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    with open(f"{dst}/{sub}_per_kernel_avg.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "counter", "dispatches", "avg_value"])
+        for k, cs in sorted(agg.items()):
+            for c, v in sorted(cs.items()):
+                w.writerow([k[:120], c, len(v), sum(v) / len(v)])
+print("collected into", dst, os.listdir(dst))
