@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-duplex", action="store_true")
     ap.add_argument("--no-trim-leg", action="store_true", help="skip the receptive-field-trimmed batch leg (profiling runs: keeps per-kernel averages to the headline path)")
-    ap.add_argument("--duplex-secs", type=float, default=20.0)
+    ap.add_argument("--duplex-secs", type=float, default=60.0)
     ap.add_argument("--variant", type=int, default=1)
     args = ap.parse_args()
 

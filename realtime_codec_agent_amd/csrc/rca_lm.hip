@@ -1160,12 +1160,16 @@ __global__ __launch_bounds__(1024) void samp_final_kernel(const float* __restric
 }
 
 // probs[i] = softmax(logits)[ids[i]] : one workgroup, two sweeps (max, sum)
-__global__ __launch_bounds__(1024) void lm_token_probs_kernel(const float* __restrict__ logits, int V, const int* __restrict__ ids,
-                                                              int n, float* __restrict__ probs) {
+// softmax(logits)[ids] in two launches (the agent asks for P(<|end_audio|>) once per frame, realtime_agent_v2.py:448-452):
+// 64 workgroups reduce a slice each to (max, sum of exp relative to it); one wave merges the slices in slice order.
+#define PROBS_SLICES 64
+__global__ __launch_bounds__(1024) void lm_softmax_slices_kernel(const float* __restrict__ logits, int V, float* __restrict__ part) {
     __shared__ float red[16];
-    __shared__ float smax, ssum;
+    __shared__ float smax;
+    const int per = (V + PROBS_SLICES - 1) / PROBS_SLICES;
+    const int i0 = blockIdx.x * per, i1 = min(V, i0 + per);
     float mx = -INFINITY;
-    for (int i = threadIdx.x; i < V; i += 1024) mx = fmaxf(mx, logits[i]);
+    for (int i = i0 + threadIdx.x; i < i1; i += 1024) mx = fmaxf(mx, logits[i]);
     mx = wave_max(mx);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
     __syncthreads();
@@ -1173,16 +1177,28 @@ __global__ __launch_bounds__(1024) void lm_token_probs_kernel(const float* __res
     __syncthreads();
     mx = smax;
     float s = 0.0f;
-    for (int i = threadIdx.x; i < V; i += 1024) s += __expf(logits[i] - mx);
+    for (int i = i0 + threadIdx.x; i < i1; i += 1024) s += __expf(logits[i] - mx);
     s = wave_sum(s);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) { float t = 0; for (int w = 0; w < 16; ++w) t += red[w]; ssum = t; }
-    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        part[2 * blockIdx.x] = mx;
+        part[2 * blockIdx.x + 1] = t;
+    }
+}
+__global__ __launch_bounds__(64) void lm_token_probs_kernel(const float* __restrict__ logits, int V, const float* __restrict__ part,
+                                                            const int* __restrict__ ids, int n, float* __restrict__ probs) {
+    const float pm = part[2 * threadIdx.x], ps = part[2 * threadIdx.x + 1];   // PROBS_SLICES == 64 lanes
+    const float mx = wave_max(pm);
+    const float contrib = (pm == -INFINITY) ? 0.0f : ps * __expf(pm - mx);
+    float tot = 0.0f;
+    for (int b = 0; b < PROBS_SLICES; ++b) tot += __shfl(contrib, b);   // slice order
     if (threadIdx.x < n) {
         const int id = ids[threadIdx.x];
-        probs[threadIdx.x] = (id >= 0 && id < V) ? __expf(logits[id] - mx) / ssum : 0.0f;
+        probs[threadIdx.x] = (id >= 0 && id < V) ? __expf(logits[id] - mx) / tot : 0.0f;
     }
 }
 
@@ -1402,7 +1418,7 @@ static int lm_common_init(rca_lm* h, const rca_tensor_t* ts, int nt) {
     if ((rc = lm_alloc((void**)&h->att_part, (size_t)(LM_MAXM / 2) * c.n_kv_heads * h->n_splits * 8 * 66 * 4)) != RCA_OK) return rc;
     h->logits_rows_cap = c.logits_all ? 64 : 1;
     if ((rc = lm_alloc((void**)&h->logits, (size_t)h->logits_rows_cap * c.vocab_size * 4)) != RCA_OK) return rc;
-    if ((rc = lm_alloc((void**)&h->probs_dev, 64 * 4)) != RCA_OK) return rc;
+    if ((rc = lm_alloc((void**)&h->probs_dev, (64 + 2 * PROBS_SLICES) * 4)) != RCA_OK) return rc;   // [64 probs][slice (max, sum) pairs]
     if ((rc = lm_alloc((void**)&h->probe_ids_dev, 64 * 4)) != RCA_OK) return rc;
     {
         const size_t kmax = (size_t)std::max(std::max(H, AO), c.ffn);
@@ -2177,7 +2193,8 @@ extern "C" int rca_lm_token_probs(rca_lm_t* h, const int32_t* token_ids, int32_t
     hipStream_t st = h->stream;
     RCA_HIP(hipMemcpyAsync(h->probe_ids_dev, token_ids, n * 4, hipMemcpyHostToDevice, st));
     const float* lg = h->logits + (long)(h->logits_rows - 1) * h->cfg.vocab_size;
-    lm_token_probs_kernel<<<1, 1024, 0, st>>>(lg, h->cfg.vocab_size, h->probe_ids_dev, n, h->probs_dev);
+    lm_softmax_slices_kernel<<<PROBS_SLICES, 1024, 0, st>>>(lg, h->cfg.vocab_size, h->probs_dev + 64);
+    lm_token_probs_kernel<<<1, 64, 0, st>>>(lg, h->cfg.vocab_size, h->probs_dev + 64, h->probe_ids_dev, n, h->probs_dev);
     RCA_LAUNCH_CHECK();
     RCA_HIP(hipMemcpyAsync(probs_out, h->probs_dev, n * 4, hipMemcpyDeviceToHost, st));
     RCA_HIP(hipStreamSynchronize(st));
