@@ -32,10 +32,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #define LM_GEMV_M 8        // largest pass served by the GEMV kernels; longer evals go through the MFMA prefill path
 #define LM_KSLICE 2048     // K handled by one workgroup pass of the GEMV
 #define LM_MAXSPLIT 4      // K splits (ffn 8192 / 2048)
-#define ATT_KEYS 256       // keys per attention workgroup
-#define ATT_WAVES 8        // waves per attention workgroup
-#define ATT_NIT 4          // groups of 8 keys per wave: ATT_WAVES * ATT_NIT * 8 == ATT_KEYS
-#define ATT_THREADS (64 * ATT_WAVES)
+#define ATT_KEYS 256       // keys per attention workgroup (8 waves x 32 keys)
 #define LM_GRAPH_BUCKETS 8  // 4, 8, ..., 256 splits, the last bucket = all of them
 #define SAMP_MAXK 256
 
@@ -531,238 +528,6 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const LmDevState* __restri
     }
 }
 
-// ------------------------------------------------------------------------------ decode attention
-// grid (nkv, n_splits, ceil(M/2)); workgroup = 4 waves, each wave one 64-key block of this split.
-// Rows r = mi*G + hq (two tokens x G query heads of this kv head), R = 2G <= 8.
-// partial layout: part[((pair*nkv + g)*n_splits + sp)*8 + r][66] = {m, l, o[64]}
-// Split-KV attention for a pair of tokens: grid (kv head, 256-key split, token pair), one wave per 64 keys.
-// lane <-> (key kq of each group of 8, 8-dim chunk dq) in BOTH phases, so K, V and q are each fetched with 16-byte
-// loads that are all in flight before the step state is read, scores are reduced over dq with three cross-lane
-// steps and land exactly where phase B needs the probabilities: no LDS until the 4-wave merge.
-// Split-KV attention for a pair of tokens: grid (kv head, 256-key split, token pair), 8 waves of 32 keys each (the
-// kernel is bound by the instruction stream of a wave, not by bytes: more, shorter waves).
-// lane <-> (key kq of each group of 8, 8-dim chunk dq) in BOTH phases, so K, V and q are each fetched with 16-byte
-// loads that are all in flight before the step state is read, scores are reduced over dq with three cross-lane
-// steps and land exactly where phase B needs the probabilities: no LDS until the 4-wave merge.
-template <int G>
-__global__ __launch_bounds__(ATT_THREADS) void lm_attn_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ qkv,
-                                                      const f16_t* __restrict__ kc, const f16_t* __restrict__ vc,
-                                                      float* __restrict__ part, int nh, int nkv, int n_splits, float scale, int n_ctx) {
-    constexpr int HD = 64;
-    constexpr int R = 2 * G;
-    const int g = blockIdx.x, sp = blockIdx.y, pair = blockIdx.z;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int kbase = sp * ATT_KEYS;
-    const int kwb = kbase + wave * (8 * ATT_NIT);
-    const int kq = lane & 7, dq = lane >> 3;
-    const int m0 = pair * 2;
-    const int ld = (nh + 2 * nkv) * HD;
-    // Nothing below depends on the step state: rows past the visible range are clamped to the cache and masked.
-    u32x4 kreg[ATT_NIT], vreg[ATT_NIT];
-    f32x4 qreg[R][2];
-#pragma unroll
-    for (int it = 0; it < ATT_NIT; ++it) {
-        const long row = ((long)min(kwb + it * 8 + kq, n_ctx - 1) * nkv + g) * HD + dq * 8;
-        kreg[it] = *reinterpret_cast<const u32x4*>(kc + row);
-        vreg[it] = *reinterpret_cast<const u32x4*>(vc + row);
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const f32x4* q = reinterpret_cast<const f32x4*>(qkv + (long)(m0 + r / G) * ld + (g * G + r % G) * HD + dq * 8);
-        qreg[r][0] = q[0];
-        qreg[r][1] = q[1];
-    }
-    __builtin_amdgcn_sched_barrier(0);   // every load is issued here, not where the scheduler would first need it
-    // a (free) use on the exit paths keeps the optimiser from sinking the loads below the exits
-    auto pin_loads = [&]() {
-#pragma unroll
-        for (int c = 0; c < ATT_NIT; ++c) asm volatile("" ::"v"(kreg[c]), "v"(vreg[c]));
-#pragma unroll
-        for (int r = 0; r < R; ++r) asm volatile("" ::"v"(qreg[r][0]), "v"(qreg[r][1]));
-    };
-    const int M = stt->m;
-    if (m0 >= M) { pin_loads(); return; }
-    const int pos0 = stt->n_tokens;
-    const int ntok = min(2, M - m0);
-    const int kmax = pos0 + m0 + ntok;  // keys [0, kmax) are visible to the last token of the pair
-    float* pout = part + ((long)(pair * nkv + g) * n_splits + sp) * 8 * 66;
-    if (kbase >= kmax) {  // nothing visible in this split
-        if (threadIdx.x < R) { pout[threadIdx.x * 66] = -INFINITY; pout[threadIdx.x * 66 + 1] = 0.0f; }
-        pin_loads();
-        return;
-    }
-    __shared__ float wm[ATT_WAVES][R], wl[ATT_WAVES][R];
-    __shared__ float wo[ATT_WAVES][R][HD];
-    // ---- phase A: 8-dim partial dot products, then the sum over the 8 dim chunks (lane bits 3..5)
-    float p[ATT_NIT][R];
-#pragma unroll
-    for (int it = 0; it < ATT_NIT; ++it) {
-        const u32x4 u = kreg[it];
-        const unsigned uw[4] = {u.x, u.y, u.z, u.w};
-        float kv[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f16x2 h2 = __builtin_bit_cast(f16x2, uw[j]);
-            kv[2 * j] = (float)h2.x;
-            kv[2 * j + 1] = (float)h2.y;
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float a = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a = __builtin_fmaf(qreg[r][0][j], kv[j], a);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a = __builtin_fmaf(qreg[r][1][j], kv[4 + j], a);
-            p[it][r] = a;
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < ATT_NIT; ++it)
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float a = p[it][r];
-            a += dpp_mov<DPP_ROR8>(a);   // dq ^ 1
-            float b = a, c = a;
-            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(b), "+v"(c));   // dq ^ 2
-            a = b + c;
-            b = a; c = a;
-            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(b), "+v"(c));   // dq ^ 4
-            p[it][r] = b + c;
-        }
-    // ---- softmax statistics of this wave's keys (every lane of a kq column holds the same scores)
-    float mrow[R], lrow[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int mi = r / G;
-        float mx = -INFINITY;
-#pragma unroll
-        for (int it = 0; it < ATT_NIT; ++it) {
-            const bool vis = (mi < ntok) && (kwb + it * 8 + kq <= pos0 + m0 + mi);
-            p[it][r] = vis ? p[it][r] * scale : -INFINITY;
-            mx = fmaxf(mx, p[it][r]);
-        }
-        mx = fmaxf(mx, dpp_mov<DPP_XOR1>(mx));
-        mx = fmaxf(mx, dpp_mov<DPP_XOR2>(mx));
-        mx = fmaxf(mx, dpp_mov<DPP_HALF_MIRROR>(mx));
-        float l = 0.0f;
-#pragma unroll
-        for (int it = 0; it < ATT_NIT; ++it) {
-            const float e = (mx == -INFINITY) ? 0.0f : __expf(p[it][r] - mx);
-            p[it][r] = e;
-            l += e;
-        }
-        l += dpp_mov<DPP_XOR1>(l);
-        l += dpp_mov<DPP_XOR2>(l);
-        l += dpp_mov<DPP_HALF_MIRROR>(l);
-        mrow[r] = mx;
-        lrow[r] = l;
-    }
-    // ---- phase B: same lane mapping, the probabilities are already in place
-    float o[R][8];
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[r][j] = 0.0f;
-#pragma unroll
-    for (int it = 0; it < ATT_NIT; ++it) {
-        const bool live = kwb + it * 8 + kq < kmax;   // rows past the visible range may hold anything (p is 0 there): zero them
-        const u32x4 u = vreg[it];
-        const unsigned uw[4] = {live ? u.x : 0u, live ? u.y : 0u, live ? u.z : 0u, live ? u.w : 0u};
-        float vv[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f16x2 h2 = __builtin_bit_cast(f16x2, uw[j]);
-            vv[2 * j] = (float)h2.x;
-            vv[2 * j + 1] = (float)h2.y;
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[r][j] = __builtin_fmaf(p[it][r], vv[j], o[r][j]);
-    }
-    // add the 8 keys of a group: butterfly over the low three lane bits
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float v = o[r][j];
-            v += dpp_mov<DPP_XOR1>(v);
-            v += dpp_mov<DPP_XOR2>(v);
-            v += dpp_mov<DPP_HALF_MIRROR>(v);
-            o[r][j] = v;
-        }
-    if (kq == 0) {
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) wo[wave][r][dq * 8 + j] = o[r][j];
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) { wm[wave][r] = mrow[r]; wl[wave][r] = lrow[r]; }
-    }
-    __syncthreads();
-    // ---- merge the waves, write the split partial
-    for (int i = threadIdx.x; i < R * HD; i += ATT_THREADS) {
-        const int r = i / HD, d = i - r * HD;
-        float mx = wm[0][r];
-#pragma unroll
-        for (int w = 1; w < ATT_WAVES; ++w) mx = fmaxf(mx, wm[w][r]);
-        float L = 0.0f, O = 0.0f;
-#pragma unroll
-        for (int w = 0; w < ATT_WAVES; ++w) {
-            const float f = (wm[w][r] == -INFINITY) ? 0.0f : __expf(wm[w][r] - mx);
-            L = __builtin_fmaf(wl[w][r], f, L);
-            O = __builtin_fmaf(wo[w][r][d], f, O);
-        }
-        pout[r * 66 + 2 + d] = O;
-        if (d == 0) { pout[r * 66] = mx; pout[r * 66 + 1] = L; }
-    }
-}
-// One wave per (token, head): lane <-> dim.  Split statistics are fetched lane <-> split (one round trip), the
-// accumulations run in split order like a serial loop, the O rows are fetched four splits at a time.
-// (Folding this into the attention kernel -- last-arriving workgroup merges -- was measured and rejected: the
-// agent-scope release/acquire it needs costs an L2 write-back + invalidate per workgroup, 17 us vs 9.6 + 4.7.)
-template <int G>
-__global__ __launch_bounds__(64) void lm_attn_combine_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ part,
-                                                             float* __restrict__ attn, int nh, int nkv, int n_splits) {
-    const int m = blockIdx.x / nh, head = blockIdx.x % nh;
-    if (m >= stt->m) return;
-    const int g = head / G, hq = head % G;
-    const int pair = m >> 1, mi = m & 1;
-    const int r = mi * G + hq;
-    const int d = threadIdx.x;
-    const int nsp = min(n_splits, (stt->n_tokens + m) / ATT_KEYS + 1);
-    const float* base = part + ((long)(pair * nkv + g) * n_splits) * 8 * 66 + r * 66;
-    float mx = -INFINITY;
-    for (int s0 = 0; s0 < nsp; s0 += 64) {
-        const int sp = s0 + d;
-        mx = fmaxf(mx, sp < nsp ? base[(long)sp * 8 * 66] : -INFINITY);
-    }
-    mx = wave_max(mx);
-    float L = 0.0f, O = 0.0f;
-    for (int s0 = 0; s0 < nsp; s0 += 64) {
-        const int spl = min(s0 + d, nsp - 1);
-        const float ml = base[(long)spl * 8 * 66], ll = base[(long)spl * 8 * 66 + 1];
-        const float fl = (ml == -INFINITY) ? 0.0f : __expf(ml - mx);
-        const int cnt = min(64, nsp - s0);
-        for (int j0 = 0; j0 < cnt; j0 += 4) {
-            float pv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pv[j] = base[(long)(s0 + min(j0 + j, cnt - 1)) * 8 * 66 + 2 + d];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j0 + j < cnt) {
-                    const float f = __shfl(fl, j0 + j), l = __shfl(ll, j0 + j);
-                    L = __builtin_fmaf(l, f, L);
-                    O = __builtin_fmaf(pv[j], f, O);
-                }
-            }
-        }
-    }
-    attn[(long)m * nh * 64 + head * 64 + d] = O / L;
-}
 
 // ------------------------------------------------------------------------- prefill: bf16 MFMA GEMM
 // Prefill tiles (up to 32 tokens per pass) run the projections on v_mfma_f32_32x32x16_bf16: weights are bf16
@@ -1564,6 +1329,254 @@ static void launch_gemv(rca_lm* h, int M, const bf16_t* W, const float* x, float
     }
 }
 
+// ------------------------------------------------------------------ attention on MFMA (decode steps and prefill tiles)
+// grid (kv head, 256-key split, block of 32 query rows); a query row is (token, q head of this kv head), 32 / G tokens
+// per block; 8 waves, each ONE block of 32 keys (so there is no online rescaling inside a wave):
+//   S^T = K (32 keys x 64 dims, fp16 straight from the cache) x Q^T  on v_mfma_f32_32x32x16_f16, Q split into fp16
+//         hi + lo (two MFMAs per 16 dims).  The result has lane <-> query row, registers <-> keys, so the softmax
+//         statistics are 16 in-lane values plus one cross-half exchange.
+//   O   = P x V: P goes in as the A operand exactly as it sits in registers (hi + lo fp16); the order of the
+//         contraction index is free as long as both operands agree, so V is read from an LDS-transposed copy
+//         vt[dim][key] in the key order P's registers have.
+// Then the 8 waves are merged and the split partial is written like the pairwise kernel does:
+// part[((qblock * nkv + g) * n_splits + split) * 32 + row][66] = {m, l, o[64]}, row = token_in_block * G + q_head.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#define ATTM_VT_PITCH 40     // fp16 per transposed-V row (32 keys + pad): 8-byte fragment reads stay aligned
+#define ATTM_LDS (8 * 32 * 64 * 4 + 2 * 8 * 32 * 4)   // wo (aliases vt) + wm + wl
+template <int G>
+__global__ __launch_bounds__(512) void lm_attn_mfma_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ qkv,
+                                                           const f16_t* __restrict__ kc, const f16_t* __restrict__ vc,
+                                                           float* __restrict__ part, int nh, int nkv, int n_splits, float scale, int n_ctx) {
+    constexpr int HD = 64;
+    constexpr int TPB = 32 / G;   // tokens per query block
+    extern __shared__ __attribute__((aligned(16))) float attm_lds[];
+    float (*wo)[32][HD] = reinterpret_cast<float (*)[32][HD]>(attm_lds);                        // [8][32][64]
+    _Float16 (*vt)[HD][ATTM_VT_PITCH] = reinterpret_cast<_Float16 (*)[HD][ATTM_VT_PITCH]>(attm_lds);   // [8][64][40], dead before wo is written
+    float (*wm)[32] = reinterpret_cast<float (*)[32]>(attm_lds + 8 * 32 * HD);
+    float (*wl)[32] = wm + 8;
+    const int g = blockIdx.x, sp = blockIdx.y, qb = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5, col = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kbase = sp * ATT_KEYS;
+    const int kwb = kbase + wave * 32;
+    const int t0 = qb * TPB;
+    const int tl = col / G, hq = col % G;
+    const int ld = (nh + 2 * nkv) * HD;
+    // every load that does not depend on the step state goes out first (rows past the visible range: clamped, masked)
+    u32x4 kf[4], vf[4];
+    f32x4 qf[4][2];
+    {
+        const long row = ((long)min(kwb + col, n_ctx - 1) * nkv + g) * HD + 8 * half;
+        const float* qp = qkv + (long)min(t0 + tl, LM_MAXM - 1) * ld + (g * G + hq) * HD + 8 * half;
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            kf[sub] = *reinterpret_cast<const u32x4*>(kc + row + 16 * sub);
+            vf[sub] = *reinterpret_cast<const u32x4*>(vc + row + 16 * sub);
+            qf[sub][0] = *reinterpret_cast<const f32x4*>(qp + 16 * sub);
+            qf[sub][1] = *reinterpret_cast<const f32x4*>(qp + 16 * sub + 4);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    auto pin_loads = [&]() {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) asm volatile("" ::"v"(kf[c]), "v"(vf[c]), "v"(qf[c][0]), "v"(qf[c][1]));
+    };
+    const int M = stt->m;
+    if (t0 >= M) { pin_loads(); return; }
+    const int pos0 = stt->n_tokens;
+    const int ntok = min(TPB, M - t0);
+    const int kmax = pos0 + t0 + ntok;   // keys [0, kmax) are visible to the last token of the block
+    float* pout = part + ((long)(qb * nkv + g) * n_splits + sp) * 32 * 66;
+    if (kbase >= kmax) {   // nothing visible in this split
+        if (threadIdx.x < 32) { pout[threadIdx.x * 66] = -INFINITY; pout[threadIdx.x * 66 + 1] = 0.0f; }
+        pin_loads();
+        return;
+    }
+    // ---- V block of this wave, transposed into LDS: vt[wave][dim][key]
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+        const f16x8 v8 = __builtin_bit_cast(f16x8, vf[sub]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vt[wave][8 * half + 16 * sub + j][col] = v8[j];
+    }
+    // ---- S^T = K Q^T (hi + lo)
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+        f16x8 qh, ql;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float q = j < 4 ? qf[sub][0][j] : qf[sub][1][j - 4];
+            const _Float16 h16 = (_Float16)q;
+            qh[j] = h16;
+            ql[j] = (_Float16)(q - (float)h16);
+        }
+        const f16x8 kfr = __builtin_bit_cast(f16x8, kf[sub]);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfr, qh, sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfr, ql, sacc, 0, 0, 0);
+    }
+    // ---- softmax statistics of this wave's 32 keys for query row `col`: registers are keys
+    const int qpos = pos0 + t0 + tl;
+    const bool qvalid = tl < ntok;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int key = kwb + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float sv = (qvalid && key <= qpos) ? sacc[r] * scale : -INFINITY;
+        sacc[r] = sv;
+        mx = fmaxf(mx, sv);
+    }
+    {
+        float a = mx, b = mx;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+        mx = fmaxf(a, b);
+    }
+    float lsum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float e = (mx == -INFINITY) ? 0.0f : __expf(sacc[r] - mx);
+        sacc[r] = e;
+        lsum += e;
+    }
+    {
+        float a = lsum, b = lsum;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+        lsum = a + b;
+    }
+    // P as the A operand of O = P V: registers 8i..8i+7 feed MFMA i (hi + lo fp16)
+    f16x8 ph[2], pl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float pv = sacc[8 * i + j];
+            const _Float16 h16 = (_Float16)pv;
+            ph[i][j] = h16;
+            pl[i][j] = (_Float16)(pv - (float)h16);
+        }
+    // vt[wave] is written and read by this wave only
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- O = P V: dims 32 * nt + col; slot j of MFMA i, half h is key 16 i + 4 h + 8 (j >> 2) + (j & 3)
+    f32x16 oacc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[nt][r] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const _Float16* vrow = &vt[wave][32 * nt + col][16 * i + 4 * half];
+            const f16x4 v0 = *reinterpret_cast<const f16x4*>(vrow);
+            const f16x4 v1 = *reinterpret_cast<const f16x4*>(vrow + 8);
+            // keys past the visible range may hold anything (their p is 0): zero them
+            f16x8 vb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int key = kwb + 16 * i + 4 * half + 8 * (j >> 2) + (j & 3);
+                const _Float16 x = j < 4 ? v0[j] : v1[j - 4];
+                vb[j] = key < kmax ? x : (_Float16)0.0f;
+            }
+            oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[i], vb, oacc[nt], 0, 0, 0);
+            oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl[i], vb, oacc[nt], 0, 0, 0);
+        }
+    }
+    __syncthreads();   // every wave is done with vt: wo may overwrite it
+    if (half == 0) { wm[wave][col] = mx; wl[wave][col] = lsum; }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wo[wave][(r & 3) + 8 * (r >> 2) + 4 * half][32 * nt + col] = oacc[nt][r];
+    __syncthreads();
+    // ---- merge the 8 waves, write the split partial
+    for (int i = threadIdx.x; i < 32 * HD; i += 512) {
+        const int r = i / HD, d = i - r * HD;
+        float m2 = wm[0][r];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) m2 = fmaxf(m2, wm[w][r]);
+        float L = 0.0f, O = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const float f = (wm[w][r] == -INFINITY) ? 0.0f : __expf(wm[w][r] - m2);
+            L = __builtin_fmaf(wl[w][r], f, L);
+            O = __builtin_fmaf(wo[w][r][d], f, O);
+        }
+        pout[r * 66 + 2 + d] = O;
+        if (d == 0) { pout[r * 66] = m2; pout[r * 66 + 1] = L; }
+    }
+}
+// merges the splits of lm_attn_mfma_kernel in split order: one wave per (token, head), lane <-> dim
+template <int G>
+__global__ __launch_bounds__(64) void lm_attn_mfma_combine_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ part,
+                                                                  float* __restrict__ attn, int nh, int nkv, int n_splits) {
+    constexpr int TPB = 32 / G;
+    const int m = blockIdx.x / nh, head = blockIdx.x % nh;
+    if (m >= stt->m) return;
+    const int g = head / G, hq = head % G;
+    const int qb = m / TPB, tl = m % TPB;
+    const int r = tl * G + hq;
+    const int d = threadIdx.x;
+    const int nsp = min(n_splits, (stt->n_tokens + m) / ATT_KEYS + 1);
+    const float* base = part + ((long)(qb * nkv + g) * n_splits) * 32 * 66 + r * 66;
+    const long sstride = 32L * 66;
+    float mx = -INFINITY;
+    for (int s0 = 0; s0 < nsp; s0 += 64) {
+        const int sp = s0 + d;
+        mx = fmaxf(mx, sp < nsp ? base[sp * sstride] : -INFINITY);
+    }
+    mx = wave_max(mx);
+    float L = 0.0f, O = 0.0f;
+    for (int s0 = 0; s0 < nsp; s0 += 64) {
+        const int spl = min(s0 + d, nsp - 1);
+        const float ml = base[spl * sstride], ll = base[spl * sstride + 1];
+        const float fl = (ml == -INFINITY) ? 0.0f : __expf(ml - mx);
+        const int cnt = min(64, nsp - s0);
+        for (int j0 = 0; j0 < cnt; j0 += 4) {
+            float pv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pv[j] = base[(s0 + min(j0 + j, cnt - 1)) * sstride + 2 + d];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j0 + j < cnt) {
+                    const float f = __shfl(fl, j0 + j), l = __shfl(ll, j0 + j);
+                    L = __builtin_fmaf(l, f, L);
+                    O = __builtin_fmaf(pv[j], f, O);
+                }
+            }
+        }
+    }
+    attn[(long)m * nh * 64 + head * 64 + d] = O / L;
+}
+
+// split attention on MFMA + merge of the splits, for the M tokens of the current pass
+static void launch_attention_mfma(rca_lm* h, int M, int nsp_launch, const f16_t* kc, const f16_t* vc, hipStream_t st) {
+    const rca_lm_config_t& c = h->cfg;
+    const int G = c.n_heads / c.n_kv_heads;
+    const float scale = 1.0f / sqrtf((float)c.head_dim);
+    dim3 agm(c.n_kv_heads, nsp_launch, cdiv(M * G, 32));
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)lm_attn_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTM_LDS);
+        (void)hipFuncSetAttribute((const void*)lm_attn_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTM_LDS);
+        (void)hipFuncSetAttribute((const void*)lm_attn_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTM_LDS);
+        attr_done = true;
+    }
+    if (G == 4) {
+        lm_attn_mfma_kernel<4><<<agm, 512, ATTM_LDS, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
+        lm_attn_mfma_combine_kernel<4><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
+    } else if (G == 2) {
+        lm_attn_mfma_kernel<2><<<agm, 512, ATTM_LDS, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
+        lm_attn_mfma_combine_kernel<2><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
+    } else {
+        lm_attn_mfma_kernel<1><<<agm, 512, ATTM_LDS, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
+        lm_attn_mfma_combine_kernel<1><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
+    }
+}
+
 // attention split blocks needed by a pass of m tokens on top of the current context
 static int lm_splits_needed(const rca_lm* h, int m) { return std::min(h->n_splits, (h->n_tokens + m + ATT_KEYS - 1) / ATT_KEYS); }
 
@@ -1576,7 +1589,6 @@ static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st, in
     const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim, F = c.ffn;
     const int G = c.n_heads / c.n_kv_heads;
     const int Mt = M <= 2 ? M : (M <= 4 ? 4 : 8);
-    const float scale = 1.0f / sqrtf((float)c.head_dim);
     const long ps = (long)LM_MAXM * H;
     const GemvPro nopro{nullptr, nullptr, nullptr, 0, 0, nullptr, 0.0f, 0};
     GemvRope rope{h->cos_t, h->sin_t, nullptr, nullptr, c.n_heads, c.n_kv_heads, c.n_ctx};
@@ -1603,17 +1615,7 @@ static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st, in
             launch_gemv<1, 2>(h, Mt, L.wqkv, nullptr, h->qkv, QKV, H, H, 1, 0, QKV, p1, rope, st);
         }
         if (np1) std::swap(cur, nxt);
-        dim3 ag(c.n_kv_heads, nsp_launch, (M + 1) / 2);
-        if (G == 4) {
-            lm_attn_kernel<4><<<ag, ATT_THREADS, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
-            lm_attn_combine_kernel<4><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
-        } else if (G == 2) {
-            lm_attn_kernel<2><<<ag, ATT_THREADS, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
-            lm_attn_combine_kernel<2><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
-        } else {
-            lm_attn_kernel<1><<<ag, ATT_THREADS, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
-            lm_attn_combine_kernel<1><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
-        }
+        launch_attention_mfma(h, M, nsp_launch, kc, vc, st);
         // O projection adds straight into the residual stream (one K slice: each output has a single writer)
         launch_gemv<0, 3>(h, Mt, L.wo, h->attn, cur, H, AO, AO, 1, 0, H, nopro, norope, st);
         if (Mt > 2) {
@@ -1886,7 +1888,6 @@ static int lm_enqueue_prefill_tile(rca_lm* h, int M, hipStream_t st, int nsp_lau
     const rca_lm_config_t& c = h->cfg;
     const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim, F = c.ffn;
     const int G = c.n_heads / c.n_kv_heads;
-    const float scale = 1.0f / sqrtf((float)c.head_dim);
     GemvRope rope{h->cos_t, h->sin_t, nullptr, nullptr, c.n_heads, c.n_kv_heads, c.n_ctx};
     const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     float* x = h->x;
@@ -1899,17 +1900,7 @@ static int lm_enqueue_prefill_tile(rca_lm* h, int M, hipStream_t st, int nsp_lau
         lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.attn_norm, h->xn, H, c.rms_eps);
         lm_split_bf16_kernel<<<dim3(cdiv(H, 256), M), 256, 0, st>>>(h->stt, h->xn, h->xh, h->xl, H);
         lm_gemm_mfma_kernel<GEMM_EPI_ROPE><<<QKV / 32, 256, 0, st>>>(h->stt, L.wqkv, h->xh, h->xl, QKV, H, h->qkv, QKV, nullptr, nullptr, rope);
-        dim3 ag(c.n_kv_heads, nsp_launch, (M + 1) / 2);
-        if (G == 4) {
-            lm_attn_kernel<4><<<ag, ATT_THREADS, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
-            lm_attn_combine_kernel<4><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
-        } else if (G == 2) {
-            lm_attn_kernel<2><<<ag, ATT_THREADS, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
-            lm_attn_combine_kernel<2><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
-        } else {
-            lm_attn_kernel<1><<<ag, ATT_THREADS, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
-            lm_attn_combine_kernel<1><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
-        }
+        launch_attention_mfma(h, M, nsp_launch, kc, vc, st);
         lm_split_bf16_kernel<<<dim3(cdiv(AO, 256), M), 256, 0, st>>>(h->stt, h->attn, h->xh, h->xl, AO);
         lm_gemm_mfma_kernel<GEMM_EPI_RESID><<<H / 32, 256, 0, st>>>(h->stt, L.wo, h->xh, h->xl, H, AO, x, H, nullptr, nullptr, norope);
         lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.ffn_norm, h->xn, H, c.rms_eps);
@@ -1927,13 +1918,13 @@ static int lm_enqueue_prefill_tile(rca_lm* h, int M, hipStream_t st, int nsp_lau
 static bool lm_can_gemm128(const rca_lm* h) {
     const rca_lm_config_t& c = h->cfg;
     const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim, F = c.ffn;
-    return c.head_dim == 64 && H % 128 == 0 && QKV % 128 == 0 && (2 * F) % 128 == 0 && AO % 32 == 0 && F % 32 == 0;
+    const int G = c.n_heads / c.n_kv_heads;
+    return c.head_dim == 64 && (G == 1 || G == 2 || G == 4) && H % 128 == 0 && QKV % 128 == 0 && (2 * F) % 128 == 0 && AO % 32 == 0 && F % 32 == 0;
 }
 static int lm_enqueue_prefill_tile128(rca_lm* h, int M, hipStream_t st, int nsp_launch) {
     const rca_lm_config_t& c = h->cfg;
     const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim, F = c.ffn;
     const int G = c.n_heads / c.n_kv_heads;
-    const float scale = 1.0f / sqrtf((float)c.head_dim);
     GemvRope rope{h->cos_t, h->sin_t, nullptr, nullptr, c.n_heads, c.n_kv_heads, c.n_ctx};
     const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     // Every GEMM is cut along k until ~512 workgroups are in flight (a workgroup's stage is one exposed HBM round
@@ -1955,17 +1946,7 @@ static int lm_enqueue_prefill_tile128(rca_lm* h, int M, hipStream_t st, int nsp_
         lm_split_bf16_kernel<<<dim3(cdiv(H, 256), M), 256, 0, st>>>(h->stt, h->xn, h->xh, h->xl, H);
         lm_gemm128_kernel<GEMM_EPI_ROPE><<<dim3(QKV / 128, sq), 256, G128_LDS, st>>>(h->stt, L.wqkv, h->xh, h->xl, QKV, H, H / sq, h->qkv, QKV, nullptr, nullptr, h->gpart, rope);
         if (sq > 1) lm_gemm128_epilogue_kernel<GEMM_EPI_ROPE><<<dim3(QKV / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sq, QKV, h->qkv, nullptr, nullptr, rope);
-        dim3 ag(c.n_kv_heads, nsp_launch, (M + 1) / 2);
-        if (G == 4) {
-            lm_attn_kernel<4><<<ag, ATT_THREADS, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
-            lm_attn_combine_kernel<4><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
-        } else if (G == 2) {
-            lm_attn_kernel<2><<<ag, ATT_THREADS, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
-            lm_attn_combine_kernel<2><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
-        } else {
-            lm_attn_kernel<1><<<ag, ATT_THREADS, 0, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
-            lm_attn_combine_kernel<1><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
-        }
+        launch_attention_mfma(h, M, nsp_launch, kc, vc, st);
         lm_split_bf16_kernel<<<dim3(cdiv(AO, 256), M), 256, 0, st>>>(h->stt, h->attn, h->xh, h->xl, AO);
         lm_gemm128_kernel<GEMM_EPI_RESID><<<dim3(H / 128, so), 256, G128_LDS, st>>>(h->stt, L.wo, h->xh, h->xl, H, AO, AO / so, x, H, nullptr, nullptr, h->gpart, norope);
         if (so > 1) lm_gemm128_epilogue_kernel<GEMM_EPI_RESID><<<dim3(H / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, so, H, x, nullptr, nullptr, norope);
