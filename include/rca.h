@@ -263,8 +263,9 @@ int rca_lm_mask_head_rows(rca_lm_t* h, int32_t row_begin, int32_t row_end);
 /* enable / disable hipGraph replay of the steady-state step (eager launches otherwise); tests and
  * bench compare the two */
 int rca_lm_set_graphs(rca_lm_t* h, int32_t enable);
-/* evals longer than 8 tokens (session prefill, KV recompute) run as 32-token tiles on bf16 MFMA with hi/lo-split
- * activations (default); 0 routes them through the 8-token GEMV chunks, which are bit-identical to decode */
+/* evals longer than 8 tokens (session prefill llamacpp_utils.py:145-161 via realtime_agent_v2.py:100, KV recompute
+ * :725-733) run as 128-token tiles on bf16 MFMA with hi/lo-split activations (default; logits within ~1e-3 of the
+ * decode path); 0 routes them through the 8-token GEMV chunks, which are bit-identical to decode */
 int rca_lm_set_mfma_prefill(rca_lm_t* h, int32_t enable);
 /* synchronise the handle's stream (timing) */
 int rca_lm_sync(rca_lm_t* h);

@@ -5,14 +5,15 @@
 // (codec_llama.py:178-206): a vanilla Llama (RMSNorm, RoPE, GQA attention, SwiGLU, untied
 // lm_head) evaluated by llama.cpp with 1-2 tokens per step (llamacpp_utils.py:145-161;
 // realtime_agent_v2.py:355).  Here:
-//   weights   bf16 in HBM, row-major [N][K], streamed once per step with non-temporal 16-B loads
-//   activations f32; every projection is a wave-per-row dot product with f32 accumulation
-//             (M <= 8 tokens per pass: the step is HBM-bound, ~3 GB of weights per step)
+//   weights   bf16 in HBM, row-major [N][K]
+//   decode    (1-8 tokens per pass) activations f32, every projection a wave-per-row-pair dot product with f32
+//             accumulation, weights streamed once per step with non-temporal 16-B loads: HBM-bound, ~3 GB per step
+//   prefill   (> 8 tokens) 128-token tiles on bf16 MFMA with hi/lo-split activations (lm_gemm128_kernel)
 //   KV cache  fp16 [layer][pos][kv_head][64] (llama.cpp's default cache type)
-//   attention split-KV decode kernel (256 keys per workgroup) + combine
-//   sampler   top-k radix select -> sorted candidates -> top-p/min-p/temperature -> inverse CDF
+//   attention one MFMA kernel for both: 256-key splits x blocks of 32 query rows, then a merge of the splits
+//   sampler   histogram -> candidate gather -> rank-by-counting top-k -> top-p/min-p/temperature -> inverse CDF
 //             with a counter-based RNG and a polynomial exp, all on the device
-//   the steady-state step (eval 1-2 tokens + sample) is captured once into a hipGraph; the KV
+//   the steady-state step (eval 1-2 tokens + sample) is captured once per context bucket into a hipGraph; the KV
 //   position, input ids and RNG counter live in device memory so the graph replays unchanged.
 #include <algorithm>
 #include <cmath>
