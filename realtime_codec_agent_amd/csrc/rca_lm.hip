@@ -189,7 +189,8 @@ __device__ __forceinline__ void lm_scale_row(float (&v)[4][8], float rstd, const
 __global__ __launch_bounds__(64) void lm_add_rmsnorm_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ xin,
                                                             float* __restrict__ xout, const float* __restrict__ parts, int nparts,
                                                             long part_stride, const float* __restrict__ w, float* __restrict__ xn,
-                                                            int K, float eps) {
+                                                            int K, float eps, bf16_t* __restrict__ hi = nullptr,
+                                                            bf16_t* __restrict__ lo = nullptr) {
     const int m = blockIdx.x;
     if (m >= stt->m) return;
     const int nchunk = K >> 3;
@@ -199,7 +200,28 @@ __global__ __launch_bounds__(64) void lm_add_rmsnorm_kernel(const LmDevState* __
     if (xout) lm_store_row(v, xout + (long)m * K, nchunk);
     const float rstd = lm_row_norm(v, nchunk, K, eps, [](int, int) {});
     lm_scale_row(v, rstd, w, nchunk);
-    lm_store_row(v, xn + (long)m * K, nchunk);
+    if (hi) {   // prefill tiles: the normalised row goes straight out as the bf16 hi + lo pair the MFMA GEMM reads
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int c = lane + 64 * it;
+            if (c < nchunk) {
+                unsigned ph[4], pl[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bf16_t h0 = f32_to_bf16_rne(v[it][2 * j]), h1 = f32_to_bf16_rne(v[it][2 * j + 1]);
+                    const bf16_t l0 = f32_to_bf16_rne(v[it][2 * j] - __uint_as_float((unsigned)h0 << 16));
+                    const bf16_t l1 = f32_to_bf16_rne(v[it][2 * j + 1] - __uint_as_float((unsigned)h1 << 16));
+                    ph[j] = (unsigned)h0 | ((unsigned)h1 << 16);
+                    pl[j] = (unsigned)l0 | ((unsigned)l1 << 16);
+                }
+                *reinterpret_cast<uint4*>(hi + (long)m * K + c * 8) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+                *reinterpret_cast<uint4*>(lo + (long)m * K + c * 8) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+            }
+        }
+    } else {
+        lm_store_row(v, xn + (long)m * K, nchunk);
+    }
 }
 
 // ------------------------------------------------------------------------------------ GEMV
@@ -1513,7 +1535,8 @@ __global__ __launch_bounds__(512) void lm_attn_mfma_kernel(const LmDevState* __r
 // merges the splits of lm_attn_mfma_kernel in split order: one wave per (token, head), lane <-> dim
 template <int G>
 __global__ __launch_bounds__(64) void lm_attn_mfma_combine_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ part,
-                                                                  float* __restrict__ attn, int nh, int nkv, int n_splits) {
+                                                                  float* __restrict__ attn, int nh, int nkv, int n_splits,
+                                                                  bf16_t* __restrict__ hi = nullptr, bf16_t* __restrict__ lo = nullptr) {
     constexpr int TPB = 32 / G;
     const int m = blockIdx.x / nh, head = blockIdx.x % nh;
     if (m >= stt->m) return;
@@ -1550,11 +1573,19 @@ __global__ __launch_bounds__(64) void lm_attn_mfma_combine_kernel(const LmDevSta
             }
         }
     }
-    attn[(long)m * nh * 64 + head * 64 + d] = O / L;
+    const float ov = O / L;
+    if (hi) {   // prefill tiles: the O-projection GEMM reads bf16 hi + lo
+        const bf16_t hb = f32_to_bf16_rne(ov);
+        hi[(long)m * nh * 64 + head * 64 + d] = hb;
+        lo[(long)m * nh * 64 + head * 64 + d] = f32_to_bf16_rne(ov - __uint_as_float((unsigned)hb << 16));
+    } else {
+        attn[(long)m * nh * 64 + head * 64 + d] = ov;
+    }
 }
 
 // split attention on MFMA + merge of the splits, for the M tokens of the current pass
-static void launch_attention_mfma(rca_lm* h, int M, int nsp_launch, const f16_t* kc, const f16_t* vc, hipStream_t st) {
+static void launch_attention_mfma(rca_lm* h, int M, int nsp_launch, const f16_t* kc, const f16_t* vc, hipStream_t st,
+                                  bf16_t* hi = nullptr, bf16_t* lo = nullptr) {
     const rca_lm_config_t& c = h->cfg;
     const int G = c.n_heads / c.n_kv_heads;
     const float scale = 1.0f / sqrtf((float)c.head_dim);
@@ -1568,13 +1599,13 @@ static void launch_attention_mfma(rca_lm* h, int M, int nsp_launch, const f16_t*
     }
     if (G == 4) {
         lm_attn_mfma_kernel<4><<<agm, 512, ATTM_LDS, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
-        lm_attn_mfma_combine_kernel<4><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
+        lm_attn_mfma_combine_kernel<4><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits, hi, lo);
     } else if (G == 2) {
         lm_attn_mfma_kernel<2><<<agm, 512, ATTM_LDS, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
-        lm_attn_mfma_combine_kernel<2><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
+        lm_attn_mfma_combine_kernel<2><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits, hi, lo);
     } else {
         lm_attn_mfma_kernel<1><<<agm, 512, ATTM_LDS, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
-        lm_attn_mfma_combine_kernel<1><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits);
+        lm_attn_mfma_combine_kernel<1><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits, hi, lo);
     }
 }
 
@@ -1943,16 +1974,13 @@ static int lm_enqueue_prefill_tile128(rca_lm* h, int M, hipStream_t st, int nsp_
         f16_t* kc = h->kc + (long)l * h->kv_layer_stride;
         f16_t* vc = h->vc + (long)l * h->kv_layer_stride;
         rope.kc = kc; rope.vc = vc;
-        lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.attn_norm, h->xn, H, c.rms_eps);
-        lm_split_bf16_kernel<<<dim3(cdiv(H, 256), M), 256, 0, st>>>(h->stt, h->xn, h->xh, h->xl, H);
+        lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.attn_norm, h->xn, H, c.rms_eps, h->xh, h->xl);
         lm_gemm128_kernel<GEMM_EPI_ROPE><<<dim3(QKV / 128, sq), 256, G128_LDS, st>>>(h->stt, L.wqkv, h->xh, h->xl, QKV, H, H / sq, h->qkv, QKV, nullptr, nullptr, h->gpart, rope);
         if (sq > 1) lm_gemm128_epilogue_kernel<GEMM_EPI_ROPE><<<dim3(QKV / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sq, QKV, h->qkv, nullptr, nullptr, rope);
-        launch_attention_mfma(h, M, nsp_launch, kc, vc, st);
-        lm_split_bf16_kernel<<<dim3(cdiv(AO, 256), M), 256, 0, st>>>(h->stt, h->attn, h->xh, h->xl, AO);
+        launch_attention_mfma(h, M, nsp_launch, kc, vc, st, h->xh, h->xl);
         lm_gemm128_kernel<GEMM_EPI_RESID><<<dim3(H / 128, so), 256, G128_LDS, st>>>(h->stt, L.wo, h->xh, h->xl, H, AO, AO / so, x, H, nullptr, nullptr, h->gpart, norope);
         if (so > 1) lm_gemm128_epilogue_kernel<GEMM_EPI_RESID><<<dim3(H / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, so, H, x, nullptr, nullptr, norope);
-        lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.ffn_norm, h->xn, H, c.rms_eps);
-        lm_split_bf16_kernel<<<dim3(cdiv(H, 256), M), 256, 0, st>>>(h->stt, h->xn, h->xh, h->xl, H);
+        lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.ffn_norm, h->xn, H, c.rms_eps, h->xh, h->xl);
         // SwiGLU epilogue writes the hi/lo split of h straight into the (ffn-wide) split buffers of the down projection:
         // it reads xh/xl [M][H] and writes [M][F] -- distinct regions are needed, so h goes to the second half of hbuf
         bf16_t* hh = reinterpret_cast<bf16_t*>(h->hbuf);
