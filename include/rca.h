@@ -51,6 +51,9 @@ typedef struct {
 
 const char* rca_last_error(void);
 int rca_device_count(int* n);
+/* hipDeviceSynchronize on `device`: the duplex profiler's fence before every timestamp (the reference's
+ * realtime_agent_profiler.py:30-38 takes its timestamps without one) */
+int rca_device_sync(int32_t device);
 const char* rca_version(void);
 
 /* ------------------------------------------------------------------ codec --

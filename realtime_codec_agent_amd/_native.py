@@ -113,7 +113,7 @@ _lib = None
 
 # every symbol include/rca.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
-    "rca_last_error", "rca_device_count", "rca_version",
+    "rca_last_error", "rca_device_count", "rca_device_sync", "rca_version",
     "rca_codec_create", "rca_codec_destroy", "rca_codec_hop", "rca_codec_num_frames",
     "rca_codec_encode", "rca_codec_encode_dev", "rca_codec_encode_windows_dev", "rca_codec_encode_chunk_range_dev",
     "rca_codec_decode", "rca_codec_decode_dev",

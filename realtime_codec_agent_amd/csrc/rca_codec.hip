@@ -1303,6 +1303,12 @@ static bool mfma_supported(int k, int s) {
 
 extern "C" const char* rca_last_error(void) { return g_err; }
 extern "C" const char* rca_version(void) { return "rca-hip 0.1 (gfx950)"; }
+extern "C" int rca_device_sync(int32_t device) {
+    RCA_HIP(hipSetDevice(device));
+    RCA_HIP(hipDeviceSynchronize());
+    return RCA_OK;
+}
+
 extern "C" int rca_device_count(int* n) {
     if (!n) return fail(RCA_ERR_ARG, "null");
     RCA_HIP(hipGetDeviceCount(n));
