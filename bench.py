@@ -80,11 +80,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # rehearsal hooks (not used by the driver): several ranks on ONE card over gloo exercise the N > 1 code path
+    # on a 1-GPU box -- RCA_BENCH_DEVICE pins every rank to that device, RCA_BENCH_BACKEND picks the backend
+    if os.environ.get("RCA_BENCH_DEVICE") is not None:
+        local_rank = int(os.environ["RCA_BENCH_DEVICE"])
+    backend = os.environ.get("RCA_BENCH_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
