@@ -227,6 +227,22 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
     const long n0 = (col_tile * 4 + wave) * NW;   // first column of this wave
     const int co0 = co_tile * MT;
     if (n0 >= Ncols) return;  // whole wave out of range (no barriers: safe)
+    // column -> (batch row, position) without a 64-bit division per lane: the wave's columns [n0 - 1, n0 + NW] start at
+    // a wave-uniform (b_base, t_base) and cross at most one row boundary when a row is longer than the window
+    const long n_base = n0 > 0 ? n0 - 1 : 0;
+    const long b_base = __builtin_amdgcn_readfirstlane((int)((unsigned)n_base / (unsigned)Lout));   // Ncols < 2^31 (host check)
+    const int t_base = (int)(n_base - b_base * Lout);
+    auto col_bt = [&](long n, long& bb, int& tt) {   // n_base <= n <= n_base + NW + 2
+        int dt = (int)(n - n_base) + t_base;
+        bb = b_base;
+        if (Lout >= NW + 3) {
+            if (dt >= Lout) { dt -= Lout; bb += 1; }
+        } else {
+            bb += dt / Lout;
+            dt = dt % Lout;
+        }
+        tt = dt;
+    };
 
     // ---- staging role: element e -> (slot, phase); fixed per lane, channel added per load
     unsigned s_goff[RE];   // element offset of x[b][0][t*S + p] (0 when the slot is outside the signal); < 2^32 by the host check
@@ -239,9 +255,9 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
         const long n = n0 - 1 + slot;
         s_ok[r] = e < E && n >= 0 && n < Ncols;
         s_loff[r] = e < E ? p * U + slot : -1;
-        const long nn = s_ok[r] ? n : 0;
-        const long b = nn / Lout;
-        const int t = (int)(nn - b * Lout);
+        const long nn = s_ok[r] ? n : n_base;
+        long b; int t;
+        col_bt(nn, b, t);
         if (TR && t >= Lin) s_ok[r] = false;   // column t0 = Lin exists (its x[t0-1] tap is valid) but has no x[t0]
         s_goff[r] = s_ok[r] ? (unsigned)(b * Cin * (long)Lin + (long)t * S + p) : 0u;
     }
@@ -253,9 +269,10 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
             const int e = lane + 64 * r;
             const int slot = e / S, p = e - slot * S;
             const long n = n0 - 1 + slot;
-            const long nn = s_ok[r] ? n : 0;
-            const long b = nn / Lout;
-            const int i = (int)(nn - b * Lout) * S + p;  // PCM sample index == conv_in output index
+            const long nn = s_ok[r] ? n : n_base;
+            long b; int tq;
+            col_bt(nn, b, tq);
+            const int i = tq * S + p;  // PCM sample index == conv_in output index
             const float* row = fin.src.base + (long)(b % fin.src.C) * fin.src.chan_stride + (long)(b / fin.src.C) * fin.src.win_stride;
 #pragma unroll
             for (int kk = 0; kk < 7; ++kk) {
@@ -282,7 +299,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
 #pragma unroll
     for (int wn = 0; wn < WN; ++wn) {
         const long n = n0 + wn * 32 + (lane & 31);
-        const int t = (int)(n % Lout);
+        long bz; int t;
+        col_bt(n, bz, t);
         zmask[wn] = (t == 0 ? m_first : 0u) | (t == Lout - 1 ? m_last : 0u);
     }
 
@@ -423,8 +441,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
     for (int wn = 0; wn < WN; ++wn) {
         const long n = n0 + wn * 32 + (lane & 31);
         if (n >= Ncols) continue;
-        const long b = n / Lout;
-        const int t = (int)(n - b * Lout);
+        long b; int t;
+        col_bt(n, b, t);
         long ocol = t;
         long orow = Lout;
         if (TR) {   // phase r of column t0 lands on output sample s*t0 - padL + r
@@ -1591,7 +1609,8 @@ static int run_conv(rca_codec* h, const ConvLayer& L, const float* x, float* y, 
         RCA_LAUNCH_CHECK();
         return RCA_OK;
     }
-    if (L.tr && h->variant >= 1 && L.wp_tr && (double)B * L.cin * Lin < 4.0e9) return launch_convtr_mfma(L, x, y, B, Lin, slope, st);
+    // the MFMA kernels index the input with 32-bit element offsets and count columns in 31 bits
+    if (L.tr && h->variant >= 1 && L.wp_tr && (double)B * L.cin * Lin < 4.0e9 && (double)B * (Lin + 1) < 2.0e9) return launch_convtr_mfma(L, x, y, B, Lin, slope, st);
     if (L.tr) {
         const long total = (long)B * L.cout * Lin * L.s;
         convtr1d_chain_kernel<<<cdiv(total, 256), 256, 0, st>>>(x, L.w, L.b, y, B, L.cin, Lin, L.cout, L.k, L.s, L.pre, slope);
@@ -1602,7 +1621,7 @@ static int run_conv(rca_codec* h, const ConvLayer& L, const float* x, float* y, 
     const double cflops = 2.0 * L.cin * L.k * L.cout * (double)B * Lout;
     const double cbytes = 4.0 * ((double)B * L.cin * Lin + (double)B * L.cout * Lout + (double)L.cin * L.k * L.cout);
     // the MFMA kernel indexes the input with 32-bit element offsets
-    if (h->variant >= 1 && L.wp && !clamp_out && (double)B * L.cin * Lin < 4.0e9) {
+    if (h->variant >= 1 && L.wp && !clamp_out && (double)B * L.cin * Lin < 4.0e9 && (double)B * Lout < 2.0e9) {
         ProfScope ps(h, st, 0, cflops, cbytes);
         if (h->variant == 2 && try_conv_ws(L, x, y, B, Lin, Lout, slope, st, nullptr)) { RCA_LAUNCH_CHECK(); return RCA_OK; }
         if (L.k == 4 && L.s == 2) return launch_conv_mfma<4, 2, 4>(L, x, y, B, Lin, Lout, slope, st);
