@@ -276,3 +276,13 @@ def test_host_tail_calls_replay_as_graphs_and_survive_reallocation(hip_full, ful
     with pytest.raises(RcaError):
         hip_full.decode_tail(np.array([[0, 131072, 5]]), 320)
     assert hip_full.decode_tail(np.array([[0, 1, 5]]), 320).shape == (1, 320)
+
+
+def test_fuzz_tails_short():
+    """A few seconds of scripts/fuzz_tails.py: random window lengths / batch sizes / keep counts, host and device
+    entry points, both codec sizes, every case compared bit for bit with the full-window call."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_tails.py"), "6", "7"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "fuzz ok" in r.stdout
