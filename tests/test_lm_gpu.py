@@ -259,3 +259,14 @@ def test_gguf_model_path_gives_the_same_logits(tmp_path, rope):
         assert np.array_equal(a, b)
     else:   # inv_freq goes through one extra divide/multiply: last-bit differences in the RoPE table
         assert np.abs(a - b).max() < 1e-4
+
+
+def test_fuzz_lm_short():
+    """Half a minute of scripts/fuzz_lm.py on the ~1B model: random splits of random sequences into evals / graph steps /
+    eager steps (exact mode: bit-identical), random MFMA tilings (bit-identical to each other, within tolerance of exact),
+    rollback + re-eval, contexts across the 256-key split and graph-bucket boundaries."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_lm.py"), "20", "11"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "fuzz ok" in r.stdout
