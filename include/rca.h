@@ -263,6 +263,9 @@ int rca_lm_token_probs(rca_lm_t* h, const int32_t* token_ids, int32_t n, float* 
 /* zero lm_head rows [row_begin, row_end) (random-init bench models: keeps the sampler on codec tokens,
  * as a trained model in audio mode does; the bytes streamed per step are unchanged) */
 int rca_lm_mask_head_rows(rca_lm_t* h, int32_t row_begin, int32_t row_end);
+/* llama_cpp's logits_all after creation: 1 = keep the logits of every evaluated position (rca_lm_get_logits_row), 0 = last
+ * position only.  get_logprobs (llamacpp_utils.py:30-37) evaluates its long context with 0 and the scored tokens with 1. */
+int rca_lm_set_logits_all(rca_lm_t* h, int32_t enable);
 /* enable / disable hipGraph replay of the steady-state step (eager launches otherwise); tests and
  * bench compare the two */
 int rca_lm_set_graphs(rca_lm_t* h, int32_t enable);

@@ -2211,6 +2211,13 @@ extern "C" int rca_lm_token_probs(rca_lm_t* h, const int32_t* token_ids, int32_t
     return RCA_OK;
 }
 
+// switch between "logits of every evaluated position" (llama_cpp's logits_all) and "last position only"
+extern "C" int rca_lm_set_logits_all(rca_lm_t* h, int32_t enable) {
+    if (!h) return fail(RCA_ERR_ARG, "null");
+    h->cfg.logits_all = enable != 0;
+    return RCA_OK;
+}
+
 // test / bench knob: disable graph replay (eager launches) to compare
 extern "C" int rca_lm_set_graphs(rca_lm_t* h, int32_t enable) {
     if (!h) return fail(RCA_ERR_ARG, "null");

@@ -306,8 +306,16 @@ class LlamaForAlternatingCodeChannels:
         if not self._logits_all:
             raise N.RcaError("get_logprobs needs a handle created with logits_all=True")
         self.reset()
-        self.eval(ctx_input_ids)
-        last_ctx = self._scores[-1]
+        # only the LAST context position is scored: evaluate the context as a plain prefill (no per-position head
+        # GEMV, no [n_ctx_tokens, vocab] logits buffer), then the scored tokens with every position kept
+        N.check(self._lib.rca_lm_set_logits_all(self._h, 0), "rca_lm_set_logits_all")
+        self._logits_all = False
+        try:
+            self.eval(ctx_input_ids)
+            last_ctx = self._scores[-1].copy()
+        finally:
+            N.check(self._lib.rca_lm_set_logits_all(self._h, 1), "rca_lm_set_logits_all")
+            self._logits_all = True
         self.eval(input_ids)
         logits = np.concatenate([last_ctx[None, :], self._scores], axis=0)[-len(input_ids) - 1:-1]
         logprobs = self.logits_to_logprobs(logits)
