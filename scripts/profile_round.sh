@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. kernel trace + stats of the headline bench command (batch encode + duplex leg)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python3 $R/bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-trim-leg > $OUT/bench_stdout.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python3 $R/bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-trim-leg --duplex-secs 20 > $OUT/bench_stdout.log 2>&1
 # 2. kernel trace + stats of LM steps alone (ctx 1000, graph replay)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lm -- python3 $R/scripts/lm_profile.py 1000 50 > $OUT/lm_stdout.log 2>&1
 # 3. PMC pass (own run, kernel-trace only): MFMA busy, waits, clock, LDS conflicts
@@ -16,4 +16,6 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_A
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-duplex --no-trim-leg > $OUT/pmc_fetch_stdout.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-duplex --no-trim-leg > $OUT/pmc_write_stdout.log 2>&1
 python3 $R/scripts/summarize_profile.py $OUT > $OUT/SUMMARY.txt 2>&1
+# the raw per-dispatch traces of the two --stats runs are large (gpurun merges at most 64 MiB back): keep the stats tables
+rm -f $OUT/bench/*/*kernel_trace.csv $OUT/lm/*/*kernel_trace.csv
 tail -60 $OUT/SUMMARY.txt
