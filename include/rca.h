@@ -263,6 +263,14 @@ int rca_lm_token_probs(rca_lm_t* h, const int32_t* token_ids, int32_t n, float* 
 /* zero lm_head rows [row_begin, row_end) (random-init bench models: keeps the sampler on codec tokens,
  * as a trained model in audio mode does; the bytes streamed per step are unchanged) */
 int rca_lm_mask_head_rows(rca_lm_t* h, int32_t row_begin, int32_t row_end);
+/* The reference's deployment step CodecLlamaForCausalLM.persist_codec_embeddings (codec_llama.py:178-206) for a checkpoint
+ * that still carries the frozen codec embedding and its projector (codec_llama.py:32-69): table row
+ * codec_vocab_start + i  <-  linear_2(gelu(linear_1(codec_embed[i]))), fp32 arithmetic, stored as bf16 (nearest even).
+ * Host pointers: codec_embed [n_codes, dim], w1 [hidden, dim], b1 [hidden], w2 [hidden, hidden], b2 [hidden];
+ * out_f32 (optional, [n_codes, hidden]) receives the rows before the 16-bit rounding.  One call per codebook. */
+int rca_lm_persist_codec_embeddings(rca_lm_t* h, const float* codec_embed, int32_t n_codes, int32_t dim,
+                                    const float* w1, const float* b1, const float* w2, const float* b2,
+                                    int32_t codec_vocab_start, float* out_f32);
 /* llama_cpp's logits_all after creation: 1 = keep the logits of every evaluated position (rca_lm_get_logits_row), 0 = last
  * position only.  get_logprobs (llamacpp_utils.py:30-37) evaluates its long context with 0 and the scored tokens with 1. */
 int rca_lm_set_logits_all(rca_lm_t* h, int32_t enable);

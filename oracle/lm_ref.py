@@ -171,6 +171,16 @@ def random_weights(cfg, seed: int, init_std: float = 0.02) -> Dict[str, np.ndarr
     return w
 
 
+# ------------------------------------------------------------------ codec-embedding projector
+def project_codec_embeddings(codec_embed: np.ndarray, w1: np.ndarray, b1: np.ndarray, w2: np.ndarray, b2: np.ndarray) -> np.ndarray:
+    """Rows that CodecLlamaForCausalLM.persist_codec_embeddings writes into the table (codec_llama.py:178-206):
+    linear_2(gelu(linear_1(e))) with the exact erf GELU (CodecLlamaMultiModalProjector, codec_llama.py:32-44), fp32."""
+    e = torch.from_numpy(np.asarray(codec_embed, np.float32))
+    h = torch.nn.functional.linear(e, torch.from_numpy(np.asarray(w1, np.float32)), torch.from_numpy(np.asarray(b1, np.float32)))
+    h = torch.nn.functional.gelu(h)
+    return torch.nn.functional.linear(h, torch.from_numpy(np.asarray(w2, np.float32)), torch.from_numpy(np.asarray(b2, np.float32))).numpy()
+
+
 # ------------------------------------------------------------------ sampler (C restatement)
 _lib = None
 

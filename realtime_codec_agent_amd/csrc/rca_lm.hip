@@ -2240,6 +2240,93 @@ extern "C" int rca_lm_mask_head_rows(rca_lm_t* h, int32_t row_begin, int32_t row
     return RCA_OK;
 }
 
+// ------------------------------------------------------------------------------------- persist_codec_embeddings
+// The reference's deployment step (codec_llama.py:178-206): every codec token's input embedding is the projector output
+// linear_2(gelu(linear_1(codec_embed[code]))) (codec_llama.py:32-44, exact erf GELU) and is baked into the plain embedding
+// table so the deployed model is a vanilla Llama.  Done here on the device for a checkpoint that still carries the frozen
+// codec embedding + projector: a small elementwise kernel for the 16 -> H layer, then an H x H f32 GEMM on
+// v_mfma_f32_32x32x2_f32 (code rows x features; one 32 x 32 tile per wave, operands straight from L2 -- a load-time
+// operation, 1.1 TFLOP for the 1B model), bias added and rounded to bf16 (nearest even) into the table rows.
+__global__ __launch_bounds__(256) void lm_codec_proj1_kernel(const float* __restrict__ e, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                             float* __restrict__ h1, int rows, int dim, int H) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)rows * H) return;
+    const int r = (int)(i / H), j = (int)(i - (long)r * H);
+    float acc = 0.0f;
+    for (int d = 0; d < dim; ++d) acc = __builtin_fmaf(w1[(long)j * dim + d], e[(long)r * dim + d], acc);
+    const float x = acc + b1[j];
+    h1[i] = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__global__ __launch_bounds__(256) void lm_codec_proj2_kernel(const float* __restrict__ h1, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                             bf16_t* __restrict__ table_rows, float* __restrict__ out_f32, int rows, int H) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r32 = lane & 31, hs = lane >> 5;
+    const int n0 = blockIdx.y * 32, f0 = (blockIdx.x * 4 + wave) * 32;
+    if (f0 >= H) return;
+    // A = h1 (code rows), B = w2 (feature rows), both contiguous along k; a lane takes 4 consecutive k of its row per 8-block
+    // (k half `hs`), so MFMA step s of a block multiplies k0+s (half 0) and k0+4+s (half 1): same pairing on both operands.
+    const float* ap = h1 + (long)min(n0 + r32, rows - 1) * H + hs * 4;
+    const float* bp = w2 + (long)min(f0 + r32, H - 1) * H + hs * 4;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int k0 = 0; k0 < H; k0 += 8) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(ap + k0);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bp + k0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+    }
+    const int f = f0 + r32;   // accumulator i of lane: code row 8*(i/4) + 4*hs + i%4, feature r32
+    if (f >= H) return;
+    const float bias = b2[f];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int n = n0 + 8 * (i / 4) + 4 * hs + (i & 3);
+        if (n < rows) {
+            const float v = acc[i] + bias;
+            table_rows[(long)n * H + f] = f32_to_bf16_rne(v);
+            if (out_f32) out_f32[(long)n * H + f] = v;
+        }
+    }
+}
+
+extern "C" int rca_lm_persist_codec_embeddings(rca_lm_t* h, const float* codec_embed, int32_t n_codes, int32_t dim, const float* w1,
+                                               const float* b1, const float* w2, const float* b2, int32_t codec_vocab_start, float* out_f32) {
+    if (!h || !codec_embed || !w1 || !b1 || !w2 || !b2) return fail(RCA_ERR_ARG, "persist_codec_embeddings: null argument");
+    const int H = h->cfg.hidden;
+    if (n_codes <= 0 || dim <= 0 || codec_vocab_start < 0 || (long)codec_vocab_start + n_codes > h->cfg.vocab_size)
+        return fail(RCA_ERR_ARG, "persist_codec_embeddings: rows [%d, %ld) are outside the vocabulary of %d", codec_vocab_start,
+                    (long)codec_vocab_start + n_codes, h->cfg.vocab_size);
+    if (H % 8) return fail(RCA_ERR_ARG, "persist_codec_embeddings: hidden size must be a multiple of 8");
+    RCA_HIP(hipSetDevice(h->device));
+    const int chunk = std::min<int>(n_codes, 8192);
+    float *de = nullptr, *dw1 = nullptr, *db1 = nullptr, *dw2 = nullptr, *db2 = nullptr, *dh1 = nullptr, *dout = nullptr;
+    auto free_all = [&]() { for (float* p : {de, dw1, db1, dw2, db2, dh1, dout}) if (p) (void)hipFree(p); };
+    auto up = [&](float** d, const float* src, size_t n) {
+        if (hipMalloc((void**)d, n * 4) != hipSuccess) return false;
+        return hipMemcpy(*d, src, n * 4, hipMemcpyHostToDevice) == hipSuccess;
+    };
+    if (!up(&de, codec_embed, (size_t)n_codes * dim) || !up(&dw1, w1, (size_t)H * dim) || !up(&db1, b1, H) || !up(&dw2, w2, (size_t)H * H) ||
+        !up(&db2, b2, H) || hipMalloc((void**)&dh1, (size_t)chunk * H * 4) != hipSuccess ||
+        (out_f32 && hipMalloc((void**)&dout, (size_t)chunk * H * 4) != hipSuccess)) {
+        free_all();
+        return fail(RCA_ERR_HIP, "persist_codec_embeddings: device allocation / upload failed");
+    }
+    for (int r0 = 0; r0 < n_codes; r0 += chunk) {
+        const int rows = std::min(chunk, n_codes - r0);
+        lm_codec_proj1_kernel<<<(unsigned)(((long)rows * H + 255) / 256), 256, 0, h->stream>>>(de + (long)r0 * dim, dw1, db1, dh1, rows, dim, H);
+        lm_codec_proj2_kernel<<<dim3((H + 127) / 128, (rows + 31) / 32), 256, 0, h->stream>>>(
+            dh1, dw2, db2, h->embed + ((long)codec_vocab_start + r0) * H, dout, rows, H);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess && out_f32) e = hipMemcpyAsync(out_f32 + (long)r0 * H, dout, (size_t)rows * H * 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) { free_all(); return fail(RCA_ERR_HIP, "persist_codec_embeddings: %s", hipGetErrorString(e)); }
+    }
+    free_all();
+    return RCA_OK;
+}
+
 // test / bench knob: route long evals through the exact GEMV chunks (0) or the bf16 MFMA prefill tiles (1, default)
 extern "C" int rca_lm_set_mfma_prefill(rca_lm_t* h, int32_t enable) {
     if (!h) return fail(RCA_ERR_ARG, "null");

@@ -100,6 +100,9 @@ def bf16_bits_to_f32(b: np.ndarray) -> np.ndarray:
     return (b.astype(np.uint32) << 16).view(np.float32)
 
 
+CODEC_PREFIX = "model.embed_codec_tokens."   # CodecLlamaCodecEmbedding's tensors (codec_llama.py:46-69)
+
+
 def lm_tensor_names(cfg: LMConfig) -> List[str]:
     names = ["model.embed_tokens.weight", "model.norm.weight", "lm_head.weight"]
     for l in range(cfg.n_layers):
@@ -142,6 +145,15 @@ def load_weights(model_path: str):
                         weights[k] = t.float().numpy()
     if "lm_head.weight" not in weights:  # tied checkpoints
         weights["lm_head.weight"] = weights["model.embed_tokens.weight"]
+    if CODEC_PREFIX + "codec_embed.weight" in weights:
+        # a CodecLlamaForCausalLM checkpoint saved BEFORE persist_codec_embeddings (codec_llama.py:178-206): the constructor
+        # bakes the projected codec embeddings into the table on the device
+        with open(os.path.join(d, "config.json")) as f:
+            hf = json.load(f)
+        if hf.get("projector_hidden_act", "gelu") != "gelu":
+            raise NotImplementedError(f"projector_hidden_act={hf['projector_hidden_act']!r}: only the reference default 'gelu' is built")
+        weights["codec.vocab_start"] = np.array(int(hf.get("codec_vocab_start", 0)))
+        weights["codec.codebook_size"] = np.array(int(hf.get("codebook_size", 131072)))
     return cfg, weights
 
 
@@ -209,11 +221,14 @@ class LlamaForAlternatingCodeChannels:
             N.check(self._lib.rca_lm_create_random(C.byref(c), C.c_uint64(random_seed), C.c_float(init_std), device, C.byref(self._h)),
                     "rca_lm_create_random")
         else:
-            w = dict(weights)
+            w = {k: v for k, v in weights.items() if not k.startswith((CODEC_PREFIX, "codec."))}
             w.setdefault("rope.inv_freq", rope_inv_freq(config))   # a GGUF brings the file's own frequencies
             tensors, keep = N.make_tensors(w)
             N.check(self._lib.rca_lm_create(C.byref(c), tensors, len(w), device, C.byref(self._h)), "rca_lm_create")
             del keep
+            if CODEC_PREFIX + "codec_embed.weight" in weights:   # un-persisted checkpoint: bake the projector output now
+                self.persist_codec_embeddings({k[len(CODEC_PREFIX):]: v for k, v in weights.items() if k.startswith(CODEC_PREFIX)},
+                                              int(weights["codec.vocab_start"]), int(weights.get("codec.codebook_size", 0)) or None)
         self._ctx = _Ctx(self)
         self._input_ids = np.zeros(self._n_ctx, dtype=np.intc)
         self.input_ids = self._input_ids
@@ -417,6 +432,34 @@ class LlamaForAlternatingCodeChannels:
     def mask_head_rows(self, row_begin: int, row_end: int) -> None:
         """Zero lm_head rows (random-init models: keep sampling on codec tokens like a trained model in audio mode)."""
         N.check(self._lib.rca_lm_mask_head_rows(self._h, int(row_begin), int(row_end)), "rca_lm_mask_head_rows")
+
+    def persist_codec_embeddings(self, codec_state: Dict[str, np.ndarray], codec_vocab_start: int, codebook_size: Optional[int] = None,
+                                 return_f32: bool = False) -> Optional[np.ndarray]:
+        """CodecLlamaForCausalLM.persist_codec_embeddings (codec_llama.py:178-206) on the device: table row
+        codec_vocab_start + i <- linear_2(gelu(linear_1(codec_embed[i]))), one projector per codebook (codec_llama.py:62-67).
+        `codec_state` holds CodecLlamaCodecEmbedding's tensors under their state-dict names ("codec_embed.weight",
+        "codebook_projectors.<i>.linear_{1,2}.{weight,bias}").  With return_f32 the rows are also returned before the
+        16-bit rounding (the reference's own check compares the table with the projector output, :206)."""
+        f32 = lambda a: np.ascontiguousarray(bf16_bits_to_f32(a) if a.dtype == np.uint16 else a, dtype=np.float32)
+        embed = f32(codec_state["codec_embed.weight"])
+        n_books = 1 + max(int(k.split(".")[1]) for k in codec_state if k.startswith("codebook_projectors."))
+        size = codebook_size or embed.shape[0] // n_books
+        if size * n_books != embed.shape[0]:
+            raise ValueError(f"codec_embed has {embed.shape[0]} rows, expected {n_books} codebooks of {size}")
+        out = np.empty((embed.shape[0], self.config.hidden), dtype=np.float32) if return_f32 else None
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        for i in range(n_books):
+            p = f"codebook_projectors.{i}."
+            w1, b1, w2, b2 = (f32(codec_state[p + s]) for s in ("linear_1.weight", "linear_1.bias", "linear_2.weight", "linear_2.bias"))
+            if w1.shape != (self.config.hidden, embed.shape[1]) or w2.shape != (self.config.hidden, self.config.hidden):
+                raise ValueError(f"projector {i}: linear_1 {w1.shape} / linear_2 {w2.shape} do not match hidden={self.config.hidden}, dim={embed.shape[1]}")
+            rows = np.ascontiguousarray(embed[i * size:(i + 1) * size])
+            dst = out[i * size:(i + 1) * size] if return_f32 else None
+            N.check(self._lib.rca_lm_persist_codec_embeddings(self._h, fp(rows), size, embed.shape[1], fp(w1), fp(b1), fp(w2), fp(b2),
+                                                              codec_vocab_start + i * size, fp(dst) if return_f32 else None),
+                    "rca_lm_persist_codec_embeddings")
+        self._logits_valid = False
+        return out
 
     def set_mfma_prefill(self, enable: bool) -> None:
         """Long evals on bf16 MFMA tiles (default) or on the exact 8-token GEMV chunks."""

@@ -94,8 +94,14 @@ def main():
 
         with torch.no_grad():
             logits_codec, _ = run(model, inputs_embeds=embed_merge(model, ids))
+            if tag == "default":   # the un-persisted pieces, for the on-device bake (rca_lm_persist_codec_embeddings)
+                for k, v in model.state_dict().items():
+                    if "embed_codec_tokens" in k:
+                        saved["c:" + k] = v.float().numpy().copy()
             # deployment step of the reference: bake projected codec embeddings into the table
             model.persist_codec_embeddings(batch_size=16, show_progress=False)
+            if tag == "default":   # the baked rows as the reference computed them (fp32, before any 16-bit storage)
+                saved["persist_rows_f32"] = model.model.embed_tokens.weight.data[100:164].float().numpy().copy()
             # the baked rows are fp32 projector outputs; the deployed GGUF stores them as 16-bit floats.
             # Round them to bf16 so the HIP LM (bf16 weights) holds exactly the table used here.
             model.model.embed_tokens.weight.data = to_bf16_representable(model.model.embed_tokens.weight.data)

@@ -261,6 +261,71 @@ def test_gguf_model_path_gives_the_same_logits(tmp_path, rope):
         assert np.abs(a - b).max() < 1e-4
 
 
+def _codec_state():
+    g = np.load(f"{GOLDEN}/lm_tiny.npz")
+    pre = "c:model.embed_codec_tokens."
+    return {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)}, g
+
+
+def test_persist_codec_embeddings_on_device():
+    """codec_llama.py:178-206 on the device: start from a table whose codec rows are zero, bake the projector output and
+    compare (a) the fp32 rows with the rows the reference's own persist_codec_embeddings produced (different summation
+    order, erf implementation: 2e-6 on values of magnitude ~1), (b) the table with the bf16 rounding of those rows -- the
+    reference's torch.equal check at :206 -- through bit-identical logits, (c) the logits with the reference fixture."""
+    from realtime_codec_agent_amd.llm import LlamaForAlternatingCodeChannels, f32_to_bf16_bits
+    state, g = _codec_state()
+    w, ids = tiny_weights()
+    blank = dict(w)
+    tbl = w["model.embed_tokens.weight"].copy()
+    tbl[100:164] = 0
+    blank["model.embed_tokens.weight"] = tbl
+    llm = LlamaForAlternatingCodeChannels(config=tiny_cfg("default"), weights=blank, n_ctx=512, device=0)
+    llm.set_mfma_prefill(False)
+    rows = llm.persist_codec_embeddings(state, codec_vocab_start=100, return_f32=True)
+    d = np.abs(rows - g["persist_rows_f32"]).max()
+    print(f"max|d| of the fp32 rows vs the reference's persist_codec_embeddings: {d:.2e} (max |row| {np.abs(rows).max():.2f})")
+    assert d < 2e-6
+    # the table now holds bf16(rows): same logits, bit for bit, as a model created with that table
+    baked = dict(w)
+    tbl2 = w["model.embed_tokens.weight"].copy()
+    tbl2[100:164] = f32_to_bf16_bits(rows)
+    baked["model.embed_tokens.weight"] = tbl2
+    ref = LlamaForAlternatingCodeChannels(config=tiny_cfg("default"), weights=baked, n_ctx=512, device=0)
+    ref.set_mfma_prefill(False)
+    llm.eval(ids.tolist()); ref.eval(ids.tolist())
+    assert np.array_equal(llm._scores[-1], ref._scores[-1])
+    assert np.abs(llm._scores[-1] - g["logits_full_default"][-1]).max() < TOL_REF
+    # bad arguments come back as errors, not faults
+    from realtime_codec_agent_amd._native import RcaError
+    with pytest.raises(RcaError):
+        llm.persist_codec_embeddings(state, codec_vocab_start=120)   # 120 + 64 > vocabulary 164
+    with pytest.raises(ValueError):
+        llm.persist_codec_embeddings({**state, "codebook_projectors.0.linear_2.weight": np.zeros((64, 64), np.float32)}, 100)
+
+
+def test_unpersisted_checkpoint_directory_loads(tmp_path):
+    """A CodecLlamaForCausalLM checkpoint saved before persist_codec_embeddings (config.json with codec_vocab_start +
+    safetensors carrying model.embed_codec_tokens.*) loads through model_path= and is baked on the way in."""
+    import json
+    from safetensors.numpy import save_file
+    from realtime_codec_agent_amd.llm import LlamaForAlternatingCodeChannels, bf16_bits_to_f32
+    state, g = _codec_state()
+    w, ids = tiny_weights()
+    cfg = tiny_cfg("default")
+    tensors = {k: np.ascontiguousarray(bf16_bits_to_f32(v) if v.dtype == np.uint16 else v, dtype=np.float32) for k, v in w.items()}
+    tensors["model.embed_tokens.weight"][100:164] = 0
+    tensors.update({"model.embed_codec_tokens." + k: np.ascontiguousarray(v, dtype=np.float32) for k, v in state.items()})
+    save_file(tensors, str(tmp_path / "model.safetensors"))
+    (tmp_path / "config.json").write_text(json.dumps(dict(
+        vocab_size=cfg.vocab_size, hidden_size=cfg.hidden, num_hidden_layers=cfg.n_layers, num_attention_heads=cfg.n_heads,
+        num_key_value_heads=cfg.n_kv_heads, head_dim=cfg.head_dim, intermediate_size=cfg.ffn, rms_norm_eps=cfg.rms_eps,
+        rope_theta=cfg.rope_theta, codec_vocab_start=100, codebook_size=64, codebook_dim=16, num_codebooks=1, projector_hidden_act="gelu")))
+    llm = LlamaForAlternatingCodeChannels(model_path=str(tmp_path), n_ctx=512, device=0)
+    llm.eval(ids.tolist())
+    assert np.abs(llm._scores[-1] - g["logits_full_default"][-1]).max() < TOL_REF
+    assert llm._scores[-1].argmax() == g["logits_full_default"][-1].argmax()
+
+
 def test_fuzz_lm_short():
     """Half a minute of scripts/fuzz_lm.py on the ~1B model: random splits of random sequences into evals / graph steps /
     eager steps (exact mode: bit-identical), random MFMA tilings (bit-identical to each other, within tolerance of exact),
