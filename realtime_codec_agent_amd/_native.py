@@ -101,7 +101,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc] + HIPCC_FLAGS + sources() + ["-o", LIB_PATH + ".tmp"]
+    extra = os.environ.get("RCA_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DRCA_CONV_TIMELINE (scripts/conv_timeline.py)
+    cmd = [hipcc] + HIPCC_FLAGS + extra + sources() + ["-o", LIB_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -18,6 +18,7 @@
 #include <array>
 #include <cmath>
 #include <map>
+#include <type_traits>
 
 #include "rca_common.h"
 
@@ -162,6 +163,16 @@ __global__ __launch_bounds__(256) void convtr1d_chain_kernel(const float* __rest
 // skips those taps).  v_mfma_f32_32x32x2_f32 is issued in ascending k into WM x WN accumulator
 // tiles; A operands (weights) come pre-packed in fragment order from L2
 // (wp[co_tile][kquad][lane][4]) and are prefetched one chunk ahead.
+// Optional per-wave timeline of conv1d_mfma_kernel (build with -DRCA_CONV_TIMELINE, run scripts/conv_timeline.py):
+// entry / first chunk staged / chunk loop done / stores issued, in wall_clock64 ticks (10 ns), plus the hardware slot.
+#ifdef RCA_CONV_TIMELINE
+__device__ long* rca_prof_buf = nullptr;
+#define RCA_TL_STAMP(v) const long v = rca_prof_buf ? (long)wall_clock64() : 0
+#define RCA_TL_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define RCA_TL_STAMP(v)
+#define RCA_TL_ADD(acc, a, b)
+#endif
 template <int S>
 struct ConvLds {
     // row stride U (in floats) for NT columns: NT + 2 halo slots, padded so that the S phase rows a
@@ -207,6 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
     static_assert((CIC * KS) % 8 == 0, "chunk must hold whole weight quads");
 
     extern __shared__ __attribute__((aligned(16))) float xs_all[];  // [4 waves][2][CIC][S][U]
+    RCA_TL_STAMP(tl0);
 
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
@@ -220,64 +232,82 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
     const long wg = blockIdx.x;
     const int xcd = (int)(wg & 7);
     const long seq = wg >> 3;
-    const int co_tile_x = (int)(seq % n_co);
+    const int co_tile_x = __builtin_amdgcn_readfirstlane((int)(seq % n_co));   // uniform, but the 64-bit division runs on the VALU: pin it to an SGPR
     const int phase = TR ? co_tile_x / n_co_real : 0;
     const int co_tile = TR ? co_tile_x % n_co_real : co_tile_x;
     const long col_tile = (seq / n_co) * 8 + xcd;
     const long n0 = (col_tile * 4 + wave) * NW;   // first column of this wave
     const int co0 = co_tile * MT;
     if (n0 >= Ncols) return;  // whole wave out of range (no barriers: safe)
-    // column -> (batch row, position) without a 64-bit division per lane: the wave's columns [n0 - 1, n0 + NW] start at
-    // a wave-uniform (b_base, t_base) and cross at most one row boundary when a row is longer than the window
+    // column -> (batch row, position): every column this wave touches is n_base + dn with 0 <= dn <= NW + 2, and the
+    // wave-uniform (b_base, t_base) of n_base turns that into 32-bit arithmetic (at most one row crossing when a row is
+    // longer than the window)
     const long n_base = n0 > 0 ? n0 - 1 : 0;
-    const long b_base = __builtin_amdgcn_readfirstlane((int)((unsigned)n_base / (unsigned)Lout));   // Ncols < 2^31 (host check)
-    const int t_base = (int)(n_base - b_base * Lout);
-    auto col_bt = [&](long n, long& bb, int& tt) {   // n_base <= n <= n_base + NW + 2
-        int dt = (int)(n - n_base) + t_base;
-        bb = b_base;
+    const int b_base = __builtin_amdgcn_readfirstlane((int)((unsigned)n_base / (unsigned)Lout));   // Ncols < 2^31 (host check)
+    const int t_base = (int)(n_base - (long)b_base * Lout);
+    const int lead = n0 > 0 ? 0 : 1;                            // staged slot 0 is column n0 - 1: absent for the very first wave
+    const long left = Ncols - n_base;
+    const int ncol_left = left > NW + 2 ? NW + 2 : (int)left;   // column n_base + dn exists for dn < ncol_left
+    auto rel_bt = [&](int dn, int& bb, int& tt) {
+        int dt = dn + t_base;
+        bb = 0;
         if (Lout >= NW + 3) {
-            if (dt >= Lout) { dt -= Lout; bb += 1; }
+            if (dt >= Lout) { dt -= Lout; bb = 1; }
         } else {
-            bb += dt / Lout;
-            dt = dt % Lout;
+            bb = dt / Lout;
+            dt -= bb * Lout;
         }
         tt = dt;
     };
 
-    // ---- staging role: element e -> (slot, phase); fixed per lane, channel added per load
-    unsigned s_goff[RE];   // element offset of x[b][0][t*S + p] (0 when the slot is outside the signal); < 2^32 by the host check
-    int s_loff[RE];    // p*U + slot; -1: lane past the window (its write lands in the spare word)
-    bool s_ok[RE];
+    // ---- staging role: element e -> (slot, phase); fixed per lane, channel added per load.  Loads go through a buffer
+    // descriptor over the wave's first batch row: a slot outside the signal carries an out-of-range offset and reads 0,
+    // so nothing has to be masked between the load and the LDS write.
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int RSRC_FLAGS = 0x00020000;
+    const __amdgpu_buffer_rsrc_t rs_x =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(FUSE ? fin.src.base : x + (long)b_base * Cin * Lin), 0, 0x7FFFFFFF, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_none = __builtin_amdgcn_make_buffer_rsrc((void*)(FUSE ? fin.src.base : x), 0, 0, RSRC_FLAGS);
+    unsigned s_boff[RE];   // byte offset of x[b][0][t*S + p] from row b_base (< 2^31 by the host check), or OOB
+    int s_loff[RE];        // p*U + slot; -1: lane past the window (its write lands in the spare word)
+    bool s_ok[FUSE ? RE : 1];
+    // ---- fused conv_in: 7-sample PCM window per staged element (zero outside the row's valid samples).  The two batch
+    // rows a wave can touch (b_base, b_base + 1: the host only fuses when a row is longer than the window) are addressed
+    // from the lower of their two PCM rows.
+    float pc[FUSE ? RE : 1][7];
+    __amdgpu_buffer_rsrc_t rs_pcm = rs_none;
+    unsigned prow[2] = {0u, 0u};
+    if (FUSE) {
+        const int C = fin.src.C;
+        const int c0 = b_base % C, w0 = b_base / C;
+        const int c1 = c0 + 1 == C ? 0 : c0 + 1, w1 = c0 + 1 == C ? w0 + 1 : w0;
+        const long o0 = (long)c0 * fin.src.chan_stride + (long)w0 * fin.src.win_stride;
+        const long o1 = (long)c1 * fin.src.chan_stride + (long)w1 * fin.src.win_stride;
+        const long om = o0 < o1 ? o0 : o1;
+        rs_pcm = __builtin_amdgcn_make_buffer_rsrc((void*)(fin.src.base + om), 0, 0x7FFFFFFF, RSRC_FLAGS);
+        prow[0] = (unsigned)(o0 - om);
+        prow[1] = (unsigned)(o1 - om);
+    }
 #pragma unroll
     for (int r = 0; r < RE; ++r) {
         const int e = lane + 64 * r;
         const int slot = e / S, p = e - slot * S;
-        const long n = n0 - 1 + slot;
-        s_ok[r] = e < E && n >= 0 && n < Ncols;
+        const int dn = slot - lead;
+        bool ok = e < E && dn >= 0 && dn < ncol_left;
+        int bb, t;
+        rel_bt(ok ? dn : 0, bb, t);
+        if (TR && t >= Lin) ok = false;   // column t0 = Lin exists (its x[t0-1] tap is valid) but has no x[t0]
         s_loff[r] = e < E ? p * U + slot : -1;
-        const long nn = s_ok[r] ? n : n_base;
-        long b; int t;
-        col_bt(nn, b, t);
-        if (TR && t >= Lin) s_ok[r] = false;   // column t0 = Lin exists (its x[t0-1] tap is valid) but has no x[t0]
-        s_goff[r] = s_ok[r] ? (unsigned)(b * Cin * (long)Lin + (long)t * S + p) : 0u;
-    }
-    // ---- fused conv_in: 7-sample PCM window per staged element (zero outside the row's valid samples)
-    float pc[FUSE ? RE : 1][7];
-    if (FUSE) {
-#pragma unroll
-        for (int r = 0; r < RE; ++r) {
-            const int e = lane + 64 * r;
-            const int slot = e / S, p = e - slot * S;
-            const long n = n0 - 1 + slot;
-            const long nn = s_ok[r] ? n : n_base;
-            long b; int tq;
-            col_bt(nn, b, tq);
-            const int i = tq * S + p;  // PCM sample index == conv_in output index
-            const float* row = fin.src.base + (long)(b % fin.src.C) * fin.src.chan_stride + (long)(b / fin.src.C) * fin.src.win_stride;
+        s_boff[r] = ok ? ((unsigned)bb * (unsigned)(Cin * Lin) + (unsigned)(t * S + p)) * 4u : OOB;
+        if (FUSE) {
+            s_ok[r] = ok;
+            const int i = t * S + p;  // PCM sample index == conv_in output index
+            const unsigned ro = bb ? prow[1] : prow[0];
 #pragma unroll
             for (int kk = 0; kk < 7; ++kk) {
                 const int j = i + kk - 3;
-                pc[r][kk] = (s_ok[r] && j >= 0 && j < fin.src.T) ? row[j] : 0.0f;
+                const unsigned off = (ok && j >= 0 && j < fin.src.T) ? (ro + (unsigned)j) * 4u : OOB;
+                pc[r][kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_pcm, off, 0, 0));
             }
         }
     }
@@ -296,24 +326,28 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
         if (q > 0) m_last |= 1u << kp;
     }
     unsigned zmask[WN];
+    unsigned zany = 0;
 #pragma unroll
     for (int wn = 0; wn < WN; ++wn) {
-        const long n = n0 + wn * 32 + (lane & 31);
-        long bz; int t;
-        col_bt(n, bz, t);
+        int bz, t;
+        rel_bt(1 - lead + wn * 32 + (lane & 31), bz, t);
         zmask[wn] = (t == 0 ? m_first : 0u) | (t == Lout - 1 ? m_last : 0u);
+        zany |= zmask[wn];
     }
+    // most waves hold no row edge: they run the MFMA block without the per-fragment edge selects
+    const bool edges = __builtin_amdgcn_ballot_w64(zany != 0) != 0;
 
+    // accumulators start at the bias; `bias` is padded to whole channel tiles, rows past Cout are never stored
     f32x16 acc[WM][WN];
 #pragma unroll
     for (int wm = 0; wm < WM; ++wm) {
-        const int cot = co0 + wm * 32;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = cot + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float bv = co < Cout ? bias[co] : 0.0f;
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(bias + co0 + wm * 32 + 8 * q + 4 * half);
 #pragma unroll
-            for (int wn = 0; wn < WN; ++wn) acc[wm][wn][r] = bv;
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int wn = 0; wn < WN; ++wn) acc[wm][wn][4 * q + j] = bq[j];
         }
     }
 
@@ -323,8 +357,6 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
 #pragma unroll
         for (int cl = 0; cl < CIC; ++cl) {
             const int ci = c * CIC + cl;
-            // branch-free: every lane loads from a valid address (slot outside the signal -> element 0) and the
-            // value is discarded at the LDS write.  Raw value only: nothing consumes it before the MFMA block.
             if (FUSE) {
                 const int cc = ci < Cin ? ci : 0;
                 const float* wr = fin.w_in + cc * 7;   // wave-uniform: scalar loads
@@ -338,9 +370,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
                     sreg[cl][r] = a;
                 }
             } else {
-                const float* xc = x + (long)(ci < Cin ? ci : 0) * Lin;
+                // raw value only: nothing consumes it before the MFMA block.  A channel past Cin (last chunk of a layer
+                // whose Cin is not a multiple of CIC) reads through the empty descriptor: zeros.
+                const __amdgpu_buffer_rsrc_t rs = ci < Cin ? rs_x : rs_none;
+                const int soff = (ci < Cin ? ci : 0) * Lin * 4;
 #pragma unroll
-                for (int r = 0; r < RE; ++r) sreg[cl][r] = xc[s_goff[r]];
+                for (int r = 0; r < RE; ++r) sreg[cl][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, s_boff[r], soff, 0));
             }
         }
     };
@@ -351,26 +386,32 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
             const bool cok = (c * CIC + cl) < Cin;
 #pragma unroll
             for (int r = 0; r < RE; ++r) {
-                float v = (s_ok[r] && cok) ? sreg[cl][r] : 0.0f;
+                float v = sreg[cl][r];
+                if (FUSE) v = (s_ok[r] && cok) ? v : 0.0f;   // computed, not loaded: slots outside the signal must hold 0
                 // LeakyReLU as max(v, slope*v): identical values for 0 < slope < 1 (incl. -0), two VALU ops
                 v = fmaxf(v, v * act_slope);
-                dst[s_loff[r] >= 0 ? cl * S * U + s_loff[r] : CIC * S * U] = v;
+                // only the last 64-element group can hold lanes past the window: one LDS address per r plus an immediate
+                if (64 * (r + 1) <= E || s_loff[r] >= 0) dst[cl * S * U + s_loff[r]] = v;
             }
         }
     };
 
     const long kquads = (long)nchunks * QPC;
-    auto load_w = [&](float4 (&a)[WM][QPC], int c) {
-#pragma unroll
-        for (int wm = 0; wm < WM; ++wm) {
-            const int cot = (TR ? phase * tr.n_co : 0) + co_tile * WM + wm;   // TR: tr.n_co 32-row tiles per phase
-            const float4* p = reinterpret_cast<const float4*>(wp) + ((long)cot * kquads + (long)c * QPC) * 64 + lane;
-#pragma unroll
-            for (int q = 0; q < QPC; ++q) a[wm][q] = p[q * 64];
-        }
+    // A fragments (weights), pre-packed in fragment order: quad q of chunk c for 32-row tile wm
+    auto w_ptr = [&](int wm, int c) {
+        const int cot = (TR ? phase * tr.n_co : 0) + co_tile * WM + wm;   // TR: tr.n_co 32-row tiles per phase
+        return reinterpret_cast<const float4*>(wp) + ((long)cot * kquads + (long)c * QPC) * 64 + lane;
     };
-    auto compute = [&](const float4 (&a)[WM][QPC], int buf) {
+    float4 a[WM][QPC];
+    // One chunk of MFMAs.  ONE set of weight fragments: as soon as the last k pair of quad q has been issued, the same
+    // registers are refilled with quad q of chunk `cn` (a full chunk of MFMAs, ~2 us, ahead of their next use), so the
+    // weights cost QPC x WM x 4 registers instead of twice that.
+    auto compute_t = [&](int buf, int cn, auto edge_tag) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
         const float* xb = xs + buf * BUF;
+        const float4* pn[WM];
+#pragma unroll
+        for (int wm = 0; wm < WM; ++wm) pn[wm] = w_ptr(wm, cn);
         // the B fragments of (half) a chunk are requested up front; the MFMAs then consume them in order
         // behind counted lgkmcnt waits, so the matrix pipe is not re-stalled on LDS latency every k step
         constexpr int NB = (KPC * WN > 32) ? ((KPC % 4 == 0) ? 4 : 2) : 1;  // register budget for the fragment prefetch
@@ -388,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
                 const int kp = nb * PB + i;
                 float bfr[WN];
 #pragma unroll
-                for (int wn = 0; wn < WN; ++wn) bfr[wn] = ((zmask[wn] >> kp) & 1u) ? 0.0f : bv[i][wn];
+                for (int wn = 0; wn < WN; ++wn) bfr[wn] = (EDGE && ((zmask[wn] >> kp) & 1u)) ? 0.0f : bv[i][wn];
 #pragma unroll
                 for (int wm = 0; wm < WM; ++wm) {
                     const float4 q4 = a[wm][kp >> 2];
@@ -397,15 +438,31 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
                     for (int wn = 0; wn < WN; ++wn)
                         acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bfr[wn], acc[wm][wn], 0, 0, 0);
                 }
+                if ((kp & 3) == 3) {
+#pragma unroll
+                    for (int wm = 0; wm < WM; ++wm) a[wm][kp >> 2] = pn[wm][(kp >> 2) * 64];
+                }
             }
         }
     };
+    auto compute = [&](int buf, int cn) __attribute__((always_inline)) {
+        if (edges) compute_t(buf, cn, std::true_type{});
+        else compute_t(buf, cn, std::false_type{});
+    };
 
-    float4 a0[WM][QPC], a1[WM][QPC];
     stage_load(0);
-    load_w(a0, 0);
+#pragma unroll
+    for (int wm = 0; wm < WM; ++wm) {
+        const float4* p0 = w_ptr(wm, 0);
+#pragma unroll
+        for (int q = 0; q < QPC; ++q) a[wm][q] = p0[q * 64];
+    }
     stage_write(0, 0);
     __builtin_amdgcn_wave_barrier();
+    RCA_TL_STAMP(tl1);
+#ifdef RCA_CONV_TIMELINE
+    long tl_load = 0, tl_mfma = 0, tl_write = 0;   // even chunks only: issue of the next loads / MFMA block / activation + LDS write
+#endif
     const int lastc = nchunks - 1;
     for (int c = 0; c < nchunks; c += 2) {
         // The next chunk's loads are issued UNCONDITIONALLY (past the end they re-read the last chunk and the
@@ -414,56 +471,87 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
         // sched_barrier(0) pins the three phases in program order so the scheduler does not sink the loads
         // down to their first use.
         const int c1 = min(c + 1, lastc);
-        load_w(a1, c1);
+        RCA_TL_STAMP(ta);
         stage_load(c1);
         __builtin_amdgcn_sched_barrier(0);
+        RCA_TL_STAMP(tb);
         __builtin_amdgcn_s_setprio(0);
-        compute(a0, 0);
+        compute(0, c1);
         __builtin_amdgcn_s_setprio(2);  // staging phases run at raised priority (measured +2.4 %)
         __builtin_amdgcn_sched_barrier(0);
+        RCA_TL_STAMP(tc);
         stage_write(c1, 1);
         __builtin_amdgcn_wave_barrier();
+        RCA_TL_STAMP(td);
+        RCA_TL_ADD(tl_load, ta, tb); RCA_TL_ADD(tl_mfma, tb, tc); RCA_TL_ADD(tl_write, tc, td);
         if (c + 1 >= nchunks) break;
         const int c2 = min(c + 2, lastc);
-        load_w(a0, c2);
         stage_load(c2);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(0);
-        compute(a1, 1);
+        compute(1, c2);
         __builtin_amdgcn_s_setprio(2);
         __builtin_amdgcn_sched_barrier(0);
         stage_write(c2, 0);
         __builtin_amdgcn_wave_barrier();
     }
 
-    // epilogue: C/D layout col = lane&31 (column), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel)
+    RCA_TL_STAMP(tl2);
+    // epilogue: C/D layout col = lane&31 (column), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel).  A store is
+    // (wave-uniform row pointer) + (per-lane 32-bit element offset): scalar address arithmetic only.
+    const long orow = TR ? tr.Lout : Lout;
+    const bool full_rows = co0 + MT <= Cout;
+    float* const yw = y + ((long)b_base * Cout + co0) * orow;
 #pragma unroll
     for (int wn = 0; wn < WN; ++wn) {
-        const long n = n0 + wn * 32 + (lane & 31);
-        if (n >= Ncols) continue;
-        long b; int t;
-        col_bt(n, b, t);
-        long ocol = t;
-        long orow = Lout;
+        const int dn = 1 - lead + wn * 32 + (lane & 31);
+        if (dn >= ncol_left) continue;
+        int bb, t;
+        rel_bt(dn, bb, t);
+        int ocol = t;
         if (TR) {   // phase r of column t0 lands on output sample s*t0 - padL + r
-            ocol = (long)tr.s * t - tr.padL + phase;
-            orow = tr.Lout;
-            if (ocol < 0 || ocol >= orow) continue;
+            ocol = tr.s * t - tr.padL + phase;
+            if (ocol < 0 || ocol >= (int)orow) continue;
         }
-        float* yb = y + b * Cout * orow + ocol;
+        // byte offset of (row bb, channel co0 + 4*half, column ocol) from yw: below 2^32 by the host check
+        const unsigned voff = ((unsigned)bb * (unsigned)(Cout * (int)orow) + (unsigned)ocol + (unsigned)(4 * half) * (unsigned)orow) * 4u;
+        if (full_rows) {
 #pragma unroll
-        for (int wm = 0; wm < WM; ++wm) {
-            const int cot = co0 + wm * 32;
+            for (int wm = 0; wm < WM; ++wm)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = cot + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (co < Cout) yb[(long)co * orow] = acc[wm][wn][r];
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int cu = wm * 32 + (r & 3) + 8 * (r >> 2);   // + 4*half, folded into voff
+                    char* const yr = reinterpret_cast<char*>(yw + (long)cu * orow);
+                    *reinterpret_cast<float*>(yr + voff) = acc[wm][wn][r];
+                }
+        } else {
+#pragma unroll
+            for (int wm = 0; wm < WM; ++wm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cu = wm * 32 + (r & 3) + 8 * (r >> 2);
+                    char* const yr = reinterpret_cast<char*>(yw + (long)cu * orow);
+                    if (co0 + cu + 4 * half < Cout) *reinterpret_cast<float*>(yr + voff) = acc[wm][wn][r];
+                }
         }
     }
+#ifdef RCA_CONV_TIMELINE
+    if (rca_prof_buf && lane == 0) {
+        const long tl3 = (long)wall_clock64();
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);    // HW_ID: wave slot, SIMD, CU, SE
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);   // XCC_ID
+        // one region of 65536 records per kernel size, indexed by wave: no atomics (a single counter serialises 64k waves)
+        constexpr int region = KS == 4 ? 0 : KS == 8 ? 1 : KS == 10 ? 2 : KS == 16 ? 3 : KS == 3 ? 4 : 5;
+        long* o = rca_prof_buf + ((long)region * 65536 + ((blockIdx.x * 4 + wave) & 0xFFFF)) * 8;
+        o[6] = tl_load | (tl_mfma << 32);
+        o[7] = tl_write | ((long)nchunks << 32);
+        o[0] = tl0; o[1] = tl1; o[2] = tl2; o[3] = tl3;
+        o[4] = (long)hw | ((long)xcc << 32);
+        o[5] = (long)KS | ((long)S << 8) | ((long)WM << 16) | ((long)wave << 24) | ((long)blockIdx.x << 32);
+    }
+#endif
 }
 
-// ------------------------------------------------ warp-specialised variant of the implicit-GEMM conv
 // Same GEMM view, LDS window layout, k order and results as conv1d_mfma_kernel, different division of
 // labour: a workgroup is 8 waves = 4 CONSUMERS (waves 0-3, one per SIMD) + 4 PRODUCERS (waves 4-7).
 // Consumer i owns a 64-channel x 64-column tile and does nothing but LDS fragment reads and
@@ -1172,6 +1260,7 @@ struct ConvLayer {
     int cin, cout, k, s, pre, tr;
     float* w = nullptr;     // original layout
     float* b = nullptr;
+    float* bp = nullptr;    // bias padded with zeros to whole channel tiles (16-byte loads in the MFMA kernel)
     float* wp = nullptr;    // MFMA-packed (encoder non-transposed layers with cin*k >= 32)
     int K = 0, Kpad = 0, cout_pad = 0, nchunks = 0;
     float* wp2 = nullptr;   // packing for the warp-specialised kernel (larger K chunks)
@@ -1334,12 +1423,27 @@ extern "C" int rca_device_count(int* n) {
 }
 
 extern "C" int rca_codec_destroy(rca_codec_t* h) {
+#ifdef RCA_CONV_TIMELINE
+    if (h && getenv("RCA_CONV_TIMELINE_OUT")) {   // dump the records for scripts/conv_timeline.py
+        long* b = nullptr;
+        unsigned n = 6 << 16;
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpyFromSymbol(&b, HIP_SYMBOL(rca_prof_buf), 8);
+        if (b) {
+            std::vector<long> host((size_t)(6 << 16) * 8);
+            (void)hipMemcpy(host.data(), b, host.size() * 8, hipMemcpyDeviceToHost);
+            if (FILE* f = fopen(getenv("RCA_CONV_TIMELINE_OUT"), "wb")) { fwrite(&n, 4, 1, f); fwrite(host.data(), 8, host.size(), f); fclose(f); }
+        }
+    }
+#endif
+
     if (!h) return RCA_OK;
     (void)hipSetDevice(h->device);
     for (auto* v : {&h->enc, &h->dec})
         for (auto& L : *v) {
             if (L.w) (void)hipFree(L.w);
             if (L.b) (void)hipFree(L.b);
+            if (L.bp) (void)hipFree(L.bp);
             if (L.wp) (void)hipFree(L.wp);
             if (L.wp2) (void)hipFree(L.wp2);
             if (L.wp_tr) (void)hipFree(L.wp_tr);
@@ -1406,6 +1510,14 @@ extern "C" int rca_codec_create(const rca_codec_config_t* cfg, const rca_tensor_
         L.cin = cin; L.cout = cout; L.k = k; L.s = s; L.pre = pre; L.tr = tr;
         if ((rc = upload(ts, nt, name + ".weight", (long)cin * cout * k, &L.w)) != RCA_OK) return rc;
         if ((rc = upload(ts, nt, name + ".bias", cout, &L.b)) != RCA_OK) { v.push_back(L); return rc; }
+        {
+            const size_t nb = ((size_t)cout + 127) / 128 * 128 + 64;
+            if (hipMalloc((void**)&L.bp, nb * 4) != hipSuccess || hipMemset(L.bp, 0, nb * 4) != hipSuccess ||
+                hipMemcpy(L.bp, L.b, (size_t)cout * 4, hipMemcpyDeviceToDevice) != hipSuccess) {
+                v.push_back(L);
+                return fail(RCA_ERR_HIP, "bias pad alloc");
+            }
+        }
         if (pack && !tr && mfma_supported(k, s)) {
             const rca_tensor_t* t = find_tensor(ts, nt, name + ".weight");
             if ((rc = pack_weights((const float*)t->data, L)) != RCA_OK) { v.push_back(L); return rc; }
@@ -1446,6 +1558,14 @@ extern "C" int rca_codec_create(const rca_codec_config_t* cfg, const rca_tensor_
         return bail(fail(RCA_ERR_HIP, "codebook alloc"));
     }
     (void)hipMemsetAsync(h->err_flag, 0, 4, h->stream);
+#ifdef RCA_CONV_TIMELINE
+    if (getenv("RCA_CONV_TIMELINE_OUT")) {
+        long* b = nullptr;
+        (void)hipMalloc((void**)&b, (size_t)(6 << 16) * 8 * 8);
+        (void)hipMemset(b, 0, (size_t)(6 << 16) * 8 * 8);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(rca_prof_buf), &b, 8);
+    }
+#endif
     // projected codebook + half norms are constants of the model: computed once (the reference
     // recomputes the projection on every decode call, audio_tokenizer.py:198)
     codebook_proj_kernel<<<cdiv((long)N * J, 256), 256, 0, h->stream>>>(raw, pw, pb, h->cb, N, R, J);
@@ -1488,7 +1608,7 @@ static void launch_conv_cfg(const ConvLayer& L, const float* wp, int nchunks, co
     // 1-D grid: column tiles padded to a multiple of 8 (one per XCD), times the channel tiles (times the phases)
     const long col_tiles = (cdiv(Ncols, NT) + 7) / 8 * 8;
     dim3 grid((unsigned)(col_tiles * cdiv(L.cout, MT) * (TR ? tr.s : 1)));
-    conv1d_mfma_kernel<KS, S, CIC, WM, WN, FUSE, TR><<<grid, 256, lds, st>>>(x, wp, L.b, y, L.cin, Lin, L.cout, Lc, Ncols, nchunks, L.pre, slope, fin, tr);
+    conv1d_mfma_kernel<KS, S, CIC, WM, WN, FUSE, TR><<<grid, 256, lds, st>>>(x, wp, L.bp, y, L.cin, Lin, L.cout, Lc, Ncols, nchunks, L.pre, slope, fin, tr);
 }
 
 template <int KS, int S, int CIC>
@@ -1610,7 +1730,9 @@ static int run_conv(rca_codec* h, const ConvLayer& L, const float* x, float* y, 
         return RCA_OK;
     }
     // the MFMA kernels index the input with 32-bit element offsets and count columns in 31 bits
-    if (L.tr && h->variant >= 1 && L.wp_tr && (double)B * L.cin * Lin < 4.0e9 && (double)B * (Lin + 1) < 2.0e9) return launch_convtr_mfma(L, x, y, B, Lin, slope, st);
+    // ... and addresses a wave's rows with 32-bit byte offsets from its first batch row (two rows of input / output at most)
+    const bool rows32 = (double)L.cin * Lin < 2.6e8 && (double)L.cout * Lin * (L.tr ? L.s : 1) < 2.6e8;
+    if (L.tr && h->variant >= 1 && L.wp_tr && rows32 && (double)B * L.cin * Lin < 4.0e9 && (double)B * (Lin + 1) < 2.0e9) return launch_convtr_mfma(L, x, y, B, Lin, slope, st);
     if (L.tr) {
         const long total = (long)B * L.cout * Lin * L.s;
         convtr1d_chain_kernel<<<cdiv(total, 256), 256, 0, st>>>(x, L.w, L.b, y, B, L.cin, Lin, L.cout, L.k, L.s, L.pre, slope);
@@ -1621,7 +1743,7 @@ static int run_conv(rca_codec* h, const ConvLayer& L, const float* x, float* y, 
     const double cflops = 2.0 * L.cin * L.k * L.cout * (double)B * Lout;
     const double cbytes = 4.0 * ((double)B * L.cin * Lin + (double)B * L.cout * Lout + (double)L.cin * L.k * L.cout);
     // the MFMA kernel indexes the input with 32-bit element offsets
-    if (h->variant >= 1 && L.wp && !clamp_out && (double)B * L.cin * Lin < 4.0e9 && (double)B * Lout < 2.0e9) {
+    if (h->variant >= 1 && L.wp && !clamp_out && rows32 && (double)B * L.cin * Lin < 4.0e9 && (double)B * Lout < 2.0e9) {
         ProfScope ps(h, st, 0, cflops, cbytes);
         if (h->variant == 2 && try_conv_ws(L, x, y, B, Lin, Lout, slope, st, nullptr)) { RCA_LAUNCH_CHECK(); return RCA_OK; }
         if (L.k == 4 && L.s == 2) return launch_conv_mfma<4, 2, 4>(L, x, y, B, Lin, Lout, slope, st);
@@ -1660,8 +1782,12 @@ static int run_encoder(rca_codec* h, RowSrc src, int B, hipStream_t st, float** 
     const ConvLayer& E0 = h->enc[0];
     const ConvLayer& E1 = h->enc[1];
     // conv_in fused into the first strided layer (MFMA variant, 7-tap conv_in, layer 0 not tapped)
+    // (the fused kernel addresses the PCM of the two batch rows a wave can touch with 32-bit offsets from the lower one,
+    //  and assumes a row is longer than a wave's window of columns)
     const bool fuse01 = !h->lat_mode && h->variant >= 1 && tap_layer != 0 && E0.k == 7 && E1.wp && E1.k == 2 * E1.s && (double)B * E1.cin * L < 4.0e9 &&
-                        ((E1.k == 4 && E1.s == 2) || (E1.k == 8 && E1.s == 4) || (E1.k == 16 && E1.s == 8));
+                        ((E1.k == 4 && E1.s == 2) || (E1.k == 8 && E1.s == 4) || (E1.k == 16 && E1.s == 8)) && L / E1.s >= 67 &&
+                        (double)E1.cout * (L / E1.s) < 2.6e8 &&
+                        (double)src.C * (double)std::labs(src.chan_stride) + (double)std::labs(src.win_stride) + src.T < 5.0e8;
     if (fuse01) {
         float* y = h->act[cur].as<float>();
         FuseIn fin{src, E0.w, E0.b};
