@@ -163,6 +163,23 @@ __global__ __launch_bounds__(256) void convtr1d_chain_kernel(const float* __rest
 // skips those taps).  v_mfma_f32_32x32x2_f32 is issued in ascending k into WM x WN accumulator
 // tiles; A operands (weights) come pre-packed in fragment order from L2
 // (wp[co_tile][kquad][lane][4]) and are prefetched one chunk ahead.
+// Buffer loads through a V# descriptor (base, num_records): a lane whose offset is >= num_records reads 0 without touching
+// memory.  The LLVM intrinsics are bound by name with float result types (this compiler folds the integer-vector forms,
+// __builtin_amdgcn_raw_buffer_load_b64 / .v2i32, into a single dword load).
+typedef int rca_rsrc_t __attribute__((ext_vector_type(4)));
+typedef float rca_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ float rca_buffer_load_f32(rca_rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ rca_f32x2_t rca_buffer_load_f32x2(rca_rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+__device__ __forceinline__ rca_rsrc_t rca_make_rsrc(const void* base, int num_records) {   // base must be wave-uniform
+    const unsigned long a = (unsigned long)base;
+    rca_rsrc_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xFFFF));   // stride 0: raw buffer
+    r[2] = num_records;
+    r[3] = 0x00020000;
+    return r;
+}
+
 // Optional per-wave timeline of conv1d_mfma_kernel (build with -DRCA_CONV_TIMELINE, run scripts/conv_timeline.py):
 // entry / first chunk staged / chunk loop done / stores issued, in wall_clock64 ticks (10 ns), plus the hardware slot.
 #ifdef RCA_CONV_TIMELINE
@@ -212,7 +229,10 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
     constexpr int KPC = CIC * KS / 2;      // k pairs per chunk
     constexpr int QPC = KPC / 4;           // float4 weight quads per chunk per co-tile
     constexpr int E = (NW + 2) * S;        // staged elements per input channel
-    constexpr int RE = (E + 63) / 64;      // per lane
+    // a lane stages PW consecutive elements per group: with an even stride two neighbours share their slot (phases p, p+1),
+    // never straddle a row or the signal edge, come from one 8-byte load and go to LDS in one ds_write2 (offsets 0, U)
+    constexpr int PW = (S % 2 == 0 && !TR) ? 2 : 1;
+    constexpr int RE = (E + 64 * PW - 1) / (64 * PW);   // groups per lane
     constexpr int padL = (KS - S + 1) / 2;
     constexpr int BUF = CIC * S * U + 4;   // + a spare word that absorbs the lanes past the window
     static_assert((CIC * KS) % 8 == 0, "chunk must hold whole weight quads");
@@ -264,18 +284,16 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
     // descriptor over the wave's first batch row: a slot outside the signal carries an out-of-range offset and reads 0,
     // so nothing has to be masked between the load and the LDS write.
     constexpr unsigned OOB = 0x80000000u;
-    constexpr int RSRC_FLAGS = 0x00020000;
-    const __amdgpu_buffer_rsrc_t rs_x =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(FUSE ? fin.src.base : x + (long)b_base * Cin * Lin), 0, 0x7FFFFFFF, RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t rs_none = __builtin_amdgcn_make_buffer_rsrc((void*)(FUSE ? fin.src.base : x), 0, 0, RSRC_FLAGS);
+    const rca_rsrc_t rs_x = rca_make_rsrc(FUSE ? fin.src.base : x + (long)b_base * Cin * Lin, 0x7FFFFFFF);
+    const rca_rsrc_t rs_none = rca_make_rsrc(FUSE ? fin.src.base : x, 0);
     unsigned s_boff[RE];   // byte offset of x[b][0][t*S + p] from row b_base (< 2^31 by the host check), or OOB
     int s_loff[RE];        // p*U + slot; -1: lane past the window (its write lands in the spare word)
     bool s_ok[FUSE ? RE : 1];
     // ---- fused conv_in: 7-sample PCM window per staged element (zero outside the row's valid samples).  The two batch
     // rows a wave can touch (b_base, b_base + 1: the host only fuses when a row is longer than the window) are addressed
     // from the lower of their two PCM rows.
-    float pc[FUSE ? RE : 1][7];
-    __amdgpu_buffer_rsrc_t rs_pcm = rs_none;
+    float pc[FUSE ? RE : 1][6 + PW];
+    rca_rsrc_t rs_pcm = rs_none;
     unsigned prow[2] = {0u, 0u};
     if (FUSE) {
         const int C = fin.src.C;
@@ -284,13 +302,13 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
         const long o0 = (long)c0 * fin.src.chan_stride + (long)w0 * fin.src.win_stride;
         const long o1 = (long)c1 * fin.src.chan_stride + (long)w1 * fin.src.win_stride;
         const long om = o0 < o1 ? o0 : o1;
-        rs_pcm = __builtin_amdgcn_make_buffer_rsrc((void*)(fin.src.base + om), 0, 0x7FFFFFFF, RSRC_FLAGS);
+        rs_pcm = rca_make_rsrc(fin.src.base + om, 0x7FFFFFFF);
         prow[0] = (unsigned)(o0 - om);
         prow[1] = (unsigned)(o1 - om);
     }
 #pragma unroll
     for (int r = 0; r < RE; ++r) {
-        const int e = lane + 64 * r;
+        const int e = PW * (lane + 64 * r);   // first element of the group
         const int slot = e / S, p = e - slot * S;
         const int dn = slot - lead;
         bool ok = e < E && dn >= 0 && dn < ncol_left;
@@ -304,10 +322,10 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
             const int i = t * S + p;  // PCM sample index == conv_in output index
             const unsigned ro = bb ? prow[1] : prow[0];
 #pragma unroll
-            for (int kk = 0; kk < 7; ++kk) {
+            for (int kk = 0; kk < 6 + PW; ++kk) {
                 const int j = i + kk - 3;
                 const unsigned off = (ok && j >= 0 && j < fin.src.T) ? (ro + (unsigned)j) * 4u : OOB;
-                pc[r][kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_pcm, off, 0, 0));
+                pc[r][kk] = rca_buffer_load_f32(rs_pcm, (int)off, 0, 0);
             }
         }
     }
@@ -351,8 +369,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
         }
     }
 
-    const float act_slope = pre ? slope : 1.0f;  // slope 1 = identity (no pre-activation)
-    float sreg[CIC][RE];
+    float sreg[CIC][RE][PW];
     auto stage_load = [&](int c) {
 #pragma unroll
         for (int cl = 0; cl < CIC; ++cl) {
@@ -362,38 +379,61 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
                 const float* wr = fin.w_in + cc * 7;   // wave-uniform: scalar loads
                 const float bi = fin.b_in[cc];
 #pragma unroll
-                for (int r = 0; r < RE; ++r) {
-                    float a = bi;
-                    // out-of-range taps hold 0: fma(w, 0, a) == a (the oracle skips them)
+                for (int r = 0; r < RE; ++r)
 #pragma unroll
-                    for (int kk = 0; kk < 7; ++kk) a = __builtin_fmaf(wr[kk], pc[r][kk], a);
-                    sreg[cl][r] = a;
-                }
+                    for (int j = 0; j < PW; ++j) {
+                        float a = bi;
+                        // out-of-range taps hold 0: fma(w, 0, a) == a (the oracle skips them)
+#pragma unroll
+                        for (int kk = 0; kk < 7; ++kk) a = __builtin_fmaf(wr[kk], pc[r][kk + j], a);
+                        sreg[cl][r][j] = a;
+                    }
             } else {
                 // raw value only: nothing consumes it before the MFMA block.  A channel past Cin (last chunk of a layer
                 // whose Cin is not a multiple of CIC) reads through the empty descriptor: zeros.
-                const __amdgpu_buffer_rsrc_t rs = ci < Cin ? rs_x : rs_none;
+                const rca_rsrc_t rs = ci < Cin ? rs_x : rs_none;
                 const int soff = (ci < Cin ? ci : 0) * Lin * 4;
 #pragma unroll
-                for (int r = 0; r < RE; ++r) sreg[cl][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, s_boff[r], soff, 0));
+                for (int r = 0; r < RE; ++r) {
+                    if (PW == 2) {
+                        const rca_f32x2_t v2 = rca_buffer_load_f32x2(rs, (int)s_boff[r], soff, 0);
+                        sreg[cl][r][0] = v2[0];
+                        sreg[cl][r][PW - 1] = v2[1];
+                    } else {
+                        sreg[cl][r][0] = rca_buffer_load_f32(rs, (int)s_boff[r], soff, 0);
+                    }
+                }
             }
         }
     };
-    auto stage_write = [&](int c, int buf) {
+    // pre-activation applied here (ACT) unless the layer that produced x already stored activated values
+    auto stage_write_t = [&](int c, int buf, auto act_tag) __attribute__((always_inline)) {
+        constexpr bool ACT = decltype(act_tag)::value;
         float* dst = xs + buf * BUF;
 #pragma unroll
         for (int cl = 0; cl < CIC; ++cl) {
             const bool cok = (c * CIC + cl) < Cin;
 #pragma unroll
             for (int r = 0; r < RE; ++r) {
-                float v = sreg[cl][r];
-                if (FUSE) v = (s_ok[r] && cok) ? v : 0.0f;   // computed, not loaded: slots outside the signal must hold 0
-                // LeakyReLU as max(v, slope*v): identical values for 0 < slope < 1 (incl. -0), two VALU ops
-                v = fmaxf(v, v * act_slope);
-                // only the last 64-element group can hold lanes past the window: one LDS address per r plus an immediate
-                if (64 * (r + 1) <= E || s_loff[r] >= 0) dst[cl * S * U + s_loff[r]] = v;
+                float v[PW];
+#pragma unroll
+                for (int j = 0; j < PW; ++j) {
+                    v[j] = sreg[cl][r][j];
+                    if (FUSE) v[j] = (s_ok[r] && cok) ? v[j] : 0.0f;   // computed, not loaded: slots outside the signal must hold 0
+                    // LeakyReLU as max(v, slope*v): identical values for 0 < slope < 1 (incl. -0), two VALU ops
+                    if (ACT) v[j] = fmaxf(v[j], v[j] * slope);
+                }
+                // only the last group can hold lanes past the window: one LDS address per group plus immediates
+                if (64 * PW * (r + 1) <= E || s_loff[r] >= 0) {
+#pragma unroll
+                    for (int j = 0; j < PW; ++j) dst[cl * S * U + s_loff[r] + j * U] = v[j];
+                }
             }
         }
+    };
+    auto stage_write = [&](int c, int buf) __attribute__((always_inline)) {
+        if (pre & 1) stage_write_t(c, buf, std::true_type{});
+        else stage_write_t(c, buf, std::false_type{});
     };
 
     const long kquads = (long)nchunks * QPC;
@@ -515,6 +555,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
         }
         // byte offset of (row bb, channel co0 + 4*half, column ocol) from yw: below 2^32 by the host check
         const unsigned voff = ((unsigned)bb * (unsigned)(Cout * (int)orow) + (unsigned)ocol + (unsigned)(4 * half) * (unsigned)orow) * 4u;
+        if (pre & 2) {   // the consumer of y is a pre-activated layer: store LeakyReLU(y) once here instead of re-applying it at every read
+#pragma unroll
+            for (int wm = 0; wm < WM; ++wm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[wm][wn][r] = fmaxf(acc[wm][wn][r], acc[wm][wn][r] * slope);
+        }
         if (full_rows) {
 #pragma unroll
             for (int wm = 0; wm < WM; ++wm)
@@ -1601,19 +1647,22 @@ extern "C" int rca_codec_sync(rca_codec_t* h) {
 
 template <int KS, int S, int CIC, int WM, int WN, int FUSE, int TR>
 static void launch_conv_cfg(const ConvLayer& L, const float* wp, int nchunks, const float* x, float* y, int Lin, int Lc, long Ncols,
-                            float slope, const FuseIn& fin, const TrInfo& tr, hipStream_t st) {
+                            float slope, const FuseIn& fin, const TrInfo& tr, hipStream_t st, int act) {
     constexpr int NT = 4 * WN * 32, MT = WM * 32;
     constexpr int lds = 4 * 2 * (CIC * S * ConvLds<S>::stride(WN * 32) + 4) * 4;
     static_assert(lds <= 65536, "LDS budget");
     // 1-D grid: column tiles padded to a multiple of 8 (one per XCD), times the channel tiles (times the phases)
     const long col_tiles = (cdiv(Ncols, NT) + 7) / 8 * 8;
     dim3 grid((unsigned)(col_tiles * cdiv(L.cout, MT) * (TR ? tr.s : 1)));
-    conv1d_mfma_kernel<KS, S, CIC, WM, WN, FUSE, TR><<<grid, 256, lds, st>>>(x, wp, L.bp, y, L.cin, Lin, L.cout, Lc, Ncols, nchunks, L.pre, slope, fin, tr);
+    conv1d_mfma_kernel<KS, S, CIC, WM, WN, FUSE, TR><<<grid, 256, lds, st>>>(x, wp, L.bp, y, L.cin, Lin, L.cout, Lc, Ncols, nchunks, act, slope, fin, tr);
 }
 
 template <int KS, int S, int CIC>
+// act: bit 0 = LeakyReLU on the input while staging (the layer's pre-activation), bit 1 = LeakyReLU on the output before the
+// store (the NEXT layer's pre-activation, applied once by the producer: same values, see run_encoder)
 static int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B, int Lin, int Lout, float slope, hipStream_t st,
-                            const FuseIn* fuse = nullptr) {
+                            const FuseIn* fuse = nullptr, int act = -1) {
+    if (act < 0) act = L.pre;
     const long Ncols = (long)B * Lout;
     // wave tile 64 channels x 64 columns while that still yields >= ~2 waves per SIMD on the chip,
     // otherwise 32 x 32 tiles (4x the waves; streaming / small batches)
@@ -1621,11 +1670,11 @@ static int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B,
     const FuseIn none{};
     const TrInfo notr{};
     if (fuse) {
-        if (waves_big >= 2048) launch_conv_cfg<KS, S, CIC, 2, 2, 1, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, *fuse, notr, st);
-        else launch_conv_cfg<KS, S, CIC, 1, 1, 1, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, *fuse, notr, st);
+        if (waves_big >= 2048) launch_conv_cfg<KS, S, CIC, 2, 2, 1, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, *fuse, notr, st, act);
+        else launch_conv_cfg<KS, S, CIC, 1, 1, 1, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, *fuse, notr, st, act);
     } else {
-        if (waves_big >= 2048) launch_conv_cfg<KS, S, CIC, 2, 2, 0, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, none, notr, st);
-        else launch_conv_cfg<KS, S, CIC, 1, 1, 0, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, none, notr, st);
+        if (waves_big >= 2048) launch_conv_cfg<KS, S, CIC, 2, 2, 0, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, none, notr, st, act);
+        else launch_conv_cfg<KS, S, CIC, 1, 1, 0, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, none, notr, st, act);
     }
     RCA_LAUNCH_CHECK();
     return RCA_OK;
@@ -1638,8 +1687,8 @@ static int launch_convtr_mfma(const ConvLayer& L, const float* x, float* y, int 
     const FuseIn none{};
     const TrInfo tr{L.s, (L.k - L.s + 1) / 2, Lin * L.s, L.cout_pad / 32};
     const long waves_big = (long)cdiv(Ncols, 64) * cdiv(L.cout, 64) * L.s;
-    if (L.cout > 32 && waves_big >= 2048) launch_conv_cfg<2, 1, 16, 2, 2, 0, 1>(L, L.wp_tr, L.nchunks_tr, x, y, Lin, Lc, Ncols, slope, none, tr, st);
-    else launch_conv_cfg<2, 1, 16, 1, 1, 0, 1>(L, L.wp_tr, L.nchunks_tr, x, y, Lin, Lc, Ncols, slope, none, tr, st);
+    if (L.cout > 32 && waves_big >= 2048) launch_conv_cfg<2, 1, 16, 2, 2, 0, 1>(L, L.wp_tr, L.nchunks_tr, x, y, Lin, Lc, Ncols, slope, none, tr, st, L.pre);
+    else launch_conv_cfg<2, 1, 16, 1, 1, 0, 1>(L, L.wp_tr, L.nchunks_tr, x, y, Lin, Lc, Ncols, slope, none, tr, st, L.pre);
     RCA_LAUNCH_CHECK();
     return RCA_OK;
 }
@@ -1723,8 +1772,22 @@ static bool try_conv_lds(rca_codec* h, const ConvLayer& L, const float* x, long 
     return false;
 }
 
-static int run_conv(rca_codec* h, const ConvLayer& L, const float* x, float* y, int B, int Lin, int clamp_out, hipStream_t st) {
+// true when run_conv sends this (non-transposed) layer to conv1d_mfma_kernel: the kernel indexes the input with 32-bit
+// element offsets, counts columns in 31 bits and addresses a wave's rows with 32-bit byte offsets from its first batch row
+static bool mfma_conv_ok(const rca_codec* h, const ConvLayer& L, int B, int Lin, int clamp_out) {
+    if (h->variant < 1 || L.tr || !L.wp || clamp_out || !mfma_supported(L.k, L.s)) return false;
+    const int Lout = Lin / L.s;
+    return (double)L.cin * Lin < 2.6e8 && (double)L.cout * Lin < 2.6e8 && (double)B * L.cin * Lin < 4.0e9 && (double)B * Lout < 2.0e9;
+}
+
+// in_activated: x already holds LeakyReLU(x) (the producer applied this layer's pre-activation); want_post: store
+// LeakyReLU(y) if the kernel that runs can (then *post_done = true and the consumer must be told its input is activated)
+static int run_conv(rca_codec* h, const ConvLayer& L, const float* x, float* y, int B, int Lin, int clamp_out, hipStream_t st,
+                    bool in_activated = false, bool want_post = false, bool* post_done = nullptr) {
     const float slope = h->cfg.leaky_slope;
+    if (post_done) *post_done = false;
+    if (in_activated && !(h->variant == 1 && !h->lat_mode && mfma_conv_ok(h, L, B, Lin, clamp_out)))
+        return fail(RCA_ERR_ARG, "internal: activated input handed to a kernel without that mode");
     if (h->lat_mode && try_conv_lds(h, L, x, (long)L.cin * Lin, Lin, y, B, Lin, clamp_out, st)) {
         RCA_LAUNCH_CHECK();
         return RCA_OK;
@@ -1743,15 +1806,18 @@ static int run_conv(rca_codec* h, const ConvLayer& L, const float* x, float* y, 
     const double cflops = 2.0 * L.cin * L.k * L.cout * (double)B * Lout;
     const double cbytes = 4.0 * ((double)B * L.cin * Lin + (double)B * L.cout * Lout + (double)L.cin * L.k * L.cout);
     // the MFMA kernel indexes the input with 32-bit element offsets
-    if (h->variant >= 1 && L.wp && !clamp_out && rows32 && (double)B * L.cin * Lin < 4.0e9 && (double)B * Lout < 2.0e9) {
+    if (mfma_conv_ok(h, L, B, Lin, clamp_out)) {
         ProfScope ps(h, st, 0, cflops, cbytes);
         if (h->variant == 2 && try_conv_ws(L, x, y, B, Lin, Lout, slope, st, nullptr)) { RCA_LAUNCH_CHECK(); return RCA_OK; }
-        if (L.k == 4 && L.s == 2) return launch_conv_mfma<4, 2, 4>(L, x, y, B, Lin, Lout, slope, st);
-        if (L.k == 8 && L.s == 4) return launch_conv_mfma<8, 4, 4>(L, x, y, B, Lin, Lout, slope, st);
-        if (L.k == 10 && L.s == 5) return launch_conv_mfma<10, 5, 4>(L, x, y, B, Lin, Lout, slope, st);
-        if (L.k == 16 && L.s == 8) return launch_conv_mfma<16, 8, 2>(L, x, y, B, Lin, Lout, slope, st);
-        if (L.k == 3 && L.s == 1) return launch_conv_mfma<3, 1, 8>(L, x, y, B, Lin, Lout, slope, st);
+        const int act = ((L.pre && !in_activated) ? 1 : 0) | (want_post ? 2 : 0);
+        if (post_done) *post_done = want_post;
+        if (L.k == 4 && L.s == 2) return launch_conv_mfma<4, 2, 4>(L, x, y, B, Lin, Lout, slope, st, nullptr, act);
+        if (L.k == 8 && L.s == 4) return launch_conv_mfma<8, 4, 4>(L, x, y, B, Lin, Lout, slope, st, nullptr, act);
+        if (L.k == 10 && L.s == 5) return launch_conv_mfma<10, 5, 4>(L, x, y, B, Lin, Lout, slope, st, nullptr, act);
+        if (L.k == 16 && L.s == 8) return launch_conv_mfma<16, 8, 2>(L, x, y, B, Lin, Lout, slope, st, nullptr, act);
+        if (L.k == 3 && L.s == 1) return launch_conv_mfma<3, 1, 8>(L, x, y, B, Lin, Lout, slope, st, nullptr, act);
     }
+    if (in_activated) return fail(RCA_ERR_ARG, "internal: activated input handed to a kernel without that mode");
     const long total = (long)B * L.cout * Lout;
     ProfScope ps(h, st, 3, cflops, cbytes);
     conv1d_chain_kernel<<<cdiv(total, 256), 256, 0, st>>>(x, L.w, L.b, y, B, L.cin, Lin, L.cout, Lout, L.k, L.s, L.pre, slope, clamp_out);
@@ -1788,6 +1854,13 @@ static int run_encoder(rca_codec* h, RowSrc src, int B, hipStream_t st, float** 
                         ((E1.k == 4 && E1.s == 2) || (E1.k == 8 && E1.s == 4) || (E1.k == 16 && E1.s == 8)) && L / E1.s >= 67 &&
                         (double)E1.cout * (L / E1.s) < 2.6e8 &&
                         (double)src.C * (double)std::labs(src.chan_stride) + (double)std::labs(src.win_stride) + src.T < 5.0e8;
+    // LeakyReLU hand-off: when layer li+1 is pre-activated and runs on conv1d_mfma_kernel, layer li stores LeakyReLU(y) and
+    // li+1 skips the activation while staging (max(v, slope*v) of the same value either way: bit-identical, but applied once
+    // per element instead of once per element per consuming workgroup per chunk).  Off when a layer output is tapped.
+    bool prev_post = false;
+    auto handoff = [&](size_t next, int Lnext) {
+        return tap_layer < 0 && h->variant == 1 && !h->lat_mode && next < h->enc.size() && h->enc[next].pre && mfma_conv_ok(h, h->enc[next], B, Lnext, 0);
+    };
     if (fuse01) {
         float* y = h->act[cur].as<float>();
         FuseIn fin{src, E0.w, E0.b};
@@ -1796,10 +1869,12 @@ static int run_encoder(rca_codec* h, RowSrc src, int B, hipStream_t st, float** 
         {
             ProfScope ps(h, st, 0, 2.0 * E1.cin * E1.k * E1.cout * (double)B * Lout + 2.0 * E0.k * E0.cout * (double)B * L,
                          4.0 * ((double)B * src.T + (double)B * E1.cout * Lout + (double)E1.cin * E1.k * E1.cout));
+            prev_post = handoff(2, Lout);
+            const int act = (E1.pre ? 1 : 0) | (prev_post ? 2 : 0);
             if (h->variant == 2 && try_conv_ws(E1, nullptr, y, B, L, Lout, slope, st, &fin)) { rc = RCA_OK; RCA_LAUNCH_CHECK(); }
-            else if (E1.k == 4) rc = launch_conv_mfma<4, 2, 4>(E1, nullptr, y, B, L, Lout, slope, st, &fin);
-            else if (E1.k == 8) rc = launch_conv_mfma<8, 4, 4>(E1, nullptr, y, B, L, Lout, slope, st, &fin);
-            else rc = launch_conv_mfma<16, 8, 2>(E1, nullptr, y, B, L, Lout, slope, st, &fin);
+            else if (E1.k == 4) rc = launch_conv_mfma<4, 2, 4>(E1, nullptr, y, B, L, Lout, slope, st, &fin, act);
+            else if (E1.k == 8) rc = launch_conv_mfma<8, 4, 4>(E1, nullptr, y, B, L, Lout, slope, st, &fin, act);
+            else rc = launch_conv_mfma<16, 8, 2>(E1, nullptr, y, B, L, Lout, slope, st, &fin, act);
         }
         if (rc != RCA_OK) return rc;
         L = Lout;
@@ -1823,7 +1898,9 @@ static int run_encoder(rca_codec* h, RowSrc src, int B, hipStream_t st, float** 
         const ConvLayer& Ly = h->enc[li];
         float* x = h->act[cur].as<float>();
         float* y = h->act[cur ^ 1].as<float>();
-        if ((rc = run_conv(h, Ly, x, y, B, L, 0, st)) != RCA_OK) return rc;
+        bool done = false;
+        if ((rc = run_conv(h, Ly, x, y, B, L, 0, st, prev_post, handoff(li + 1, L / Ly.s), &done)) != RCA_OK) return rc;
+        prev_post = done;
         L /= Ly.s;
         cur ^= 1;
         if (tap_layer == (int)li) RCA_HIP(hipMemcpyAsync(tap_dev, y, (size_t)B * Ly.cout * L * 4, hipMemcpyDeviceToDevice, st));
