@@ -96,12 +96,12 @@ def needs_build() -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc cross-compiles every HIP source for gfx950 into ONE in-tree shared library."""
-    if not force and not needs_build():
+    extra = os.environ.get("RCA_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DRCA_CONV_TIMELINE (scripts/conv_timeline.py)
+    if not force and not extra and not needs_build():
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    extra = os.environ.get("RCA_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DRCA_CONV_TIMELINE (scripts/conv_timeline.py)
     cmd = [hipcc] + HIPCC_FLAGS + extra + sources() + ["-o", LIB_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd))

@@ -184,7 +184,7 @@ __device__ __forceinline__ rca_rsrc_t rca_make_rsrc(const void* base, int num_re
 // entry / first chunk staged / chunk loop done / stores issued, in wall_clock64 ticks (10 ns), plus the hardware slot.
 #ifdef RCA_CONV_TIMELINE
 __device__ long* rca_prof_buf = nullptr;
-#define RCA_TL_STAMP(v) const long v = rca_prof_buf ? (long)wall_clock64() : 0
+#define RCA_TL_STAMP(v) const long v = tl_buf ? (long)wall_clock64() : 0   // tl_buf: the buffer pointer, read once per wave
 #define RCA_TL_ADD(acc, a, b) acc += (b) - (a)
 #else
 #define RCA_TL_STAMP(v)
@@ -238,6 +238,9 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
     static_assert((CIC * KS) % 8 == 0, "chunk must hold whole weight quads");
 
     extern __shared__ __attribute__((aligned(16))) float xs_all[];  // [4 waves][2][CIC][S][U]
+#ifdef RCA_CONV_TIMELINE
+    long* const tl_buf = rca_prof_buf;
+#endif
     RCA_TL_STAMP(tl0);
 
     const int lane = threadIdx.x & 63;
@@ -582,13 +585,13 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
         }
     }
 #ifdef RCA_CONV_TIMELINE
-    if (rca_prof_buf && lane == 0) {
+    if (tl_buf && lane == 0) {
         const long tl3 = (long)wall_clock64();
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);    // HW_ID: wave slot, SIMD, CU, SE
         const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);   // XCC_ID
         // one region of 65536 records per kernel size, indexed by wave: no atomics (a single counter serialises 64k waves)
         constexpr int region = KS == 4 ? 0 : KS == 8 ? 1 : KS == 10 ? 2 : KS == 16 ? 3 : KS == 3 ? 4 : 5;
-        long* o = rca_prof_buf + ((long)region * 65536 + ((blockIdx.x * 4 + wave) & 0xFFFF)) * 8;
+        long* o = tl_buf + ((long)region * 65536 + ((blockIdx.x * 4 + wave) & 0xFFFF)) * 8;
         o[6] = tl_load | (tl_mfma << 32);
         o[7] = tl_write | ((long)nchunks << 32);
         o[0] = tl0; o[1] = tl1; o[2] = tl2; o[3] = tl3;
