@@ -1667,16 +1667,19 @@ static int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B,
                             const FuseIn* fuse = nullptr, int act = -1) {
     if (act < 0) act = L.pre;
     const long Ncols = (long)B * Lout;
-    // wave tile 64 channels x 64 columns while that still yields >= ~2 waves per SIMD on the chip,
-    // otherwise 32 x 32 tiles (4x the waves; streaming / small batches)
+    // wave tile 64 channels x 64 columns (two waves per SIMD, most reuse per staged element) while that yields at least ~4
+    // rounds of workgroups on the chip's 512 slots; below that the last, partly filled round costs more than the reuse
+    // gains and 32 x 32 tiles win (4x the workgroups, 3-4 waves per SIMD): measured 1081 -> 992 us on the k16s8 layer of
+    // the 256-window step (896 workgroups of 64 x 64 tiles), 2x2 still ahead at 3360 (k10s5: 1137 vs 1169 us)
     const long waves_big = (long)cdiv(Ncols, 64) * cdiv(L.cout, 64);
+    constexpr long BIG_MIN = 8192;
     const FuseIn none{};
     const TrInfo notr{};
     if (fuse) {
-        if (waves_big >= 2048) launch_conv_cfg<KS, S, CIC, 2, 2, 1, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, *fuse, notr, st, act);
+        if (waves_big >= BIG_MIN) launch_conv_cfg<KS, S, CIC, 2, 2, 1, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, *fuse, notr, st, act);
         else launch_conv_cfg<KS, S, CIC, 1, 1, 1, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, *fuse, notr, st, act);
     } else {
-        if (waves_big >= 2048) launch_conv_cfg<KS, S, CIC, 2, 2, 0, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, none, notr, st, act);
+        if (waves_big >= BIG_MIN) launch_conv_cfg<KS, S, CIC, 2, 2, 0, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, none, notr, st, act);
         else launch_conv_cfg<KS, S, CIC, 1, 1, 0, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, none, notr, st, act);
     }
     RCA_LAUNCH_CHECK();
