@@ -389,6 +389,10 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
                         // out-of-range taps hold 0: fma(w, 0, a) == a (the oracle skips them)
 #pragma unroll
                         for (int kk = 0; kk < 7; ++kk) a = __builtin_fmaf(wr[kk], pc[r][kk + j], a);
+                        // computed, not loaded: the value is final here (zero outside the signal, pre-activation applied), so
+                        // the write phase after the MFMA block is LDS stores only
+                        a = (s_ok[r] && ci < Cin) ? a : 0.0f;
+                        if (pre & 1) a = fmaxf(a, a * slope);
                         sreg[cl][r][j] = a;
                     }
             } else {
@@ -415,16 +419,14 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
         float* dst = xs + buf * BUF;
 #pragma unroll
         for (int cl = 0; cl < CIC; ++cl) {
-            const bool cok = (c * CIC + cl) < Cin;
 #pragma unroll
             for (int r = 0; r < RE; ++r) {
                 float v[PW];
 #pragma unroll
                 for (int j = 0; j < PW; ++j) {
                     v[j] = sreg[cl][r][j];
-                    if (FUSE) v[j] = (s_ok[r] && cok) ? v[j] : 0.0f;   // computed, not loaded: slots outside the signal must hold 0
                     // LeakyReLU as max(v, slope*v): identical values for 0 < slope < 1 (incl. -0), two VALU ops
-                    if (ACT) v[j] = fmaxf(v[j], v[j] * slope);
+                    if (ACT && !FUSE) v[j] = fmaxf(v[j], v[j] * slope);
                 }
                 // only the last group can hold lanes past the window: one LDS address per group plus immediates
                 if (64 * PW * (r + 1) <= E || s_loff[r] >= 0) {

@@ -91,6 +91,34 @@ def test_decode_rejects_out_of_range(hip_tiny, tiny_codec):
     assert hip_tiny.decode(np.array([[0, 1]])).shape == (1, 640)
 
 
+def test_odd_channel_counts_and_big_batches_bit_exact():
+    """Shapes the two shipped configs do not reach in conv1d_mfma_kernel: channel counts that are not multiples of the K
+    chunk (the last chunk reads its missing channels through the empty buffer descriptor), outputs narrower than a 32-row
+    tile, and a batch large enough for the 64 x 64 wave tiles and the fused first layer of a small model (LeakyReLU handed
+    from producer to consumer, 8-byte paired staging).  Codes, every layer tap and the decode against the C oracle."""
+    from realtime_codec_agent_amd.codec import HipCodec
+    from realtime_codec_agent_amd.codec_model import init_codec_weights, tiny_codec_config
+    from oracle.codec import OracleCodec
+    cfg = tiny_codec_config(channels=(6, 10, 12, 20, 36), latent_dim=24, name="odd")
+    w = init_codec_weights(cfg, seed=3)
+    hip, oc = HipCodec(cfg, w, device=0), OracleCodec(cfg, w)
+    x = np.stack([rich_signal(6400, 20 + b) for b in range(3)])
+    for variant in (1, 2):
+        hip.set_variant(variant)
+        for layer in range(cfg.n_stages + 3):
+            _, want = oc.encode(x, tap_layer=layer)
+            assert np.array_equal(hip.encode_tap(x, layer), want), (variant, layer)
+        assert np.array_equal(hip.encode(x), oc.encode(x))
+    hip.set_variant(1)
+    big = np.stack([rich_signal(33600, 40 + b) for b in range(160)])   # 160 windows of 2.1 s: 64 x 64 tiles on the first layers
+    want = oc.encode(big[:6])
+    got = hip.encode(big)
+    assert np.array_equal(got[:6], want)
+    assert np.array_equal(got[154:], oc.encode(big[154:]))
+    codes = oc.encode(x)
+    assert np.abs(hip.decode(codes) - oc.decode(codes)).max() == 0.0
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2])
 def test_batch_windows_match_streaming_semantics(variant, hip_full, full_oracle):
     """rca_codec_encode_windows_dev == chunk-by-chunk tokenize_audio semantics (oracle.encode_windows)
