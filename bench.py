@@ -221,7 +221,7 @@ def main():
             "frac": achieved / F32_MFMA_PEAK_TFLOPS,
             # HBM bytes per launch of this kernel from the committed PMC passes (profiles/r01: FETCH_SIZE x2 per
             # the gfx950 note + WRITE_SIZE, separate rocprofv3 --pmc runs); algorithmic bytes for comparison
-            "traffic": 8.696e8,
+            "traffic": 1.026e9,
             "traffic_source": "profiles/r01/SUMMARY.txt (avg over the 5 conv launches of a step)",
             "algorithmic_bytes_per_launch": conv["bytes"] / max(1, conv["launches"]),
             "avg_launch_ms": conv["ms"] / max(1, conv["launches"]),

@@ -1671,10 +1671,13 @@ static int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B,
     const long Ncols = (long)B * Lout;
     // wave tile 64 channels x 64 columns (two waves per SIMD, most reuse per staged element) while that yields at least ~4
     // rounds of workgroups on the chip's 512 slots; below that the last, partly filled round costs more than the reuse
-    // gains and 32 x 32 tiles win (4x the workgroups, 3-4 waves per SIMD): measured 1081 -> 992 us on the k16s8 layer of
-    // the 256-window step (896 workgroups of 64 x 64 tiles), 2x2 still ahead at 3360 (k10s5: 1137 vs 1169 us)
+    // gains and smaller wave tiles win (more workgroups, 3-4 waves per SIMD).  Measured on the k16s8 layer of the 256-window
+    // step (896 workgroups of 64 x 64 tiles): 64x64 1081 us / 0.54 GB fetched, 32x64 991 us / 1.3 GB, 64x32 1071 us / 2.6 GB,
+    // 32x32 992 us / 3.3 GB -- every column tile streams the layer's 8.4 MB of weights through a 4 MB L2, so narrow
+    // column tiles multiply the fetches: 32 x 64 in the middle range, 32 x 32 only for small launches.  64x64 stays ahead
+    // at 3360 workgroups (k10s5: 1137 vs 1169 us).
     const long waves_big = (long)cdiv(Ncols, 64) * cdiv(L.cout, 64);
-    constexpr long BIG_MIN = 8192;
+    constexpr long BIG_MIN = 8192, MID_MIN = 2048;
     const FuseIn none{};
     const TrInfo notr{};
     if (fuse) {
@@ -1682,6 +1685,7 @@ static int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B,
         else launch_conv_cfg<KS, S, CIC, 1, 1, 1, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, *fuse, notr, st, act);
     } else {
         if (waves_big >= BIG_MIN) launch_conv_cfg<KS, S, CIC, 2, 2, 0, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, none, notr, st, act);
+        else if (waves_big >= MID_MIN) launch_conv_cfg<KS, S, CIC, 1, 2, 0, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, none, notr, st, act);
         else launch_conv_cfg<KS, S, CIC, 1, 1, 0, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, none, notr, st, act);
     }
     RCA_LAUNCH_CHECK();
