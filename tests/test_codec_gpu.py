@@ -119,6 +119,30 @@ def test_odd_channel_counts_and_big_batches_bit_exact():
     assert np.abs(hip.decode(codes) - oc.decode(codes)).max() == 0.0
 
 
+def test_chunk_range_of_a_very_long_signal_takes_the_unfused_path(hip_full):
+    """The fused first layer addresses the PCM of a wave's two batch rows with 32-bit offsets; a signal long enough to
+    break that (here 5.2e8 samples per channel: 9 hours) must fall back to the separate conv_in launch and still give
+    the codes of the same audio held in a short buffer."""
+    import torch
+    chunk, ctx, n_long = 1600, 32000, 520_000_000
+    head = 64 * chunk
+    audio = np.stack([rich_signal(head, 61)])
+    short = torch.from_numpy(audio).cuda()
+    long_buf = torch.empty(n_long, dtype=torch.float32, device="cuda")   # 2.1 GB, only the head is ever read
+    long_buf[:head] = short[0]
+    fpc = hip_full.frames_per_chunk(chunk)
+    st = torch.cuda.current_stream().cuda_stream
+    hip_full.set_variant(1)
+    outs = []
+    for buf, n in ((short, head), (long_buf, n_long)):
+        codes = torch.zeros((1, 40 * fpc), dtype=torch.int64, device="cuda")
+        hip_full.encode_chunk_range_dev(buf.data_ptr(), 1, n, chunk, ctx, 64, 20, 60, codes.data_ptr(), codes.shape[1], st)
+        torch.cuda.synchronize()
+        outs.append(codes.cpu().numpy())
+    del long_buf
+    assert np.array_equal(outs[0], outs[1]) and outs[0].max() > 0
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2])
 def test_batch_windows_match_streaming_semantics(variant, hip_full, full_oracle):
     """rca_codec_encode_windows_dev == chunk-by-chunk tokenize_audio semantics (oracle.encode_windows)
