@@ -149,20 +149,22 @@ __global__ __launch_bounds__(256) void convtr1d_chain_kernel(const float* __rest
 // K = Cin*KS walked ci-major / tap-minor in chunks of CIC input channels.
 //
 // Every WAVE is a self-contained pipeline over its own (WM*32 channels) x (WN*32 columns) tile: no
-// workgroup barrier anywhere.  Per chunk the wave (a) issues the global loads of the NEXT chunk's input
-// span and weight fragments, (b) runs the MFMA block of the current chunk from its private LDS
-// window, (c) writes the next window to LDS.  Other waves on the SIMD fill the matrix pipe while one
-// waits.
+// workgroup barrier anywhere.  Per chunk the wave (a) issues the loads of the NEXT chunk's input span,
+// (b) runs the MFMA block of the current chunk from its private LDS window, refilling its single set of
+// weight fragments quad by quad for the next chunk as it goes, (c) writes the next window to LDS.  The
+// other wave of the SIMD fills the matrix pipe while one stages.  Everything outside the MFMA blocks is
+// kept short on purpose: a non-MFMA instruction costs the SIMD about a quarter of an MFMA slot while the
+// neighbour streams MFMAs (measured with the RCA_CONV_TIMELINE stamps below).
 //
 // LDS sliding window (per wave): for every input channel of the chunk the contiguous input span of
-// the wave's columns is staged ONCE (coalesced loads, LeakyReLU fused at the LDS write),
-// de-interleaved by stride phase:  xs[ci][p][slot] = act(x[b][ci][t*S + p]) for the column (b,t) in
-// `slot` (one halo slot each side).  Tap kk of column j is xs[ci][(kk-padL) mod S][j + floor((kk-padL)/S)]:
-// consecutive lanes read consecutive LDS words (no bank conflicts, no im2col copy).  Reads that
-// would cross a window edge are zeroed by a per-lane bit mask (fma(w, 0, acc) == acc; the oracle
-// skips those taps).  v_mfma_f32_32x32x2_f32 is issued in ascending k into WM x WN accumulator
-// tiles; A operands (weights) come pre-packed in fragment order from L2
-// (wp[co_tile][kquad][lane][4]) and are prefetched one chunk ahead.
+// the wave's columns is staged ONCE (coalesced buffer loads; LeakyReLU at the LDS write unless the
+// producing layer already stored activated values), de-interleaved by stride phase:
+// xs[ci][p][slot] = act(x[b][ci][t*S + p]) for the column (b,t) in `slot` (one halo slot each side).
+// Tap kk of column j is xs[ci][(kk-padL) mod S][j + floor((kk-padL)/S)]: consecutive lanes read
+// consecutive LDS words (no bank conflicts, no im2col copy).  Reads that would cross a window edge are
+// zeroed by a per-lane bit mask, in the few waves that hold a row edge (fma(w, 0, acc) == acc; the
+// oracle skips those taps).  v_mfma_f32_32x32x2_f32 is issued in ascending k into WM x WN accumulator
+// tiles; A operands (weights) come pre-packed in fragment order from L2 (wp[co_tile][kquad][lane][4]).
 // Buffer loads through a V# descriptor (base, num_records): a lane whose offset is >= num_records reads 0 without touching
 // memory.  The LLVM intrinsics are bound by name with float result types (this compiler folds the integer-vector forms,
 // __builtin_amdgcn_raw_buffer_load_b64 / .v2i32, into a single dword load).
