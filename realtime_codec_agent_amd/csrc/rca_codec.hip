@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
         }
     };
     // pre-activation applied here (ACT) unless the layer that produced x already stored activated values
-    auto stage_write_t = [&](int c, int buf, auto act_tag) __attribute__((always_inline)) {
+    auto stage_write_t = [&](int buf, auto act_tag) __attribute__((always_inline)) {
         constexpr bool ACT = decltype(act_tag)::value;
         float* dst = xs + buf * BUF;
 #pragma unroll
@@ -438,9 +438,9 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
             }
         }
     };
-    auto stage_write = [&](int c, int buf) __attribute__((always_inline)) {
-        if (pre & 1) stage_write_t(c, buf, std::true_type{});
-        else stage_write_t(c, buf, std::false_type{});
+    auto stage_write = [&](int buf) __attribute__((always_inline)) {
+        if (pre & 1) stage_write_t(buf, std::true_type{});
+        else stage_write_t(buf, std::false_type{});
     };
 
     const long kquads = (long)nchunks * QPC;
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
 #pragma unroll
         for (int q = 0; q < QPC; ++q) a[wm][q] = p0[q * 64];
     }
-    stage_write(0, 0);
+    stage_write(0);
     __builtin_amdgcn_wave_barrier();
     RCA_TL_STAMP(tl1);
 #ifdef RCA_CONV_TIMELINE
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
         __builtin_amdgcn_s_setprio(2);  // staging phases run at raised priority (measured +2.4 %)
         __builtin_amdgcn_sched_barrier(0);
         RCA_TL_STAMP(tc);
-        stage_write(c1, 1);
+        stage_write(1);
         __builtin_amdgcn_wave_barrier();
         RCA_TL_STAMP(td);
         RCA_TL_ADD(tl_load, ta, tb); RCA_TL_ADD(tl_mfma, tb, tc); RCA_TL_ADD(tl_write, tc, td);
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
         compute(1, c2);
         __builtin_amdgcn_s_setprio(2);
         __builtin_amdgcn_sched_barrier(0);
-        stage_write(c2, 0);
+        stage_write(0);
         __builtin_amdgcn_wave_barrier();
     }
 
@@ -1018,7 +1018,6 @@ __global__ __launch_bounds__(64 * NW) void convtr1d_lds_kernel(const float* __re
         if (pre) v = lrelu(v, slope);
         xs[j * CP + ci] = v;
     }
-    const int nwe = Cin * K;
     constexpr int VW = (K % 4 == 0) ? 4 : 2;      // the K = 2S taps of one (ci, co) are contiguous: 16- or 8-byte loads
     constexpr int KV = K / VW;
     typedef float fvw __attribute__((ext_vector_type(VW)));
