@@ -908,7 +908,6 @@ __global__ __launch_bounds__(1024) void samp_final_kernel(const float* __restric
         int cnt = min(n, k);
         int pick = 0;
         if (!greedy && cnt > 1) {
-            const float mx = cval[0];
             if (sp->top_p < 1.0f) {  // smallest prefix whose probability mass reaches top_p
                 float tot = 0.0f;
                 for (int i = 0; i < cnt; ++i) tot += e_plain[i];
@@ -984,7 +983,7 @@ __global__ __launch_bounds__(64) void lm_token_probs_kernel(const float* __restr
     const float contrib = (pm == -INFINITY) ? 0.0f : ps * __expf(pm - mx);
     float tot = 0.0f;
     for (int b = 0; b < PROBS_SLICES; ++b) tot += __shfl(contrib, b);   // slice order
-    if (threadIdx.x < n) {
+    if ((int)threadIdx.x < n) {
         const int id = ids[threadIdx.x];
         probs[threadIdx.x] = (id >= 0 && id < V) ? __expf(logits[id] - mx) / tot : 0.0f;
     }
@@ -1619,7 +1618,6 @@ static int lm_splits_needed(const rca_lm* h, int m) { return std::min(h->n_split
 static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st, int nsp_launch) {
     const rca_lm_config_t& c = h->cfg;
     const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim, F = c.ffn;
-    const int G = c.n_heads / c.n_kv_heads;
     const int Mt = M <= 2 ? M : (M <= 4 ? 4 : 8);
     const long ps = (long)LM_MAXM * H;
     const GemvPro nopro{nullptr, nullptr, nullptr, 0, 0, nullptr, 0.0f, 0};
@@ -1919,7 +1917,6 @@ static bool lm_can_mfma_prefill(const rca_lm* h) {
 static int lm_enqueue_prefill_tile(rca_lm* h, int M, hipStream_t st, int nsp_launch) {
     const rca_lm_config_t& c = h->cfg;
     const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim, F = c.ffn;
-    const int G = c.n_heads / c.n_kv_heads;
     GemvRope rope{h->cos_t, h->sin_t, nullptr, nullptr, c.n_heads, c.n_kv_heads, c.n_ctx};
     const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     float* x = h->x;
@@ -1956,7 +1953,6 @@ static bool lm_can_gemm128(const rca_lm* h) {
 static int lm_enqueue_prefill_tile128(rca_lm* h, int M, hipStream_t st, int nsp_launch) {
     const rca_lm_config_t& c = h->cfg;
     const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim, F = c.ffn;
-    const int G = c.n_heads / c.n_kv_heads;
     GemvRope rope{h->cos_t, h->sin_t, nullptr, nullptr, c.n_heads, c.n_kv_heads, c.n_ctx};
     const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     // Every GEMM is cut along k until ~512 workgroups are in flight (a workgroup's stage is one exposed HBM round
