@@ -232,6 +232,10 @@ int rca_lm_create(const rca_lm_config_t* cfg, const rca_tensor_t* tensors, int32
  * there are no checkpoints offline).  oracle/lm_ref.py regenerates the same values. */
 int rca_lm_create_random(const rca_lm_config_t* cfg, uint64_t seed, float init_std, int32_t device,
                          rca_lm_t** out);
+/* A second instance over the same weights: what the reference obtains by loading one GGUF twice (`llm` and its logits_all twin
+ * `aux_llm`, realtime_agent_resources.py:19-33).  Own KV cache / workspace / sampler / stream; n_ctx may not exceed the
+ * parent's.  Either handle may be destroyed first; weight-modifying calls act on both. */
+int rca_lm_create_shared(rca_lm_t* parent, int32_t n_ctx, int32_t logits_all, rca_lm_t** out);
 int rca_lm_destroy(rca_lm_t* h);
 
 /* Llama.reset(): n_tokens = 0 (realtime_agent_v2.py:68) */

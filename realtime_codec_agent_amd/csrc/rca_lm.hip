@@ -1063,6 +1063,11 @@ struct rca_lm {
     hipGraphExec_t graph[3][LM_GRAPH_BUCKETS] = {};
     bool graphs_enabled = true;
     bool mfma_prefill = true;   // evals longer than LM_GEMV_M tokens use the bf16 MFMA tiles
+    // weight sharing (rca_lm_create_shared): a borrower points at the handle that owns the weights and the RoPE tables; an owner
+    // destroyed while borrowers are alive keeps those allocations (and its struct) until the last borrower is gone
+    rca_lm* weights_of = nullptr;
+    int borrowers = 0;
+    bool zombie = false;
 };
 
 static int lm_alloc(void** p, size_t bytes) {
@@ -1071,22 +1076,45 @@ static int lm_alloc(void** p, size_t bytes) {
     return RCA_OK;
 }
 
+static void lm_free_weights(rca_lm* h) {
+    for (auto& L : h->layers)
+        for (void* p : {(void*)L.wqkv, (void*)L.wo, (void*)L.wgu, (void*)L.wdown, (void*)L.attn_norm, (void*)L.ffn_norm})
+            if (p) (void)hipFree(p);
+    for (void* p : {(void*)h->embed, (void*)h->head, (void*)h->final_norm, (void*)h->cos_t, (void*)h->sin_t})
+        if (p) (void)hipFree(p);
+    h->layers.clear();
+    h->embed = h->head = nullptr;
+    h->final_norm = h->cos_t = h->sin_t = nullptr;
+}
+
 extern "C" int rca_lm_destroy(rca_lm_t* h) {
     if (!h) return RCA_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int i = 0; i < 3; ++i)
         for (int b = 0; b < LM_GRAPH_BUCKETS; ++b)
-            if (h->graph[i][b]) (void)hipGraphExecDestroy(h->graph[i][b]);
-    for (auto& L : h->layers)
-        for (void* p : {(void*)L.wqkv, (void*)L.wo, (void*)L.wgu, (void*)L.wdown, (void*)L.attn_norm, (void*)L.ffn_norm})
-            if (p) (void)hipFree(p);
-    for (void* p : {(void*)h->embed, (void*)h->head, (void*)h->final_norm, (void*)h->cos_t, (void*)h->sin_t, (void*)h->kc, (void*)h->vc,
-                    (void*)h->x, (void*)h->x2, (void*)h->xn, (void*)h->qkv, (void*)h->attn, (void*)h->part_o, (void*)h->hbuf, (void*)h->part_d,
-                    (void*)h->att_part, (void*)h->logits, (void*)h->probs_dev, (void*)h->probe_ids_dev, (void*)h->xh, (void*)h->xl, (void*)h->gpart, (void*)h->stt, (void*)h->samp, (void*)h->swork})
+            if (h->graph[i][b]) { (void)hipGraphExecDestroy(h->graph[i][b]); h->graph[i][b] = nullptr; }
+    for (void* p : {(void*)h->kc, (void*)h->vc, (void*)h->x, (void*)h->x2, (void*)h->xn, (void*)h->qkv, (void*)h->attn, (void*)h->part_o, (void*)h->hbuf,
+                    (void*)h->part_d, (void*)h->att_part, (void*)h->logits, (void*)h->probs_dev, (void*)h->probe_ids_dev, (void*)h->xh, (void*)h->xl,
+                    (void*)h->gpart, (void*)h->stt, (void*)h->samp, (void*)h->swork})
         if (p) (void)hipFree(p);
-    if (h->h_stt) (void)hipHostFree(h->h_stt);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    h->kc = h->vc = nullptr;
+    h->x = h->x2 = h->xn = h->qkv = h->attn = h->part_o = h->hbuf = h->part_d = h->att_part = h->logits = h->probs_dev = h->gpart = nullptr;
+    h->probe_ids_dev = nullptr; h->xh = h->xl = nullptr; h->stt = nullptr; h->samp = nullptr; h->swork = nullptr;
+    if (h->h_stt) { (void)hipHostFree(h->h_stt); h->h_stt = nullptr; }
+    if (h->stream) { (void)hipStreamDestroy(h->stream); h->stream = nullptr; }
+    if (h->weights_of) {            // borrower: the weights belong to someone else
+        rca_lm* owner = h->weights_of;
+        h->layers.clear();
+        if (--owner->borrowers == 0 && owner->zombie) { lm_free_weights(owner); delete owner; }
+        delete h;
+        return RCA_OK;
+    }
+    if (h->borrowers > 0) {         // owner with live borrowers: keep the weights until the last one goes
+        h->zombie = true;
+        return RCA_OK;
+    }
+    lm_free_weights(h);
     delete h;
     return RCA_OK;
 }
@@ -1147,12 +1175,16 @@ static int lm_upload_f32(const rca_tensor_t* ts, int nt, const std::string& name
     return RCA_OK;
 }
 
-static int lm_common_init(rca_lm* h, const rca_tensor_t* ts, int nt) {
+static int lm_common_init(rca_lm* h, const rca_tensor_t* ts, int nt, const rca_lm* rope_src = nullptr) {
     const rca_lm_config_t& c = h->cfg;
     int rc;
     const int half = c.head_dim / 2;
     h->n_ctx_pad = (c.n_ctx + ATT_KEYS - 1) / ATT_KEYS * ATT_KEYS;
     h->n_splits = h->n_ctx_pad / ATT_KEYS;
+    if (rope_src) {   // borrower: the owner's tables cover at least this context (checked by the caller)
+        h->cos_t = rope_src->cos_t;
+        h->sin_t = rope_src->sin_t;
+    } else {
     // RoPE tables from inv_freq (supplied by the host layer exactly as HF computes it, or derived here)
     std::vector<float> inv(half);
     const rca_tensor_t* tinv = find_tensor(ts, nt, "rope.inv_freq");
@@ -1183,6 +1215,7 @@ static int lm_common_init(rca_lm* h, const rca_tensor_t* ts, int nt) {
     lm_rope_table_kernel<<<cdiv((long)h->n_ctx_pad * half, 256), 256, 0, h->stream>>>(inv_dev, h->cos_t, h->sin_t, h->n_ctx_pad, half);
     RCA_HIP(hipStreamSynchronize(h->stream));
     (void)hipFree(inv_dev);
+    }
     // KV cache
     h->kv_layer_stride = (long)h->n_ctx_pad * c.n_kv_heads * c.head_dim;
     const size_t kvb = (size_t)c.n_layers * h->kv_layer_stride * 2;
@@ -1317,6 +1350,33 @@ extern "C" int rca_lm_create_random(const rca_lm_config_t* cfg, uint64_t seed, f
     }
     RCA_HIP(hipStreamSynchronize(h->stream));
     if ((rc = lm_common_init(h, nullptr, 0)) != RCA_OK) return bail(rc);
+    *out = h;
+    return RCA_OK;
+}
+
+// A second instance over the SAME weights (the reference keeps two llama.cpp models of one file: `llm` and the logits_all twin
+// `aux_llm`, realtime_agent_resources.py:19-33): own KV cache, workspace, sampler, stream and graphs; weights and RoPE tables
+// are the parent's.  Either handle may be destroyed first.  Calls that modify weights (rca_lm_mask_head_rows,
+// rca_lm_persist_codec_embeddings) act on both.
+extern "C" int rca_lm_create_shared(rca_lm_t* parent, int32_t n_ctx, int32_t logits_all, rca_lm_t** out) {
+    if (!parent || !out) return fail(RCA_ERR_ARG, "null argument");
+    rca_lm* owner = parent->weights_of ? parent->weights_of : parent;
+    if (owner->zombie) return fail(RCA_ERR_STATE, "create_shared: the parent handle was destroyed");
+    rca_lm_config_t cfg = parent->cfg;
+    cfg.n_ctx = n_ctx;
+    cfg.logits_all = logits_all;
+    if (n_ctx < 2 || (n_ctx + ATT_KEYS - 1) / ATT_KEYS * ATT_KEYS > owner->n_ctx_pad)
+        return fail(RCA_ERR_ARG, "create_shared: n_ctx %d exceeds the parent's RoPE tables (%d positions)", n_ctx, owner->n_ctx_pad);
+    rca_lm* h = nullptr;
+    int rc;
+    if ((rc = lm_new(&cfg, parent->device, &h)) != RCA_OK) return rc;
+    h->embed = owner->embed;
+    h->head = owner->head;
+    h->final_norm = owner->final_norm;
+    h->layers = owner->layers;
+    h->weights_of = owner;
+    owner->borrowers++;
+    if ((rc = lm_common_init(h, nullptr, 0, owner)) != RCA_OK) { rca_lm_destroy(h); return rc; }
     *out = h;
     return RCA_OK;
 }

@@ -188,6 +188,7 @@ class LlamaForAlternatingCodeChannels:
         device: Optional[int] = None,
         random_seed: int = 0,
         init_std: float = 0.02,
+        share_weights_with: Optional["LlamaForAlternatingCodeChannels"] = None,
         **_ignored,
     ):
         self._lib = N.lib()
@@ -201,6 +202,18 @@ class LlamaForAlternatingCodeChannels:
                 raise N.RcaError("LlamaForAlternatingCodeChannels needs a GPU; there is no CPU fallback")
             device = torch.cuda.current_device()
         self._device = device
+        if share_weights_with is not None:
+            # a second instance over the same device weights (the reference loads its GGUF twice: llm and the logits_all twin
+            # aux_llm, realtime_agent_resources.py:19-33): own KV cache / sampler / stream, n_ctx <= the parent's
+            parent = share_weights_with
+            self.config = parent.config
+            self._n_vocab = parent._n_vocab
+            self._n_ctx = int(n_ctx)
+            self._h = C.c_void_p()
+            N.check(self._lib.rca_lm_create_shared(parent._h, self._n_ctx, 1 if logits_all else 0, C.byref(self._h)), "rca_lm_create_shared")
+            self._weights_parent = parent   # (the library also copes with the parent being closed first)
+            self._finish_init(seed)
+            return
         random_init = weights is None and (model_path is None or str(model_path).startswith("random:"))
         if weights is None and not random_init:
             config, weights = load_weights(model_path)
@@ -229,6 +242,9 @@ class LlamaForAlternatingCodeChannels:
             if CODEC_PREFIX + "codec_embed.weight" in weights:   # un-persisted checkpoint: bake the projector output now
                 self.persist_codec_embeddings({k[len(CODEC_PREFIX):]: v for k, v in weights.items() if k.startswith(CODEC_PREFIX)},
                                               int(weights["codec.vocab_start"]), int(weights.get("codec.codebook_size", 0)) or None)
+        self._finish_init(seed)
+
+    def _finish_init(self, seed: int) -> None:
         self._ctx = _Ctx(self)
         self._input_ids = np.zeros(self._n_ctx, dtype=np.intc)
         self.input_ids = self._input_ids

@@ -33,9 +33,10 @@ class RealtimeAgentResources:
         kw = dict(model_path=llm_model_path, n_ctx=llm_n_ctx, n_gpu_layers=-1, verbose=False, flash_attn=True,
                   config=llm_config, random_seed=llm_random_seed)
         self.llm = LlamaForAlternatingCodeChannels(**kw)
-        # second instance with every position's logits (realtime_agent_resources.py:26-33); optional here
-        # because it doubles the resident weights and only finalize_last_response uses it
-        self.aux_llm = LlamaForAlternatingCodeChannels(logits_all=True, **kw) if with_aux_llm else None
+        # second instance with every position's logits (realtime_agent_resources.py:26-33): it shares the device weights of
+        # `llm` (own KV cache and workspace only); only finalize_last_response uses it
+        self.aux_llm = LlamaForAlternatingCodeChannels(logits_all=True, share_weights_with=self.llm, n_ctx=llm_n_ctx,
+                                                       model_path=llm_model_path) if with_aux_llm else None
         if isinstance(whisper_model, str):
             raise NotImplementedError("whisper.cpp transcription is out of scope; pass a model object or None")
         self.whisper_model = whisper_model

@@ -326,6 +326,32 @@ def test_unpersisted_checkpoint_directory_loads(tmp_path):
     assert llm._scores[-1].argmax() == g["logits_full_default"][-1].argmax()
 
 
+def test_shared_weights_instance_is_an_independent_model_over_the_same_weights():
+    """rca_lm_create_shared: the logits_all twin (aux_llm, realtime_agent_resources.py:26-33) borrows the device weights of
+    `llm`.  Same logits bit for bit as a separately loaded instance, independent KV caches, and either handle may be closed first."""
+    from realtime_codec_agent_amd.llm import LlamaForAlternatingCodeChannels
+    llm, w, ids = make_llm("llama3")
+    twin = LlamaForAlternatingCodeChannels(logits_all=True, share_weights_with=llm, n_ctx=512, device=0)
+    solo = LlamaForAlternatingCodeChannels(config=tiny_cfg("llama3"), weights=w, n_ctx=512, logits_all=True, device=0)
+    for m in (llm, twin, solo):
+        m.set_mfma_prefill(False)
+    llm.eval(ids[:9].tolist())                       # the parent is mid-sequence while the twin scores another one
+    a = twin.get_logprobs(ids[:20].tolist(), ids[20:29].tolist())
+    b = solo.get_logprobs(ids[:20].tolist(), ids[20:29].tolist())
+    assert np.array_equal(np.asarray(a), np.asarray(b))
+    llm.eval(ids[9:11].tolist())
+    assert llm.n_tokens == 11 and twin.n_tokens != 11
+    want = llm._scores[-1].copy()
+    llm.close()                                       # owner first: the weights must outlive it
+    twin.reset()
+    twin.eval(ids[:11].tolist())
+    assert np.array_equal(twin._scores[-1], want)
+    twin.close()
+    solo.close()
+    with pytest.raises(Exception):
+        LlamaForAlternatingCodeChannels(logits_all=True, share_weights_with=make_llm("default", n_ctx=256)[0], n_ctx=4096, device=0)
+
+
 def test_fuzz_lm_short():
     """Half a minute of scripts/fuzz_lm.py on the ~1B model: random splits of random sequences into evals / graph steps /
     eager steps (exact mode: bit-identical), random MFMA tilings (bit-identical to each other, within tolerance of exact),
