@@ -28,11 +28,15 @@ class RealtimeAgentResources:
         tokenizer: Optional[Any] = None,
         with_aux_llm: bool = True,
         llm_random_seed: int = 0,
+        share_llm_weights_with: Optional[LlamaForAlternatingCodeChannels] = None,
     ):
         self.llm_model_dir = os.path.dirname(llm_model_path) if not llm_model_path.startswith("random:") else ""
         kw = dict(model_path=llm_model_path, n_ctx=llm_n_ctx, n_gpu_layers=-1, verbose=False, flash_attn=True,
                   config=llm_config, random_seed=llm_random_seed)
-        self.llm = LlamaForAlternatingCodeChannels(**kw)
+        if share_llm_weights_with is not None:   # clone_for_self_play: a fresh model state over the weights already on the device
+            self.llm = LlamaForAlternatingCodeChannels(model_path=llm_model_path, n_ctx=llm_n_ctx, share_weights_with=share_llm_weights_with)
+        else:
+            self.llm = LlamaForAlternatingCodeChannels(**kw)
         # second instance with every position's logits (realtime_agent_resources.py:26-33): it shares the device weights of
         # `llm` (own KV cache and workspace only); only finalize_last_response uses it
         self.aux_llm = LlamaForAlternatingCodeChannels(logits_all=True, share_weights_with=self.llm, n_ctx=llm_n_ctx,
@@ -62,7 +66,8 @@ class RealtimeAgentResources:
         self._llm_random_seed = llm_random_seed
 
     def clone_for_self_play(self) -> "RealtimeAgentResources":
-        """Copy sharing everything except the LLM, which gets a fresh instance (reference :41-49)."""
+        """Copy sharing everything except the LLM, which gets a fresh instance (reference :41-49) -- fresh KV cache, sampler
+        and position, over the same device weights (the reference loads the file again)."""
         return RealtimeAgentResources(
             llm_model_path=self.llm.model_path or "random:clone",
             llm_n_ctx=self.llm.n_ctx(),
@@ -73,4 +78,5 @@ class RealtimeAgentResources:
             tokenizer=self.tokenizer,
             with_aux_llm=self.aux_llm is not None,
             llm_random_seed=self._llm_random_seed,
+            share_llm_weights_with=self.llm,
         )

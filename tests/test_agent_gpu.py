@@ -61,3 +61,28 @@ def test_trim_recompute_matches_fresh_prefill():
     llm.reset()
     llm.eval(seq)
     assert np.array_equal(llm._scores[-1], a)
+
+
+def test_self_play_clone_shares_weights_and_talks_to_the_original():
+    """clone_for_self_play (realtime_agent_resources.py:41-49): the second agent's LM is a fresh model state over the same
+    device weights, with its own KV cache; two agents in self-play mode feed each other's ids
+    (inference_client_self_play.py:148-159) and the clone behaves exactly like an agent built from scratch."""
+    from realtime_codec_agent_amd.realtime_agent_config import RealtimeAgentConfig
+    from realtime_codec_agent_amd.realtime_agent_v2 import RealtimeAgent
+    a, res = make_agent()
+    a = RealtimeAgent(resources=res, config=a.config, self_play_mode=True)
+    r2 = res.clone_for_self_play()
+    assert r2.llm is not res.llm and r2.audio_tokenizer.codec_model is res.audio_tokenizer.codec_model
+    b = RealtimeAgent(resources=r2, config=RealtimeAgentConfig(chunk_size_secs=0.08, use_whisper=False, force_trans_after_inactivity_secs=0.0,
+                                                               force_response_after_inactivity_secs=0.0), self_play_mode=True)
+    fresh, _ = make_agent()          # same seeds, loaded separately: the reference's way
+    sig = rich_signal(16000, 12)
+    for s in range(0, len(sig) - 1279, 1280):
+        chunk = sig[s:s + 1280]
+        out_a, ids_a = a.process_audio(chunk)
+        out_b, ids_b = b.process_audio(chunk)
+        out_f = fresh.process_audio(chunk)
+        assert np.array_equal(out_b, out_f)              # the clone is indistinguishable from a separately loaded agent
+        assert len(ids_a) == len(ids_b) == 4
+    assert a.input_ids == b.input_ids                    # same seeds, same audio, same weights: same sessions
+    assert res.llm.n_tokens == r2.llm.n_tokens
