@@ -1,7 +1,7 @@
 """Fuzz the batch encoder (MFMA variant) against the C oracle: random model widths (channel counts that are and are not
 multiples of the kernel's K chunk, outputs narrower than a tile), random batch sizes and window lengths (aligned and
 ragged, rows shorter and longer than a wave's window of columns), random layer taps.  Bit-exact or it stops.
-usage: fuzz_encode_oracle.py [seconds] [seed]"""
+usage: tests/fuzz_encode_oracle.py [seconds] [seed]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -341,10 +341,10 @@ def test_fuzz_tails_short():
 
 
 def test_fuzz_encode_against_oracle_short():
-    """Twenty seconds of scripts/fuzz_encode_oracle.py: random model widths, batch sizes and (ragged) window lengths through
+    """Twenty seconds of tests/fuzz_encode_oracle.py: random model widths, batch sizes and (ragged) window lengths through
     the MFMA encoder, codes and random layer taps bit-identical to the C oracle (a 4-minute run covers ~1400 cases)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_encode_oracle.py"), "20", "5"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_encode_oracle.py"), "20", "5"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "fuzz ok" in r.stdout
