@@ -1,6 +1,6 @@
-"""Fuzz the batch encoder (MFMA variant) against the C oracle: random model widths (channel counts that are and are not
+"""Fuzz the batch encoder and decoder (MFMA variant) against the C oracle: random model widths (channel counts that are and are not
 multiples of the kernel's K chunk, outputs narrower than a tile), random batch sizes and window lengths (aligned and
-ragged, rows shorter and longer than a wave's window of columns), random layer taps.  Bit-exact or it stops.
+ragged, rows shorter and longer than a wave's window of columns), random layer taps, random code sequences through the decoder.  Bit-exact or it stops.
 usage: tests/fuzz_encode_oracle.py [seconds] [seed]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -40,5 +40,11 @@ while time.time() - t0 < budget:
         _, tw = oc.encode(x, tap_layer=layer)
         tg = hip.encode_tap(x, layer)
         assert np.array_equal(tg, tw), ("tap", cfg.name, B, T, layer)
+    if rng.random() < 0.3:   # decoder: transposed convolutions on the same kernel (phase GEMMs)
+        Fd = int(rng.integers(1, 8 if big else 120))
+        Bd = int(rng.integers(1, 4 if big else 24))
+        codes = rng.integers(0, cfg.codebook_size, (Bd, Fd)).astype(np.int64)
+        dg, dw = hip.decode(codes), oc.decode(codes)
+        assert dg.shape == dw.shape and np.array_equal(dg, dw), ("decode", cfg.name, Bd, Fd, float(np.abs(dg - dw).max()))
     n += 1
 print(f"fuzz ok: {n} random (model, batch, length) cases bit-identical to the C oracle in {time.time() - t0:.0f} s")
