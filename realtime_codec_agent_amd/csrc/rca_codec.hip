@@ -1687,6 +1687,9 @@ static int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B,
     } else {
         if (waves_big >= BIG_MIN) launch_conv_cfg<KS, S, CIC, 2, 2, 0, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, none, notr, st, act);
         else if (waves_big >= MID_MIN) launch_conv_cfg<KS, S, CIC, 1, 2, 0, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, none, notr, st, act);
+        // the stride-1 k = 3 layers have a short reduction per column tile: 64 x 32 wave tiles (half the staging per MFMA of 32 x 32)
+        // measured 213 vs 222 us on conv_out of the 256-window step; weights (0.8 MB) stay in L2, so no extra fetches
+        else if (KS == 3 && L.cout >= 64 && waves_big >= 1024) launch_conv_cfg<KS, S, CIC, (KS == 3 ? 2 : 1), 1, 0, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, none, notr, st, act);
         else launch_conv_cfg<KS, S, CIC, 1, 1, 0, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, none, notr, st, act);
     }
     RCA_LAUNCH_CHECK();
