@@ -243,18 +243,15 @@ int oracle_codec_encode(const oracle_codec_config_t* cfg, const oracle_codec_wei
     return F;
 }
 
-/* AudioTokenizer._magicodec_decode (audio_tokenizer.py:196-201): codes [B][F] -> pcm [B][F*hop] */
-int oracle_codec_decode(const oracle_codec_config_t* cfg, const oracle_codec_weights_t* W, const float* cb,
-                        const int64_t* codes, int B, int F, float* pcm) {
+/* codec_model.decoder(z_q) (audio_tokenizer.py:199-200): z_q [B][F][cd] -> pcm [B][F*hop], clamped to [-1, 1] */
+int oracle_codec_decoder(const oracle_codec_config_t* cfg, const oracle_codec_weights_t* W, const float* zq, int B,
+                         int F, float* pcm) {
     const int n = cfg->n_stages, J = cfg->codebook_dim;
-    /* z_q [B][cd][F] */
+    /* [B][F][cd] -> [B][cd][F] */
     float* cur = (float*)malloc((size_t)B * J * F * sizeof(float));
     for (int b = 0; b < B; ++b)
-        for (int f = 0; f < F; ++f) {
-            const int64_t c = codes[(size_t)b * F + f];
-            if (c < 0 || c >= cfg->codebook_size) { free(cur); return -1; }
-            for (int j = 0; j < J; ++j) cur[((size_t)b * J + j) * F + f] = cb[(size_t)c * J + j];
-        }
+        for (int f = 0; f < F; ++f)
+            for (int j = 0; j < J; ++j) cur[((size_t)b * J + j) * F + f] = zq[((size_t)b * F + f) * J + j];
     int C = J, L = F;
     {
         const int Co = cfg->channels[n];
@@ -278,5 +275,21 @@ int oracle_codec_decode(const oracle_codec_config_t* cfg, const oracle_codec_wei
         pcm[i] = v > 1.0f ? 1.0f : (v < -1.0f ? -1.0f : v);
     }
     free(cur);
+    return L;
+}
+
+/* AudioTokenizer._magicodec_decode (audio_tokenizer.py:196-201): codes [B][F] -> pcm [B][F*hop]:
+ * embedding(codes, codebook_proj(codebook.weight)) -> decoder */
+int oracle_codec_decode(const oracle_codec_config_t* cfg, const oracle_codec_weights_t* W, const float* cb,
+                        const int64_t* codes, int B, int F, float* pcm) {
+    const int J = cfg->codebook_dim;
+    float* zq = (float*)malloc((size_t)B * F * J * sizeof(float));
+    for (size_t i = 0; i < (size_t)B * F; ++i) {
+        const int64_t c = codes[i];
+        if (c < 0 || c >= cfg->codebook_size) { free(zq); return -1; }
+        memcpy(zq + i * J, cb + (size_t)c * J, (size_t)J * sizeof(float));
+    }
+    const int L = oracle_codec_decoder(cfg, W, zq, B, F, pcm);
+    free(zq);
     return L;
 }

@@ -6,7 +6,7 @@ import numpy as np
 def run() -> None:
     import torch
     from oracle import lm_ref
-    from .llm import LlamaForAlternatingCodeChannels, LMConfig
+    from realtime_codec_agent_amd.llm import LlamaForAlternatingCodeChannels, LMConfig
     cfg = LMConfig(vocab_size=4096, hidden=256, n_layers=2, n_heads=4, n_kv_heads=1, head_dim=64, ffn=512)
     llm = LlamaForAlternatingCodeChannels(model_path="random:smoke", config=cfg, n_ctx=256, random_seed=5, init_std=0.05, device=0)
     ref = lm_ref.LMRef(cfg, lm_ref.random_weights(cfg, 5, 0.05), kv_dtype=torch.float16)
