@@ -215,7 +215,7 @@ typedef struct {
 } rca_lm_config_t;
 
 typedef struct {
-    int32_t top_k;   /* <=0: whole vocabulary */
+    int32_t top_k;   /* 1..256 (llama.cpp's <=0 = whole vocabulary is refused by rca_lm_sampler_init unless temp <= 0) */
     float top_p;     /* 1.0 = off */
     float min_p;     /* 0.0 = off */
     float temp;      /* <=0: greedy */

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_DIR, "librca_oracle.so")
 
 def build(force: bool = False) -> str:
     """Compile the C restatements -> librca_oracle.so (gcc, seconds)."""
-    srcs = [os.path.join(_DIR, f) for f in ("codec_oracle.c", "sampler_oracle.c")]
+    srcs = [os.path.join(_DIR, f) for f in ("codec_oracle.c", "sampler_oracle.c", "lm_init_oracle.c")]
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(LIB_PATH) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _DIR, "-B", "librca_oracle.so"], stdout=subprocess.DEVNULL)
     return LIB_PATH

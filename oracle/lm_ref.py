@@ -52,8 +52,14 @@ class LMRef:
         self.kv_dtype = kv_dtype
         self.w = {}
         for k, v in weights.items():
-            if v.dtype == np.uint16:
-                v = (v.astype(np.uint32) << 16).view(np.float32)
+            if isinstance(v, _SparseRows):
+                self.w[k] = v
+                continue
+            if v.dtype == np.uint16:       # bf16 bits: widened by the C helper (a 1B-size lm_head is 0.5 G values)
+                f = np.empty(v.shape, np.float32)
+                v = np.ascontiguousarray(v)
+                _slib().oracle_bf16_to_f32(v.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_int64(v.size), f.ctypes.data_as(C.POINTER(C.c_float)))
+                v = f
             self.w[k] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
         self.inv_freq = inv_freq(cfg)
         self.reset()
@@ -133,27 +139,72 @@ def _splitmix_np(seed: int, ctr: np.ndarray) -> np.ndarray:
     return z
 
 
-def random_bf16_tensor(seed: int, tensor_id: int, n: int, init_std: float) -> np.ndarray:
-    """Same values as lm_random_bf16_kernel (rca_lm.hip): Irwin-Hall sum of four 16-bit uniforms of a
-    splitmix64 hash, scaled in float32, rounded to bf16 (RNE).  Returns uint16 bf16 bits."""
-    with np.errstate(over="ignore"):
-        s = np.uint64(seed) ^ (np.uint64(tensor_id) * np.uint64(0xD6E8FEB86659FD93))
-    z = _splitmix_np(int(s), np.arange(n, dtype=np.uint64))
-    m = np.uint64(0xFFFF)
-    total = ((z & m) + ((z >> np.uint64(16)) & m) + ((z >> np.uint64(32)) & m) + ((z >> np.uint64(48)) & m)).astype(np.int64)
+def random_bf16_tensor_c(seed: int, tensor_id: int, n: int, init_std: float, start: int = 0) -> np.ndarray:
+    """random_bf16_tensor through oracle/lm_init_oracle.c (OpenMP): the 1.5 G weights of the ~1B bench model in seconds."""
     scale = np.float32(np.float32(init_std) * np.float32(1.7320508) / np.float32(65535.0))
-    f = (total - 131070).astype(np.float32) * scale
-    u = f.view(np.uint32)
-    return ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)).astype(np.uint16)
+    out = np.empty(n, np.uint16)
+    _slib().oracle_random_bf16(C.c_uint64(seed), C.c_uint64(tensor_id), C.c_int64(start), C.c_int64(n), C.c_float(float(scale)),
+                               out.ctypes.data_as(C.POINTER(C.c_uint16)))
+    return out
 
 
-def random_weights(cfg, seed: int, init_std: float = 0.02) -> Dict[str, np.ndarray]:
+def random_bf16_tensor(seed: int, tensor_id: int, n: int, init_std: float, start: int = 0) -> np.ndarray:
+    """Same values as lm_random_bf16_kernel (rca_lm.hip): Irwin-Hall sum of four 16-bit uniforms of a
+    splitmix64 hash, scaled in float32, rounded to bf16 (RNE).  Returns uint16 bf16 bits of elements
+    [start, start + n) of the tensor; generated in blocks so that the 1B-model tensors fit in memory."""
+    with np.errstate(over="ignore"):
+        s = int(np.uint64(seed) ^ (np.uint64(tensor_id) * np.uint64(0xD6E8FEB86659FD93)))
+    scale = np.float32(np.float32(init_std) * np.float32(1.7320508) / np.float32(65535.0))
+    m = np.uint64(0xFFFF)
+    out = np.empty(n, np.uint16)
+    BLK = 1 << 24
+    for b0 in range(0, n, BLK):
+        b1 = min(n, b0 + BLK)
+        z = _splitmix_np(s, np.arange(start + b0, start + b1, dtype=np.uint64))
+        total = ((z & m) + ((z >> np.uint64(16)) & m) + ((z >> np.uint64(32)) & m) + ((z >> np.uint64(48)) & m)).astype(np.int64)
+        f = (total - 131070).astype(np.float32) * scale
+        u = f.view(np.uint32)
+        out[b0:b1] = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)).astype(np.uint16)
+    return out
+
+
+def random_embedding_rows(cfg, seed: int, ids, init_std: float = 0.02) -> np.ndarray:
+    """Rows `ids` of the random-init embedding table (tensor id 1) without generating all V of them."""
+    H = cfg.hidden
+    return np.stack([random_bf16_tensor(seed, 1, H, init_std, start=int(i) * H) for i in ids])
+
+
+class _SparseRows:
+    """Stand-in for a [V, H] float table of which only a few rows exist: indexing with a LongTensor of ids returns them."""
+
+    def __init__(self, rows: Dict[int, np.ndarray], H: int):
+        self.rows, self.H = rows, H
+        self.dtype = np.float32
+
+    def __getitem__(self, ids):
+        return torch.stack([torch.from_numpy(self.rows[int(i)]) for i in ids])
+
+
+def _embed_table(cfg, seed, init_std, embed_rows):
+    V, H = cfg.vocab_size, cfg.hidden
+    if embed_rows is None:
+        return random_bf16_tensor_c(seed, 1, V * H, init_std).reshape(V, H)
+    rows = {}
+    for i in set(int(t) for t in embed_rows):
+        b = random_bf16_tensor_c(seed, 1, H, init_std, start=i * H)
+        rows[i] = (b.astype(np.uint32) << 16).view(np.float32)
+    return _SparseRows(rows, H)
+
+
+def random_weights(cfg, seed: int, init_std: float = 0.02, embed_rows=None) -> Dict[str, np.ndarray]:
     """HF-named state dict equal to what rca_lm_create_random generates (fused qkv / interleaved
-    gate-up tensors are split back into their HF parts)."""
+    gate-up tensors are split back into their HF parts).  embed_rows: when given, only those rows of the embedding
+    table are generated (the others stay zero): a 1B-size table is 0.5 G values of which a test reads a few dozen."""
+    random_bf16_tensor = random_bf16_tensor_c
     H, V, F = cfg.hidden, cfg.vocab_size, cfg.ffn
     Q, KVD = cfg.n_heads * cfg.head_dim, cfg.n_kv_heads * cfg.head_dim
     w = {
-        "model.embed_tokens.weight": random_bf16_tensor(seed, 1, V * H, init_std).reshape(V, H),
+        "model.embed_tokens.weight": _embed_table(cfg, seed, init_std, embed_rows),
         "lm_head.weight": random_bf16_tensor(seed, 2, V * H, init_std).reshape(V, H),
         "model.norm.weight": np.ones(H, np.float32),
     }

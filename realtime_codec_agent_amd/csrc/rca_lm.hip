@@ -1087,13 +1087,19 @@ static void lm_free_weights(rca_lm* h) {
     h->final_norm = h->cos_t = h->sin_t = nullptr;
 }
 
+// The captured step graphs carry the addresses of the logits buffer, the KV cache and the workspace in their kernel nodes:
+// whenever one of those is reallocated (or the handle goes away) every captured graph has to go with it.
+static void lm_drop_graphs(rca_lm* h) {
+    for (int i = 0; i < 3; ++i)
+        for (int b = 0; b < LM_GRAPH_BUCKETS; ++b)
+            if (h->graph[i][b]) { (void)hipGraphExecDestroy(h->graph[i][b]); h->graph[i][b] = nullptr; }
+}
+
 extern "C" int rca_lm_destroy(rca_lm_t* h) {
     if (!h) return RCA_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (int i = 0; i < 3; ++i)
-        for (int b = 0; b < LM_GRAPH_BUCKETS; ++b)
-            if (h->graph[i][b]) { (void)hipGraphExecDestroy(h->graph[i][b]); h->graph[i][b] = nullptr; }
+    lm_drop_graphs(h);
     for (void* p : {(void*)h->kc, (void*)h->vc, (void*)h->x, (void*)h->x2, (void*)h->xn, (void*)h->qkv, (void*)h->attn, (void*)h->part_o, (void*)h->hbuf,
                     (void*)h->part_d, (void*)h->att_part, (void*)h->logits, (void*)h->probs_dev, (void*)h->probe_ids_dev, (void*)h->xh, (void*)h->xl,
                     (void*)h->gpart, (void*)h->stt, (void*)h->samp, (void*)h->swork})
@@ -2087,12 +2093,15 @@ extern "C" int rca_lm_eval(rca_lm_t* h, const int32_t* ids, int32_t n) {
     if (!h || (!ids && n > 0) || n < 0) return fail(RCA_ERR_ARG, "eval: bad argument");
     if (n == 0) return RCA_OK;
     if (h->n_tokens + n > h->cfg.n_ctx) return fail(RCA_ERR_STATE, "context overflow: %d + %d > n_ctx %d", h->n_tokens, n, h->cfg.n_ctx);
+    for (int i = 0; i < n; ++i)
+        if (ids[i] < 0 || ids[i] >= h->cfg.vocab_size) return fail(RCA_ERR_ARG, "eval: token id %d at index %d is outside the vocabulary [0, %d)", ids[i], i, h->cfg.vocab_size);
     RCA_HIP(hipSetDevice(h->device));
     hipStream_t st = h->stream;
     int rc;
     const bool all = h->cfg.logits_all != 0;
     if (all && n > h->logits_rows_cap) {
         RCA_HIP(hipStreamSynchronize(st));
+        lm_drop_graphs(h);   // their head-GEMV and sampler nodes point at the buffer that is about to be freed
         (void)hipFree(h->logits);
         h->logits = nullptr;
         h->logits_rows_cap = n;
@@ -2166,6 +2175,10 @@ extern "C" int rca_lm_get_logits_row(rca_lm_t* h, int32_t row, float* out_host) 
 extern "C" int rca_lm_sampler_init(rca_lm_t* h, const rca_sampler_params_t* p) {
     if (!h || !p) return fail(RCA_ERR_ARG, "null");
     if (p->n_bias < 0 || p->n_bias > 8) return fail(RCA_ERR_ARG, "at most 8 logit-bias entries");
+    // llama.cpp reads top_k <= 0 as "whole vocabulary"; the device sampler ranks at most SAMP_MAXK candidates, so anything it
+    // cannot honour is refused instead of being clamped silently (greedy, temp <= 0, needs one candidate whatever top_k says)
+    if (p->temp > 0.0f && (p->top_k <= 0 || p->top_k > SAMP_MAXK))
+        return fail(RCA_ERR_ARG, "sampler: top_k %d unsupported (1..%d; top_k <= 0 = whole vocabulary is not implemented)", p->top_k, SAMP_MAXK);
     RCA_HIP(hipSetDevice(h->device));
     SamplerDev s;
     memset(&s, 0, sizeof(s));
@@ -2211,6 +2224,8 @@ extern "C" int rca_lm_step(rca_lm_t* h, const int32_t* ids, int32_t n, int32_t* 
     if (!h || !ids || !token || n < 1) return fail(RCA_ERR_ARG, "step: bad argument");
     if (!h->sampler_set) return fail(RCA_ERR_STATE, "sampler not initialised");
     if (h->n_tokens + n > h->cfg.n_ctx) return fail(RCA_ERR_STATE, "context overflow: %d + %d > n_ctx %d", h->n_tokens, n, h->cfg.n_ctx);
+    for (int i = 0; i < n; ++i)
+        if (ids[i] < 0 || ids[i] >= h->cfg.vocab_size) return fail(RCA_ERR_ARG, "step: token id %d at index %d is outside the vocabulary [0, %d)", ids[i], i, h->cfg.vocab_size);
     RCA_HIP(hipSetDevice(h->device));
     hipStream_t st = h->stream;
     int rc;
@@ -2270,6 +2285,11 @@ extern "C" int rca_lm_token_probs(rca_lm_t* h, const int32_t* token_ids, int32_t
 // switch between "logits of every evaluated position" (llama_cpp's logits_all) and "last position only"
 extern "C" int rca_lm_set_logits_all(rca_lm_t* h, int32_t enable) {
     if (!h) return fail(RCA_ERR_ARG, "null");
+    if ((h->cfg.logits_all != 0) != (enable != 0)) {
+        RCA_HIP(hipSetDevice(h->device));
+        RCA_HIP(hipStreamSynchronize(h->stream));
+        lm_drop_graphs(h);   // a later eval may move the logits buffer; nothing captured before the switch is replayed after it
+    }
     h->cfg.logits_all = enable != 0;
     return RCA_OK;
 }

@@ -165,3 +165,69 @@ def scenarios(tok):
                         finalize_response_after_inactivity_secs=0.3),
                    {}, 4.0),
     }
+
+
+class _OracleCtx:
+    def __init__(self, llm):
+        self.llm = llm
+
+    def get_logits(self):
+        return self.llm._logits.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+class OracleLLM:
+    """The llama_cpp.Llama surface the agent uses (SURVEY.md 8b-3) over the torch oracle oracle/lm_ref.py::LMRef and the C
+    sampler restatement: the CPU counterpart of realtime_codec_agent_amd.llm.LlamaForAlternatingCodeChannels, for running
+    the SAME agent over oracle objects and over HIP objects (tests/test_agent_gpu.py)."""
+
+    def __init__(self, cfg, weights, n_ctx=4096):
+        from oracle import lm_ref
+        self._lm_ref = lm_ref
+        self.ref = lm_ref.LMRef(cfg, weights, kv_dtype=torch.float16)
+        self._n_vocab = cfg.vocab_size
+        self._n_ctx = n_ctx
+        self._ctx = _OracleCtx(self)
+        self._logits = np.zeros(cfg.vocab_size, np.float32)
+        self.model_path = "oracle"
+        self._sampler = None
+        self._counter = 0
+        self.n_evals = 0
+
+    def n_ctx(self):
+        return self._n_ctx
+
+    @property
+    def n_tokens(self):
+        return self.ref.n_tokens
+
+    @n_tokens.setter
+    def n_tokens(self, n):
+        self.ref.set_n_tokens(int(n))
+
+    def reset(self):
+        self.ref.reset()
+
+    def eval(self, tokens):
+        tokens = [int(t) for t in tokens]
+        if tokens:
+            self._logits = np.ascontiguousarray(self.ref.eval(tokens)[-1].numpy(), dtype=np.float32)
+            self.n_evals += 1
+
+    def init_sampler_for_generate(self, top_k=40, top_p=0.95, min_p=0.05, temp=0.8, seed=None, logits_processor=None, **_):
+        bias = dict(getattr(logits_processor, "logit_bias_map", {}) or {})
+        self._sampler = dict(top_k=top_k, top_p=top_p, min_p=min_p, temp=temp, seed=(seed if seed is not None else -1) & 0xFFFFFFFF, bias=bias)
+        self._counter = 0
+
+    def sample(self, idx=None):
+        s = self._sampler
+        tok = self._lm_ref.sample(self._logits, s["top_k"], s["top_p"], s["min_p"], s["temp"], s["seed"], self._counter, s["bias"])
+        self._counter += 1
+        return tok
+
+    def generate(self, tokens, reset=False):
+        assert reset is False
+        self.eval(tokens)
+        while True:
+            tok = self.sample()
+            more = yield tok
+            self.eval([tok] + list(more or []))

@@ -86,3 +86,64 @@ def test_self_play_clone_shares_weights_and_talks_to_the_original():
         assert len(ids_a) == len(ids_b) == 4
     assert a.input_ids == b.input_ids                    # same seeds, same audio, same weights: same sessions
     assert res.llm.n_tokens == r2.llm.n_tokens
+
+
+def _paired_resources(seed=3):
+    """Two resource sets over the SAME weights: HIP objects (MagiCodecHIP + the HIP LM through the C ABI) and oracle objects
+    (C codec oracle + torch LMRef + C sampler restatement)."""
+    from types import SimpleNamespace
+    from agent_fakes import OracleCodecModel, OracleLLM
+    from oracle import lm_ref
+    from oracle.codec import OracleCodec
+    from realtime_codec_agent_amd.audio_tokenizer import AudioTokenizer
+    from realtime_codec_agent_amd.codec import MagiCodecHIP
+    from realtime_codec_agent_amd.codec_model import init_codec_weights, tiny_codec_config
+    from realtime_codec_agent_amd.llm import LlamaForAlternatingCodeChannels, LMConfig
+    from realtime_codec_agent_amd.tokenizer import CodecTokenizer
+    ccfg = tiny_codec_config()
+    cw = init_codec_weights(ccfg, seed=0)
+    tok = CodecTokenizer(base_vocab_size=512, codebook_size=ccfg.codebook_size)
+    lcfg = LMConfig(vocab_size=tok.vocab_size, hidden=256, n_layers=2, n_heads=4, n_kv_heads=2, head_dim=64, ffn=512)
+    w = lm_ref.random_weights(lcfg, seed, 0.05)
+    head = w["lm_head.weight"].copy()
+    head[: tok.codec_vocab_start] = 0          # like a trained codec LM in audio mode: the text rows never win
+    head[len(tok):] = 0
+    w["lm_head.weight"] = head
+    hip = SimpleNamespace(llm=LlamaForAlternatingCodeChannels(config=lcfg, weights=w, n_ctx=2048, device=0), aux_llm=None, tokenizer=tok,
+                          audio_tokenizer=AudioTokenizer(codec_model=MagiCodecHIP(ccfg, cw)), whisper_model=None, llm_model_dir="")
+    ora = SimpleNamespace(llm=OracleLLM(lcfg, w, n_ctx=2048), aux_llm=None, tokenizer=tok,
+                          audio_tokenizer=AudioTokenizer(codec_model=OracleCodecModel(OracleCodec(ccfg, cw)), device="cpu"),
+                          whisper_model=None, llm_model_dir="")
+    return hip, ora
+
+
+@pytest.mark.parametrize("chunk,exact_prefill", [(0.08, True), (0.1, True), (0.08, False)])
+def test_agent_over_hip_objects_equals_agent_over_oracle_objects(chunk, exact_prefill):
+    """a12 / a16 against the oracle, not against itself: the SAME RealtimeAgent code runs once over the HIP model objects and once
+    over the CPU oracle objects (greedy sampling, the reference's process_audio loop realtime_agent_v2.py:504-554 with the
+    sliding-window trim + KV recompute :187-190,725-733 firing several times).  Token stream, KV position, emitted PCM and the
+    audio history must be equal -- ids exactly, PCM bit for bit (the codec kernels are bit-exact and the ids are equal)."""
+    from realtime_codec_agent_amd.realtime_agent_config import RealtimeAgentConfig
+    from realtime_codec_agent_amd.realtime_agent_v2 import RealtimeAgent
+    hip, ora = _paired_resources()
+    hip.llm.set_mfma_prefill(not exact_prefill)
+    cfg = dict(chunk_size_secs=chunk, use_whisper=False, force_trans_after_inactivity_secs=0.0, force_response_after_inactivity_secs=0.0,
+               temperature=0.0, max_context_secs=1.0, trim_by_secs=0.4)
+    a_hip = RealtimeAgent(resources=hip, config=RealtimeAgentConfig(**cfg))
+    a_ora = RealtimeAgent(resources=ora, config=RealtimeAgentConfig(**cfg))
+    assert a_hip.input_ids == a_ora.input_ids                      # header: enrollment codes from both tokenizers
+    n = int(chunk * 16000)
+    sig = rich_signal(n * 36, 21)
+    for s in range(0, len(sig), n):
+        o_hip = a_hip.process_audio(sig[s:s + n])
+        o_ora = a_ora.process_audio(sig[s:s + n])
+        assert a_hip.input_ids == a_ora.input_ids, f"token streams diverge in chunk {s // n}"
+        assert np.array_equal(o_hip, o_ora), f"emitted PCM differs in chunk {s // n}"
+        assert hip.llm.n_tokens == ora.llm.n_tokens
+    assert a_hip.trim_to_secs == a_ora.trim_to_secs and a_hip.trim_to_secs >= 0.8      # several trims happened
+    assert np.array_equal(a_hip.get_audio_history(), a_ora.get_audio_history())
+    assert a_hip.audio_tokens_idx == a_ora.audio_tokens_idx
+    d = np.abs(hip.llm._scores[-1] - ora.llm._logits).max()
+    print(f"last-step logits HIP vs oracle after {len(a_hip.input_ids)} tokens: max|d| = {d:.2e}")
+    assert d < (2e-4 if exact_prefill else 6e-4)
+    assert len(set(a_hip.input_ids[a_hip.context_start_pos + 8::2])) > 10           # the agent channel is not stuck on one code

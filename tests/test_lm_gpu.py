@@ -161,6 +161,57 @@ def test_logits_all_and_get_logprobs():
     assert lp.shape == (8,) and np.abs(lp - want).max() < 1e-3
 
 
+def test_step_graphs_survive_a_logits_all_excursion():
+    """A captured step graph has the logits buffer's address baked into its head-GEMV and sampler nodes.  Switching the handle to
+    logits_all and evaluating more rows than the buffer holds reallocates it; stepping afterwards must re-capture (not replay a
+    graph over freed memory) and give exactly the eager result."""
+    llm, w, ids = make_llm("llama3")
+    params = dict(top_k=20, top_p=1.0, min_p=0.0, temp=1.0, seed=7)
+
+    def run(excursion, graphs):
+        llm.set_graphs(graphs)
+        llm.reset()
+        llm.init_sampler_for_generate(**params)
+        llm.eval(ids[:9].tolist())
+        out = [llm.step(ids[9:11].tolist())]
+        if excursion:
+            keep = llm.n_tokens
+            llm._lib.rca_lm_set_logits_all(llm._h, 1)
+            llm._logits_all = True
+            llm.eval(ids[11:24].tolist())                      # 13 rows > the single row allocated: the buffer moves
+            assert llm._scores.shape[0] == 13
+            llm._lib.rca_lm_set_logits_all(llm._h, 0)
+            llm._logits_all = False
+            llm.n_tokens = keep
+        out.append(llm.step([out[0], int(ids[11])]))
+        out.append(llm.step([out[1], int(ids[12])]))
+        return out, llm._scores[-1].copy(), llm.token_probs([3, 120])
+
+    base = run(False, False)
+    for excursion, graphs in ((True, True), (True, False), (False, True)):
+        got = run(excursion, graphs)
+        assert got[0] == base[0] and np.array_equal(got[1], base[1]) and np.array_equal(got[2], base[2]), (excursion, graphs)
+
+
+def test_sampler_and_token_ids_are_validated():
+    """llama.cpp reads top_k <= 0 as 'whole vocabulary'; the device sampler cannot, so it refuses instead of clamping.  Token ids
+    outside the vocabulary are an error, not a clamped embedding row."""
+    from realtime_codec_agent_amd._native import RcaError
+    llm, w, ids = make_llm("default")
+    for bad in (0, -1, 257):
+        with pytest.raises(RcaError):
+            llm.init_sampler_for_generate(top_k=bad, top_p=1.0, min_p=0.0, temp=1.0, seed=1)
+    llm.init_sampler_for_generate(top_k=0, top_p=1.0, min_p=0.0, temp=0.0, seed=1)      # greedy ignores top_k
+    llm.init_sampler_for_generate(top_k=256, top_p=1.0, min_p=0.0, temp=1.0, seed=1)
+    llm.eval(ids[:4].tolist())
+    for bad in ([llm._n_vocab], [-1], [3, 1 << 20]):
+        with pytest.raises(RcaError):
+            llm.eval(bad)
+        with pytest.raises(RcaError):
+            llm.step(bad)
+    assert llm.n_tokens == 4
+
+
 def test_context_overflow_and_bad_args():
     from realtime_codec_agent_amd._native import RcaError
     llm, w, ids = make_llm("default", n_ctx=16)
@@ -234,6 +285,61 @@ def test_full_size_1b_properties():
     assert outs[0] == outs[1]
     want = lm_ref.sample(llm._scores[-1], 100, 1.0, 0.0, 1.0, 42, 5)
     assert outs[1][-1] == want
+
+
+# ~1B dims (H=2048, ffn 8192, 16 layers, V=259 344): |logit| <= ~4.5, std 0.9.  Exact mode sums 2048- and 8192-long dot
+# products in a different order than torch (measured 3e-4); the MFMA prefill adds the bf16 hi/lo split (measured 8e-4).
+TOL_1B = {False: 1.5e-3, True: 3e-3}
+
+
+def _check_1b_point(got, want_full, fix, i, tol, tag):
+    import lm_1b_case as case
+    got = np.asarray(got, np.float32)
+    s = case.summarize(got)
+    top_ids, top_vals = fix[f"p{i}/top_ids"], fix[f"p{i}/top_vals"]
+    d_fix = max(np.abs(got[top_ids] - top_vals).max(), np.abs(s["strided"] - fix[f"p{i}/strided"]).max())
+    d_live = np.abs(got - want_full).max()
+    print(f"1B {tag} point {i}: max|dlogit| vs fixture slice {d_fix:.3e}, vs live oracle (all {got.size} logits) {d_live:.3e}")
+    assert d_fix < tol and d_live < tol
+    assert int(s["top_ids"][0]) == int(top_ids[0]) == int(np.argmax(want_full))
+    # top-100 membership may differ only where the 100th / 101st logits are closer than the tolerance
+    missing = set(top_ids.tolist()) - set(s["top_ids"].tolist())
+    assert all(got[j] > s["top_vals"][-1] - 2 * tol for j in missing), missing
+    assert len(missing) <= 3
+    assert abs(s["std"] - float(fix[f"p{i}/std"])) < 1e-4 and abs(s["mean"] - float(fix[f"p{i}/mean"])) < 1e-4
+
+
+@pytest.mark.parametrize("mfma_prefill", [False, True])
+def test_1b_logits_match_oracle_and_committed_slice(mfma_prefill):
+    """BASELINE config 3's model at full size against oracle.lm_ref.LMRef on the same hash-generated weights: the last-token
+    logits after a 96-token context (one eval: GEMV chunks in exact mode, one bf16-MFMA tile otherwise) and after two S=2
+    decode steps -- all 259 344 of them against the oracle run live on the host, and the committed top-100 / strided
+    slice (tests/golden/lm_1b_topk.npz, made by tests/golden/make_lm_1b_golden.py).  Also through the graph step."""
+    import lm_1b_case as case
+    from realtime_codec_agent_amd.llm import LlamaForAlternatingCodeChannels
+    fix = np.load(f"{GOLDEN}/lm_1b_topk.npz")
+    ctx, steps = case.token_ids()
+    assert np.array_equal(ctx, fix["ctx_ids"]) and np.array_equal(np.stack(steps), fix["step_ids"])
+    want = case.oracle_points()
+    llm = LlamaForAlternatingCodeChannels(model_path="random:1b", config=case.config(), n_ctx=1024, random_seed=case.SEED,
+                                          init_std=case.INIT_STD, device=0)
+    llm.set_mfma_prefill(mfma_prefill)
+    tol = TOL_1B[mfma_prefill]
+    tag = "mfma-prefill" if mfma_prefill else "exact"
+    llm.eval(ctx.tolist())
+    _check_1b_point(llm._scores[-1], want[0], fix, 0, tol, tag)
+    for i, s in enumerate(steps):
+        llm.eval(s.tolist())
+        _check_1b_point(llm._scores[-1], want[i + 1], fix, i + 1, tol, tag)
+    # the same two steps as captured-graph steps (greedy): same logits bit for bit, token = argmax
+    llm.n_tokens = len(ctx)
+    llm.init_sampler_for_generate(top_k=100, top_p=1.0, min_p=0.0, temp=0.0, seed=42)
+    eager = llm._scores[-1].copy()
+    for i, s in enumerate(steps):
+        tok = llm.step(s.tolist())
+        assert tok == int(fix[f"p{i + 1}/top_ids"][0])
+    assert np.array_equal(llm._scores[-1], eager)
+    llm.close()
 
 
 @pytest.mark.parametrize("rope", ["default", "llama3"])
