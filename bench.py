@@ -61,6 +61,67 @@ def cpu_baseline_encode(cfg, weights, chunk, ctx, n_chunks, channels):
                 sample=f"{len(wins)} windows of {W} samples ({n_chunks} chunk positions x {channels} ch) in {dt:.2f} s, OpenMP x{os.cpu_count()}")
 
 
+def cpu_baseline_lm_step(cfg, ctx_tokens=64, steps=4):
+    """The LM oracle (oracle/lm_ref.py::LMRef, fp32 torch on the host cores, kind 'port': the reference's realtime LM is
+    llama.cpp, absent offline) at the SAME dims and hash-generated weights as the GPU model: S=2 decode steps on top of a
+    short context.  Bounded: weight generation ~10 s, a step streams 6 GB of fp32 weights."""
+    import torch as _t
+    from oracle import lm_ref
+    _t.set_num_threads(os.cpu_count())
+    rng = np.random.default_rng(7)
+    ids = rng.integers(128266, 128266 + 131072, ctx_tokens + 2 * (steps + 1))
+    t0 = time.perf_counter()
+    ref = lm_ref.LMRef(cfg, lm_ref.random_weights(cfg, 0, 0.02, embed_rows=ids), kv_dtype=_t.float16)
+    gen_s = time.perf_counter() - t0
+    ref.eval(ids[:ctx_tokens])
+    ref.eval(ids[ctx_tokens:ctx_tokens + 2])    # warm
+    t0 = time.perf_counter()
+    for i in range(1, steps + 1):
+        ref.eval(ids[ctx_tokens + 2 * i:ctx_tokens + 2 * i + 2])
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    return dict(value=ms, unit="ms per S=2 LM step", cores=os.cpu_count(), kind="port",
+                sample=f"{steps} S=2 steps of LMRef (fp32 torch, {os.cpu_count()} threads) at Llama-3.2-1B dims, V={cfg.vocab_size}, "
+                       f"context {ctx_tokens}+ tokens; weights regenerated from the device hash in {gen_s:.1f} s")
+
+
+def latest_profile_traffic():
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC passes (profiles/rNN/traffic.json, written by
+    scripts/collect_profiles.py from separate rocprofv3 --pmc runs: FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE).  None when
+    no such file is committed -- the number is a property of the profiled build, never of this run."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        return float(d["conv1d_mfma_kernel"]["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` with N > 1 outside a launcher: start the N ranks as CHILD processes (one per GPU, the reference's
+    own form of parallelism: encode_audio_gpu_{1..4}.sh, realtime_agent_v2.py:832-836) before anything here has touched the GPU,
+    relay rank 0's JSON line and the exit code.  Never an exec of a process that holds the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{") and '"metric"' in ln), None)
+    if line is not None:
+        print(line)
+    else:
+        sys.stdout.write(r.stdout)
+    return r.returncode if line is not None or r.returncode else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,11 +133,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-duplex", action="store_true")
     ap.add_argument("--no-trim-leg", action="store_true", help="skip the receptive-field-trimmed batch leg (profiling runs: keeps per-kernel averages to the headline path)")
-    ap.add_argument("--duplex-secs", type=float, default=60.0)
+    ap.add_argument("--duplex-secs", type=float, default=125.0,
+                    help="audio seconds of the duplex leg; >= 110 puts two sliding-window trims (80 s context, trim by 20 s) inside the timed window")
     ap.add_argument("--variant", type=int, default=1)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))          # nothing above this line has touched the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU (python bench.py --gpus N does it itself)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -151,29 +217,29 @@ def main():
 
     # SURVEY 8f-1 leg (reported beside the headline, never as `value`): the same steps with every window cut down
     # to the receptive field of its kept frames -- identical codes (checked), ~10x less encoder work
-    codes_full = codes.clone()
-    hip.set_window_trim(not args.no_trim_leg)
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, total_steps):
-        step(i)
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    elapsed_trim = time.perf_counter() - t0
-    hip.set_window_trim(False)
-    if dist is not None:
-        t = torch.tensor([elapsed_trim], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed_trim = float(t.item())
-    trim_identical = bool(torch.equal(codes, codes_full))
-    assert trim_identical, "window-trimmed batch encode produced different codes"
-    if args.no_trim_leg:
-        elapsed_trim = 1.0
+    elapsed_trim, trim_identical = None, None
+    if not args.no_trim_leg:
+        codes_full = codes.clone()
+        hip.set_window_trim(True)
+        for i in range(args.warmup):
+            step(i)
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(args.warmup, total_steps):
+            step(i)
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        elapsed_trim = time.perf_counter() - t0
+        hip.set_window_trim(False)
+        if dist is not None:
+            t = torch.tensor([elapsed_trim], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed_trim = float(t.item())
+        trim_identical = bool(torch.equal(codes, codes_full))
+        assert trim_identical, "window-trimmed batch encode produced different codes"
 
     prof = {k: hip.profile_read(k) for k in (0, 1, 2, 3)}
     audio_secs = args.steps * chunks_per_step * chunk / cfg.sample_rate  # per rank, stereo seconds
@@ -184,6 +250,7 @@ def main():
     sample = codes[:, : 64 * fpc].cpu().numpy()
     assert sample.min() >= 0 and sample.max() < cfg.codebook_size
 
+    traffic, traffic_src = latest_profile_traffic()
     out = {
         "metric": "batch-encode audio-hours/hour (+ xRT and p50 frame-step latency of 1 duplex stream in `duplex`)",
         "value": value,
@@ -200,6 +267,10 @@ def main():
         "config": {
             "workload": "batch MagiCodec-style encode, 16 kHz stereo, 0.1 s chunks / 2.0 s context, 256 windows per step (BASELINE configs[1])",
             "windows_per_step": args.batch_windows,
+            # the codebook search runs on the frames a window KEEPS (its chunk's own codes), not on all 100 frames of the window: the
+            # quantiser is per-frame, so the discarded 95 never influence an output (SURVEY 8d counts 25 600 rows per step)
+            "vq_rows_per_step": args.batch_windows * fpc,
+            "vq_rows_per_step_if_every_window_frame_were_searched": args.batch_windows * (max(chunk, ctx) // cfg.hop),
             "audio_hours_timed_per_gpu": audio_secs / 3600.0,
             "channel_hours_per_hour": value * C,
             "codebook": f"{cfg.codebook_size}x{cfg.codebook_dim}",
@@ -221,8 +292,8 @@ def main():
             "frac": achieved / F32_MFMA_PEAK_TFLOPS,
             # HBM bytes per launch of this kernel from the committed PMC passes (profiles/r01: FETCH_SIZE x2 per
             # the gfx950 note + WRITE_SIZE, separate rocprofv3 --pmc runs); algorithmic bytes for comparison
-            "traffic": 1.026e9,
-            "traffic_source": "profiles/r01/SUMMARY.txt (avg over the 5 conv launches of a step)",
+            "traffic": traffic,
+            "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": conv["bytes"] / max(1, conv["launches"]),
             "avg_launch_ms": conv["ms"] / max(1, conv["launches"]),
             "launches": conv["launches"],
@@ -238,16 +309,21 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_encode(cfg, weights, chunk, ctx, 64, C)
+        if not args.no_duplex:
+            from realtime_codec_agent_amd.llm import LMConfig
+            out["cpu_baseline"]["lm_step"] = cpu_baseline_lm_step(LMConfig.llama_3_2_1b())
     if not args.no_duplex:
         # one independent duplex session per GPU (BASELINE configs[3]/[4]; no exchange between sessions)
         from realtime_codec_agent_amd.duplex_bench import run_duplex_bench
         mine = run_duplex_bench(dev, secs=args.duplex_secs if world == 1 else min(args.duplex_secs, 10.0))
         if dist is not None:
             allr = [None] * world
-            dist.all_gather_object(allr, {k: mine[k] for k in ("xRT", "p50_frame_step_ms", "p95_frame_step_ms", "lm_step_ms")})
+            dist.all_gather_object(allr, {k: mine[k] for k in ("xRT", "p50_frame_step_ms", "p95_frame_step_ms", "p99_frame_step_ms", "max_frame_step_ms",
+                                                                "frames_over_budget", "lm_step_ms")})
             mine = dict(mine, sessions=world, per_gpu=allr, xRT_min=min(r["xRT"] for r in allr),
                         p50_frame_step_ms_max=max(r["p50_frame_step_ms"] for r in allr))
         out["duplex"] = mine
+        out["roofline_lm"] = mine.pop("roofline_lm")
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
