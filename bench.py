@@ -61,13 +61,14 @@ def cpu_baseline_encode(cfg, weights, chunk, ctx, n_chunks, channels):
                 sample=f"{len(wins)} windows of {W} samples ({n_chunks} chunk positions x {channels} ch) in {dt:.2f} s, OpenMP x{os.cpu_count()}")
 
 
-def cpu_baseline_lm_step(cfg, ctx_tokens=64, steps=4):
+def cpu_baseline_lm_step(cfg, ctx_tokens=64, steps=3):
     """The LM oracle (oracle/lm_ref.py::LMRef, fp32 torch on the host cores, kind 'port': the reference's realtime LM is
     llama.cpp, absent offline) at the SAME dims and hash-generated weights as the GPU model: S=2 decode steps on top of a
     short context.  Bounded: weight generation ~10 s, a step streams 6 GB of fp32 weights."""
     import torch as _t
     from oracle import lm_ref
-    _t.set_num_threads(os.cpu_count())
+    threads = min(os.cpu_count(), 32)     # M=2 GEMVs: more threads than memory channels only add contention (256 threads: 42 s per step)
+    _t.set_num_threads(threads)
     rng = np.random.default_rng(7)
     ids = rng.integers(128266, 128266 + 131072, ctx_tokens + 2 * (steps + 1))
     t0 = time.perf_counter()
@@ -79,8 +80,8 @@ def cpu_baseline_lm_step(cfg, ctx_tokens=64, steps=4):
     for i in range(1, steps + 1):
         ref.eval(ids[ctx_tokens + 2 * i:ctx_tokens + 2 * i + 2])
     ms = (time.perf_counter() - t0) * 1e3 / steps
-    return dict(value=ms, unit="ms per S=2 LM step", cores=os.cpu_count(), kind="port",
-                sample=f"{steps} S=2 steps of LMRef (fp32 torch, {os.cpu_count()} threads) at Llama-3.2-1B dims, V={cfg.vocab_size}, "
+    return dict(value=ms, unit="ms per S=2 LM step", cores=threads, kind="port",
+                sample=f"{steps} S=2 steps of LMRef (fp32 torch, {threads} threads) at Llama-3.2-1B dims, V={cfg.vocab_size}, "
                        f"context {ctx_tokens}+ tokens; weights regenerated from the device hash in {gen_s:.1f} s")
 
 

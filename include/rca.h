@@ -243,6 +243,20 @@ int rca_lm_reset(rca_lm_t* h);
 /* Llama.eval(tokens): append n ids at position n_tokens, run the forward, keep the
  * last position's logits (every position's when logits_all) (llamacpp_utils.py:150) */
 int rca_lm_eval(rca_lm_t* h, const int32_t* ids, int32_t n);
+/* Llama.eval that returns once its LAST pass (a 128-token prefill tile, or a 1-2 token decode pass) is enqueued instead of
+ * finished; any later call on the handle waits for it first.  The pieces are evaluated with the arithmetic of ONE long eval
+ * (prefill tiles even for a handful of tokens), so a cache built piecewise equals the cache of a single rca_lm_eval.  Used to build the post-trim KV cache ahead of the sliding-window
+ * trim (realtime_agent_v2.py:187-190,725-733) on a weight-sharing twin while the live handle keeps stepping. */
+int rca_lm_eval_async(rca_lm_t* h, const int32_t* ids, int32_t n);
+/* The reference recomputes the KV cache of the surviving context inside the frame that trims (realtime_agent_v2.py:725-733:
+ * n_tokens = header, eval(suffix)).  Here a twin handle (rca_lm_create_shared, same n_ctx) can be given the header's KV
+ * (rca_lm_copy_kv: positions [0, n_pos) of every layer, device to device), be fed the suffix over the preceding frames, and
+ * trade caches with the live handle at the trim (rca_lm_swap_kv: O(1), both streams are drained first; captured step graphs
+ * are kept per cache).  n_tokens is not exchanged: the caller sets it, as the reference does. */
+int rca_lm_copy_kv(rca_lm_t* dst, rca_lm_t* src, int32_t n_pos);
+int rca_lm_swap_kv(rca_lm_t* a, rca_lm_t* b);
+/* run the handle's stream at the device's lowest (1) / highest (0) stream priority: background prefill next to a live session */
+int rca_lm_set_low_priority(rca_lm_t* h, int32_t enable);
 /* read / write Llama.n_tokens: the agent rolls the KV cache back by writing it
  * (realtime_agent_v2.py:208,219,261,465,730); stale slots are overwritten by the next eval */
 int rca_lm_get_n_tokens(const rca_lm_t* h, int32_t* n);

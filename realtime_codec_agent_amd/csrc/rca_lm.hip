@@ -30,9 +30,10 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 #define LM_MAXM 128        // tokens per forward pass (activation buffers); the 128-token prefill tiles use all of them
 #define LM_TILE32 32       // token tile of the small-model prefill kernels (lm_gemm_mfma_kernel)
-#define LM_GEMV_M 8        // largest pass served by the GEMV kernels; longer evals go through the MFMA prefill path
-#define LM_KSLICE 2048     // K handled by one workgroup pass of the GEMV
-#define LM_MAXSPLIT 4      // K splits (ffn 8192 / 2048)
+#define LM_GEMV_M 2        // tokens per decode pass (GEMV kernels); evals longer than LM_PREFILL_MIN go through the MFMA prefill path
+#define LM_PREFILL_MIN 8    // evals of up to this many tokens are decode passes, longer ones prefill tiles
+#define LM_KSLICE 2048     // widest hidden / attention-output dimension (one 16-byte chunk per lane and wave in the GEMV)
+#define LM_MAXSPLIT 4      // ffn <= LM_KSLICE * LM_MAXSPLIT (up to four chunks per lane and wave)
 #define ATT_KEYS 256       // keys per attention workgroup (8 waves x 32 keys)
 #define LM_GRAPH_BUCKETS 8  // 4, 8, ..., 256 splits, the last bucket = all of them
 #define SAMP_MAXK 256
@@ -224,304 +225,229 @@ __global__ __launch_bounds__(64) void lm_add_rmsnorm_kernel(const LmDevState* __
     }
 }
 
-// ------------------------------------------------------------------------------------ GEMV
-// y[slice][m][n] = sum_{k in slice} W[n][k] * x[m][k].   One wave owns 2 rows at a time and walks
-// its K slice (<= 2048) in 16-byte (8 x bf16) lane chunks, all of a row pair's loads issued before
-// the first use; x sits in LDS as f32.
-//   PRO 1: prologue = residual add + RMSNorm: v = xin[m] + sum_s parts[s][m]; the first workgroup
-//          writes v to xout (ping-pong residual stream); xs = v * rsqrt(mean(v^2)+eps) * norm_w
-//   EPI 0: store partial sums                 EPI 1: rows (2i, 2i+1) = (gate_i, up_i): h = silu(g)*u
-//   EPI 2: QKV rows paired (d, d+32) inside each head: RoPE (HF rotate_half), q back to qkv[],
-//          k / v straight into the fp16 KV cache at position n_tokens + m
+// ------------------------------------------------------------------------------------ GEMV (decode passes, M <= 2)
+// y[m][n] = sum_k W[n][k] * x[m][k] for the 1-2 tokens of a decode pass, weights streamed ONCE with non-temporal 16-byte
+// loads.  Shape of the kernel:
+//   * the 4 waves of a workgroup split K: wave w owns the chunk range [w * cpw, (w + 1) * cpw) (a chunk = 8 bf16 = one
+//     16-byte lane load), so a lane keeps only ITS x values in registers (8 * NIT * M floats: 16 for the 2048-wide
+//     projections) and the registers go to weights in flight instead: R rows x NIT chunks are requested per batch before
+//     anything is consumed (R = 16: 16 KB per wave, ~200 KB per CU);
+//   * per lane, per (row, token): one fma chain over its chunks (chunk ascending, element ascending);
+//   * the R * M partial sums of a batch are reduced across the 64 lanes TOGETHER: two transposing steps on the gfx950
+//     permlane swaps (xor 32, xor 16: every exchange halves the number of live registers) and four DPP steps inside the
+//     rows of 16 -- R * M / 4 + ... instead of R * M butterflies; lane 0 of row q then holds value i + (V/4)(q&1) + (V/2)(q>>1);
+//   * the 4 waves' sums meet in LDS (double-buffered by batch parity: one barrier per batch) and are added in wave order by
+//     the first V threads, which run the fused epilogue.
+// Any (R, batches per workgroup) gives the same bits: a value's reduction sequence does not depend on its slot.
+//   PRO 1: prologue = RMSNorm of the residual row(s): each wave squares its own K range, the 4 partial sums are added in
+//          wave order; xs = (v * rstd) * norm_w.  only_last: the single row handled is the pass's last token (head).
+//   EPI 0: store (logits)          EPI 1: rows (2i, 2i+1) = (gate_i, up_i): h = silu(g) * u
+//   EPI 2: QKV rows paired (d, d+32) inside each head: RoPE (HF rotate_half), q back to qkv[], k / v straight into the
+//          fp16 KV cache at position n_tokens + m          EPI 3: add into the residual stream in place
 struct GemvPro {
-    const float* xin; float* xout; const float* parts; int nparts; long part_stride; const float* norm_w; float eps; int only_last;
+    const float* xin; const float* norm_w; float eps; int only_last;
 };
 struct GemvRope {
     const float* cos_t; const float* sin_t; f16_t* kc; f16_t* vc; int nh, nkv, n_ctx;
 };
-template <int M, int PRO, int EPI, int KW, int XR>
+__device__ __forceinline__ void lane_swap32(float& a, float& b) {   // a = [a.lo, b.lo], b = [a.hi, b.hi]
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void lane_swap16(float& a, float& b) {   // a = [a.r0, b.r0, a.r2, b.r2], b = [a.r1, b.r1, a.r3, b.r3]
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float row16_sum(float v) {   // sum over the 16 lanes of a DPP row, every lane gets it
+    v = v + dpp_mov<DPP_ROR8>(v);
+    v = v + dpp_mov<DPP_ROR4>(v);
+    v = v + dpp_mov<DPP_XOR2>(v);
+    v = v + dpp_mov<DPP_XOR1>(v);
+    return v;
+}
+// V values per lane -> V / 4 registers; afterwards register i of row q (16 lanes) holds the full sum of value
+// i + (V / 4) * (q & 1) + (V / 2) * (q >> 1).  V is a multiple of 4.
+template <int V>
+__device__ __forceinline__ void wave_reduce_transposed(float (&val)[V]) {
+#pragma unroll
+    for (int i = 0; i < V / 2; ++i) {
+        lane_swap32(val[i], val[i + V / 2]);
+        val[i] = val[i] + val[i + V / 2];
+    }
+#pragma unroll
+    for (int i = 0; i < V / 4; ++i) {
+        lane_swap16(val[i], val[i + V / 4]);
+        val[i] = val[i] + val[i + V / 4];
+    }
+#pragma unroll
+    for (int i = 0; i < V / 4; ++i) val[i] = row16_sum(val[i]);
+}
+
+template <int M, int NIT, int R, int PRO, int EPI>
 __global__ __launch_bounds__(256) void lm_gemv_kernel(const LmDevState* __restrict__ stt, const bf16_t* __restrict__ W,
-                                                      const float* __restrict__ x, float* __restrict__ y, int N, int K, int kslice,
-                                                      int rows_per_wg, long y_slice_stride, int ldy, GemvPro pro, GemvRope rope) {
-    // KW = 1: the 4 waves of the workgroup split K between them (kslice = K/4 each) and work on the SAME row
-    // pair; their partial sums are added in wave order on top of the residual (EPI 3).
-    // XR = 1 (decode, M <= 2): x lives in REGISTERS -- each lane loads exactly the chunks it multiplies
-    // (c = lane + 64*it) straight from L2, every wave normalises its own copy (lm_row_norm), and there is no LDS
-    // staging and no workgroup barrier in front of the weight stream.  XR = 0 keeps x in LDS (prefill, M > 2).
-    extern __shared__ __attribute__((aligned(16))) float xs[];  // [M][KW ? K : kslice]
-    __shared__ float red[M][4];
-    __shared__ float kred[4][2][M];
+                                                      const float* __restrict__ x, float* __restrict__ y, int N, int K,
+                                                      int batches_per_wg, int ldy, GemvPro pro, GemvRope rope) {
+    constexpr int V = R * M;
+    static_assert(V % 4 == 0 && R % 2 == 0, "R * M must be a multiple of 4");
+    __shared__ float kred[2][4][V];
+    __shared__ float nred[M][4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int sl = KW ? wave : blockIdx.y;
-    const int k0 = sl * kslice;
-    const int kl = min(kslice, K - k0);
-    const int xld = KW ? K : kslice;      // LDS row stride
-    const int xoff = KW ? k0 : 0;         // this wave's slice inside the LDS row
-    const int nchunk = kl >> 3;           // 8-element chunks in this slice (<= 256)
-    const int row_beg = blockIdx.x * rows_per_wg;
-    const int row_end = min(N, row_beg + rows_per_wg);
-    const int rstep = KW ? 2 : 8;
-    auto rows_of = [&](int rb, int& r0, int& r1) {
-        r0 = rb; r1 = rb + 1;
-        if (EPI == 2) {  // pair index -> rows (d, d+32) of one head
-            const int pidx = rb >> 1;
-            r0 = (pidx >> 5) * 64 + (pidx & 31);
-            r1 = r0 + 32;
+    const int tid = threadIdx.x;
+    const int nchunk = K >> 3;
+    const int cpw = (nchunk + 3) >> 2;                       // chunks per wave
+    const int c0 = wave * cpw;
+    const int cn = max(0, min(cpw, nchunk - c0));            // this wave's chunk count (<= 64 * NIT)
+    const int n_batches = (N + R - 1) / R;
+    const int b_beg = blockIdx.x * batches_per_wg;
+    const int b_end = min(n_batches, b_beg + batches_per_wg);
+    // slot r of batch b -> weight row
+    auto row_of = [&](int b, int r) {
+        if (EPI == 2) {   // slots (2s, 2s+1) = rows (d, d+32) of one head
+            const int pair = b * (R / 2) + (r >> 1);
+            return (pair >> 5) * 64 + (pair & 31) + 32 * (r & 1);
         }
+        return b * R + r;
     };
-    u32x4 wa[4], wb[4];
-    auto load_rows = [&](int rb) {
-        int r0, r1;
-        rows_of(rb, r0, r1);
-        const u32x4* w0 = reinterpret_cast<const u32x4*>(W + (long)r0 * K + k0);
-        const u32x4* w1 = reinterpret_cast<const u32x4*>(W + (long)(r1 < N ? r1 : r0) * K + k0);
+    u32x4 wq[R][NIT];
+    auto load_batch = [&](int b) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int c = lane + 64 * it;
-            if (c < nchunk) {
-                wa[it] = __builtin_nontemporal_load(w0 + c);
-                wb[it] = __builtin_nontemporal_load(w1 + c);
+        for (int r = 0; r < R; ++r) {
+            const int row = min(row_of(b, r), N - 1);
+            const u32x4* wr = reinterpret_cast<const u32x4*>(W + (long)row * K) + c0;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = lane + 64 * it;
+                if (c < cn) wq[r][it] = __builtin_nontemporal_load(wr + c);
+                else wq[r][it] = u32x4{0u, 0u, 0u, 0u};
             }
         }
     };
-    // the first row pair's weights do not depend on x: get them in flight before the prologue
-    const int rb0 = row_beg + (KW ? 0 : wave * 2);
-    if (rb0 < row_end) load_rows(rb0);
+    // the first batch's weights do not depend on x: get them in flight before the prologue
+    if (b_beg < b_end) load_batch(b_beg);
 
-    float xr[XR ? M : 1][4][8];
-    // RoPE rows of this step's positions (EPI 2): lane l holds cos/sin[pos0 + m][l & 31], fetched now and read with
-    // a lane broadcast in the epilogue instead of a dependent load at the tail of the kernel
-    float cosv[EPI == 2 ? M : 1], sinv[EPI == 2 ? M : 1];
-    int ep_m = M, ep_pos0 = 0;
-    if (EPI == 2) {
-        ep_m = stt->m; ep_pos0 = stt->n_tokens;
+    // ---- this lane's x values
+    float xr[M][NIT][8];
+    {
+        int mbase = 0;
+        if (PRO == 1 && pro.only_last) mbase = stt->m - 1;
+        const float* xsrc = PRO == 1 ? pro.xin : x;
 #pragma unroll
-        for (int m = 0; m < M; ++m) {
-            const long pos = min(ep_pos0 + m, rope.n_ctx - 1);
-            cosv[m] = rope.cos_t[pos * 32 + (lane & 31)];
-            sinv[m] = rope.sin_t[pos * 32 + (lane & 31)];
-        }
-    }
-    if (EPI == 3) ep_m = stt->m;
-    if (XR) {
+        for (int m = 0; m < M; ++m)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = lane + 64 * it;
+                if (c < cn) {
+                    const float* p = xsrc + (long)(mbase + m) * K + (long)(c0 + c) * 8;
+                    const float4 a = *reinterpret_cast<const float4*>(p);
+                    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+                    xr[m][it][0] = a.x; xr[m][it][1] = a.y; xr[m][it][2] = a.z; xr[m][it][3] = a.w;
+                    xr[m][it][4] = b.x; xr[m][it][5] = b.y; xr[m][it][6] = b.z; xr[m][it][7] = b.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xr[m][it][j] = 0.0f;
+                }
+            }
         if (PRO == 1) {
-            // decode passes carry exactly M live rows: only the last-row head pass has to wait for the step state
-            int Mv = M, mbase = 0;
-            if (pro.only_last) { Mv = stt->m; mbase = Mv - 1; }
 #pragma unroll
             for (int m = 0; m < M; ++m) {
-                const int mr = mbase + m;
-                const bool valid = mr < Mv;
-                lm_load_row(xr[m], pro.xin + (long)(valid ? mr : 0) * K, nchunk, valid);
-                for (int s2 = 0; s2 < pro.nparts; ++s2)
-                    if (valid) lm_add_row(xr[m], pro.parts + s2 * pro.part_stride + (long)mr * K, nchunk);
-                if (pro.xout && blockIdx.x == 0 && wave == 0 && valid) lm_store_row(xr[m], pro.xout + (long)mr * K, nchunk);
-                const float rstd = lm_row_norm(xr[m], nchunk, K, pro.eps, [](int, int) {});
-                lm_scale_row(xr[m], rstd, pro.norm_w, nchunk);
-            }
-        } else {
+                float ss = 0.0f;
 #pragma unroll
-            for (int m = 0; m < M; ++m) lm_load_row(xr[m], x + (long)m * K + k0, nchunk, true);
-        }
-    } else {
-        if (PRO == 1) {
-            // rows of the residual stream handled by this pass (only_last: just the final token)
-            const int Mv = stt->m;
-            const int mbase = pro.only_last ? Mv - 1 : 0;
-            float ss[M];
-            // K <= 2048: at most 8 elements per thread and token; all loads are issued before any is used
-            float pv[M][8];
-    #pragma unroll
-            for (int m = 0; m < M; ++m) {
-                ss[m] = 0.0f;
-                const int mr = mbase + m;
-    #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int k = threadIdx.x + 256 * i;
-                    pv[m][i] = (mr < Mv && k < K) ? pro.xin[(long)mr * K + k] : 0.0f;
-                }
-            }
-            for (int s2 = 0; s2 < pro.nparts; ++s2) {
-    #pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    const int mr = mbase + m;
-    #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int k = threadIdx.x + 256 * i;
-                        if (mr < Mv && k < K) pv[m][i] += pro.parts[s2 * pro.part_stride + (long)mr * K + k];
-                    }
-                }
-            }
-    #pragma unroll
-            for (int m = 0; m < M; ++m) {
-                const int mr = mbase + m;
-    #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int k = threadIdx.x + 256 * i;
-                    if (k < K) {
-                        const float v = pv[m][i];
-                        if (blockIdx.x == 0 && pro.xout && mr < Mv) pro.xout[(long)mr * K + k] = v;
-                        xs[m * xld + k] = v;
-                        ss[m] = __builtin_fmaf(v, v, ss[m]);
-                    }
-                }
-            }
-    #pragma unroll
-            for (int m = 0; m < M; ++m) {
-                const float t = wave_sum(ss[m]);
-                if (lane == 0) red[m][wave] = t;
+                for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ss = __builtin_fmaf(xr[m][it][j], xr[m][it][j], ss);
+                ss = wave_sum(ss);
+                if (lane == 0) nred[m][wave] = ss;
             }
             __syncthreads();
-            float rstd[M];
-    #pragma unroll
-            for (int m = 0; m < M; ++m) rstd[m] = rsqrtf((red[m][0] + red[m][1] + red[m][2] + red[m][3]) / (float)K + pro.eps);
-    #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int k = threadIdx.x + 256 * i;
-                if (k < K) {
-                    const float w = pro.norm_w[k];
-    #pragma unroll
-                    for (int m = 0; m < M; ++m) xs[m * xld + k] = (pv[m][i] * rstd[m]) * w;
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const float tot = ((nred[m][0] + nred[m][1]) + nred[m][2]) + nred[m][3];
+                const float rstd = rsqrtf(tot / (float)K + pro.eps);
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int c = lane + 64 * it;
+                    if (c < cn) {
+                        const float* p = pro.norm_w + (long)(c0 + c) * 8;
+                        const float4 a = *reinterpret_cast<const float4*>(p);
+                        const float4 b = *reinterpret_cast<const float4*>(p + 4);
+                        const float wv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) xr[m][it][j] = (xr[m][it][j] * rstd) * wv[j];
+                    }
                 }
             }
-        } else if (KW) {
-            // M*K/4 <= 4096 float4: 16 per thread, loaded in two batches of 8
-            const int n4 = (M * K) >> 2;
-    #pragma unroll
-            for (int b8 = 0; b8 < 2; ++b8) {
-                float4 t[8];
-    #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int j = threadIdx.x + 256 * (b8 * 8 + i);
-                    if (j < n4) t[i] = reinterpret_cast<const float4*>(x)[j];
-                }
-    #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int j = threadIdx.x + 256 * (b8 * 8 + i);
-                    if (j < n4) reinterpret_cast<float4*>(xs)[j] = t[i];
-                }
+        }
+    }
+    int pos0 = 0;
+    if (EPI == 2) pos0 = stt->n_tokens;
+
+    for (int b = b_beg; b < b_end; ++b) {
+        float val[V];   // value index v = m * R + r
+#pragma unroll
+        for (int v = 0; v < V; ++v) val[v] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const u32x4 a = wq[r][it];
+                const float f[8] = {bf16_lo(a.x), bf16_hi(a.x), bf16_lo(a.y), bf16_hi(a.y), bf16_lo(a.z), bf16_hi(a.z), bf16_lo(a.w), bf16_hi(a.w)};
+#pragma unroll
+                for (int m = 0; m < M; ++m)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) val[m * R + r] = __builtin_fmaf(f[j], xr[m][it][j], val[m * R + r]);
             }
-        } else {
-            const int kl4 = kl >> 2;
-            for (int i = threadIdx.x; i < M * kl4; i += 256) {
-                const int m = i / kl4, k4 = i - m * kl4;
-                reinterpret_cast<float4*>(xs + m * xld)[k4] = reinterpret_cast<const float4*>(x + (long)m * K + k0)[k4];
-            }
+        }
+        // the weight registers are free: request the next batch before the (latency-bound) reduction and epilogue
+        if (b + 1 < b_end) load_batch(b + 1);
+        // epilogue operands that do not depend on the sums (fetched under the reduction)
+        float yv = 0.0f, cs = 0.0f, sn = 0.0f;
+        if (EPI == 3 && tid < V) {
+            const int m = tid / R, row = row_of(b, tid % R);
+            if (row < N) yv = y[(long)m * ldy + row];
+        }
+        if (EPI == 2 && tid < V / 2) {
+            const int m = tid / (R / 2), s = tid % (R / 2);
+            const int d = (b * (R / 2) + s) & 31;
+            const long pos = min(pos0 + m, rope.n_ctx - 1);
+            cs = rope.cos_t[pos * 32 + d];
+            sn = rope.sin_t[pos * 32 + d];
+        }
+        wave_reduce_transposed<V>(val);
+        const int buf = (b - b_beg) & 1;
+        if ((lane & 15) == 0) {
+            const int q = lane >> 4;
+#pragma unroll
+            for (int i = 0; i < V / 4; ++i) kred[buf][wave][i + (V / 4) * (q & 1) + (V / 2) * (q >> 1)] = val[i];
         }
         __syncthreads();
-    }
-    for (int rb = rb0; rb < row_end; rb += rstep) {
-        int r0, r1;
-        rows_of(rb, r0, r1);
-        const bool has2 = r1 < N;
-        float acc[2][M];
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-            for (int m = 0; m < M; ++m) acc[rr][m] = 0.0f;
-        // unpack this pair to f32, then immediately refill the weight registers with the next pair
-        float fa[4][8], fb[4][8];
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const u32x4 a = wa[it], b = wb[it];
-            fa[it][0] = bf16_lo(a.x); fa[it][1] = bf16_hi(a.x); fa[it][2] = bf16_lo(a.y); fa[it][3] = bf16_hi(a.y);
-            fa[it][4] = bf16_lo(a.z); fa[it][5] = bf16_hi(a.z); fa[it][6] = bf16_lo(a.w); fa[it][7] = bf16_hi(a.w);
-            fb[it][0] = bf16_lo(b.x); fb[it][1] = bf16_hi(b.x); fb[it][2] = bf16_lo(b.y); fb[it][3] = bf16_hi(b.y);
-            fb[it][4] = bf16_lo(b.z); fb[it][5] = bf16_hi(b.z); fb[it][6] = bf16_lo(b.w); fb[it][7] = bf16_hi(b.w);
-        }
-        if (rb + rstep < row_end) load_rows(rb + rstep);
-        // residual values this pair is added to (EPI 3): fetched under the FMA block, not after the reduction
-        float yv[2][M];
-        float ykw = 0.0f;
-        if (EPI == 3) {
-            if (KW) {
-                if (threadIdx.x < 2 * M) {
-                    const int rr = threadIdx.x / M, m = threadIdx.x % M;
-                    const int r = rr ? r1 : r0;
-                    if (r < N && m < ep_m) ykw = y[(long)m * ldy + r];
-                }
-            } else if (lane == 0) {
-#pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    yv[0][m] = m < ep_m ? y[(long)m * ldy + r0] : 0.0f;
-                    yv[1][m] = (m < ep_m && has2) ? y[(long)m * ldy + r1] : 0.0f;
+        auto total = [&](int v) { return ((kred[buf][0][v] + kred[buf][1][v]) + kred[buf][2][v]) + kred[buf][3][v]; };
+        if (EPI == 0 || EPI == 3) {
+            if (tid < V) {
+                const int m = tid / R, row = row_of(b, tid % R);
+                if (row < N) y[(long)m * ldy + row] = EPI == 3 ? yv + total(tid) : total(tid);
+            }
+        } else if (EPI == 1) {
+            if (tid < V / 2) {
+                const int m = tid / (R / 2), s = tid % (R / 2);
+                const int row = b * R + 2 * s;
+                if (row + 1 < N) {
+                    const float g = total(m * R + 2 * s), u = total(m * R + 2 * s + 1);
+                    y[(long)m * ldy + (row >> 1)] = (g / (1.0f + __expf(-g))) * u;
                 }
             }
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int c = lane + 64 * it;
-            if (c < nchunk) {
-#pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    float xv[8];
-                    if (XR) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) xv[j] = xr[m][it][j];
-                    } else {
-                        const float4 x0 = *reinterpret_cast<const float4*>(xs + m * xld + xoff + c * 8);
-                        const float4 x1 = *reinterpret_cast<const float4*>(xs + m * xld + xoff + c * 8 + 4);
-                        xv[0] = x0.x; xv[1] = x0.y; xv[2] = x0.z; xv[3] = x0.w; xv[4] = x1.x; xv[5] = x1.y; xv[6] = x1.z; xv[7] = x1.w;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        acc[0][m] = __builtin_fmaf(fa[it][j], xv[j], acc[0][m]);
-                        acc[1][m] = __builtin_fmaf(fb[it][j], xv[j], acc[1][m]);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-            for (int m = 0; m < M; ++m) acc[rr][m] = wave_sum(acc[rr][m]);
-        if (KW) {
-            if (lane == 0) {
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-                    for (int m = 0; m < M; ++m) kred[wave][rr][m] = acc[rr][m];
-            }
-            __syncthreads();
-            if (threadIdx.x < 2 * M) {
-                const int rr = threadIdx.x / M, m = threadIdx.x % M;
-                const int r = rr ? r1 : r0;
-                if (r < N && m < ep_m) {
-                    float v = ykw;
-                    v += kred[0][rr][m]; v += kred[1][rr][m]; v += kred[2][rr][m]; v += kred[3][rr][m];
-                    y[(long)m * ldy + r] = v;
-                }
-            }
-            __syncthreads();
-        } else if (lane == 0) {
-            if (EPI == 1) {
-#pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    const float g = acc[0][m], u = acc[1][m];
-                    y[(long)m * ldy + (r0 >> 1)] = (g / (1.0f + __expf(-g))) * u;
-                }
-            } else if (EPI == 2) {
-                const int head = r0 >> 6, d = r0 & 63;  // d < 32
-                float cs[M], sn_[M];
-#pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    cs[m] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cosv[m]), __builtin_amdgcn_readfirstlane(d)));
-                    sn_[m] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sinv[m]), __builtin_amdgcn_readfirstlane(d)));
-                }
-                const int Mv = ep_m, pos0 = ep_pos0;
-#pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    const int pos = pos0 + m;
-                    if (m >= Mv || pos >= rope.n_ctx) continue;
-                    const float x1 = acc[0][m], x2 = acc[1][m];
+        } else {
+            if (tid < V / 2) {
+                const int m = tid / (R / 2), s = tid % (R / 2);
+                const int r0 = row_of(b, 2 * s);
+                const int pos = pos0 + m;
+                if (r0 + 32 < N && pos < rope.n_ctx) {
+                    const float x1 = total(m * R + 2 * s), x2 = total(m * R + 2 * s + 1);
+                    const int head = r0 >> 6, d = r0 & 63;   // d < 32
                     if (head < rope.nh + rope.nkv) {
-                        const float c = cs[m], sn = sn_[m];
-                        const float o1 = x1 * c + (-x2) * sn;
-                        const float o2 = x2 * c + x1 * sn;
+                        const float o1 = x1 * cs + (-x2) * sn;
+                        const float o2 = x2 * cs + x1 * sn;
                         if (head < rope.nh) {
                             y[(long)m * ldy + r0] = o1;
-                            y[(long)m * ldy + r1] = o2;
+                            y[(long)m * ldy + r0 + 32] = o2;
                         } else {
                             f16_t* kp = rope.kc + ((long)pos * rope.nkv + (head - rope.nh)) * 64;
                             kp[d] = (f16_t)o1;
@@ -532,19 +458,6 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const LmDevState* __restri
                         vp[d] = (f16_t)x1;
                         vp[d + 32] = (f16_t)x2;
                     }
-                }
-            } else if (EPI == 3) {  // residual add in place (single K slice)
-#pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    if (m >= ep_m) continue;
-                    y[(long)m * ldy + r0] = yv[0][m] + acc[0][m];
-                    if (has2) y[(long)m * ldy + r1] = yv[1][m] + acc[1][m];
-                }
-            } else {
-#pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    y[sl * y_slice_stride + (long)m * ldy + r0] = acc[0][m];
-                    if (has2) y[sl * y_slice_stride + (long)m * ldy + r1] = acc[1][m];
                 }
             }
         }
@@ -1044,7 +957,7 @@ struct rca_lm {
     long kv_layer_stride = 0;
     int n_ctx_pad = 0, n_splits = 0;
     // activations
-    float *x = nullptr, *x2 = nullptr, *xn = nullptr, *qkv = nullptr, *attn = nullptr, *part_o = nullptr, *hbuf = nullptr, *part_d = nullptr,
+    float *x = nullptr, *xn = nullptr, *qkv = nullptr, *attn = nullptr, *hbuf = nullptr,
           *att_part = nullptr, *logits = nullptr, *probs_dev = nullptr;
     int* probe_ids_dev = nullptr;
     bf16_t *xh = nullptr, *xl = nullptr;   // prefill: bf16 hi / lo split of the current GEMM input [LM_MAXM][max K]
@@ -1057,10 +970,14 @@ struct rca_lm {
     LmDevState* h_stt = nullptr;   // pinned host staging (ids, n_tokens, m in; out_token back)
     int n_tokens = 0;           // host mirror (llama_cpp.Llama.n_tokens)
     bool sampler_set = false;
-    int ksplit_down = 1, kslice_down = 0;
     // captured steady-state steps (n = 1, 2)
     // decode-step graphs per (tokens 1..2, context bucket): bucket b launches min(n_splits, 4 << b) attention splits
-    hipGraphExec_t graph[3][LM_GRAPH_BUCKETS] = {};
+    // Two sets: the handle's KV cache can be exchanged with a twin's (rca_lm_swap_kv) and the cache address is baked into the
+    // captured kernel nodes, so a set remembers the cache it was captured over (at most two caches ever rotate through a handle).
+    struct GraphSet { const f16_t* kc = nullptr; hipGraphExec_t g[3][LM_GRAPH_BUCKETS] = {}; unsigned long long last_use = 0; };
+    GraphSet gset[2];
+    unsigned long long gset_clock = 0;
+    bool async_pending = false;   // an rca_lm_eval_async pass may still be running on the stream
     bool graphs_enabled = true;
     bool mfma_prefill = true;   // evals longer than LM_GEMV_M tokens use the bf16 MFMA tiles
     // weight sharing (rca_lm_create_shared): a borrower points at the handle that owns the weights and the RoPE tables; an owner
@@ -1089,10 +1006,27 @@ static void lm_free_weights(rca_lm* h) {
 
 // The captured step graphs carry the addresses of the logits buffer, the KV cache and the workspace in their kernel nodes:
 // whenever one of those is reallocated (or the handle goes away) every captured graph has to go with it.
-static void lm_drop_graphs(rca_lm* h) {
+static void lm_drop_graph_set(rca_lm::GraphSet& gs) {
     for (int i = 0; i < 3; ++i)
         for (int b = 0; b < LM_GRAPH_BUCKETS; ++b)
-            if (h->graph[i][b]) { (void)hipGraphExecDestroy(h->graph[i][b]); h->graph[i][b] = nullptr; }
+            if (gs.g[i][b]) { (void)hipGraphExecDestroy(gs.g[i][b]); gs.g[i][b] = nullptr; }
+    gs.kc = nullptr;
+}
+static void lm_drop_graphs(rca_lm* h) {
+    for (auto& gs : h->gset) lm_drop_graph_set(gs);
+}
+// the graph set captured over the KV cache that is installed now (evicting the older set if neither matches)
+static rca_lm::GraphSet& lm_graph_set(rca_lm* h) {
+    rca_lm::GraphSet* hit = nullptr;
+    for (auto& gs : h->gset)
+        if (gs.kc == h->kc) hit = &gs;
+    if (!hit) {
+        hit = h->gset[0].last_use <= h->gset[1].last_use ? &h->gset[0] : &h->gset[1];
+        lm_drop_graph_set(*hit);
+        hit->kc = h->kc;
+    }
+    hit->last_use = ++h->gset_clock;
+    return *hit;
 }
 
 extern "C" int rca_lm_destroy(rca_lm_t* h) {
@@ -1100,12 +1034,12 @@ extern "C" int rca_lm_destroy(rca_lm_t* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     lm_drop_graphs(h);
-    for (void* p : {(void*)h->kc, (void*)h->vc, (void*)h->x, (void*)h->x2, (void*)h->xn, (void*)h->qkv, (void*)h->attn, (void*)h->part_o, (void*)h->hbuf,
-                    (void*)h->part_d, (void*)h->att_part, (void*)h->logits, (void*)h->probs_dev, (void*)h->probe_ids_dev, (void*)h->xh, (void*)h->xl,
+    for (void* p : {(void*)h->kc, (void*)h->vc, (void*)h->x, (void*)h->xn, (void*)h->qkv, (void*)h->attn, (void*)h->hbuf,
+                    (void*)h->att_part, (void*)h->logits, (void*)h->probs_dev, (void*)h->probe_ids_dev, (void*)h->xh, (void*)h->xl,
                     (void*)h->gpart, (void*)h->stt, (void*)h->samp, (void*)h->swork})
         if (p) (void)hipFree(p);
     h->kc = h->vc = nullptr;
-    h->x = h->x2 = h->xn = h->qkv = h->attn = h->part_o = h->hbuf = h->part_d = h->att_part = h->logits = h->probs_dev = h->gpart = nullptr;
+    h->x = h->xn = h->qkv = h->attn = h->hbuf = h->att_part = h->logits = h->probs_dev = h->gpart = nullptr;
     h->probe_ids_dev = nullptr; h->xh = h->xl = nullptr; h->stt = nullptr; h->samp = nullptr; h->swork = nullptr;
     if (h->h_stt) { (void)hipHostFree(h->h_stt); h->h_stt = nullptr; }
     if (h->stream) { (void)hipStreamDestroy(h->stream); h->stream = nullptr; }
@@ -1231,16 +1165,11 @@ static int lm_common_init(rca_lm* h, const rca_tensor_t* ts, int nt, const rca_l
     RCA_HIP(hipMemsetAsync(h->vc, 0, kvb, h->stream));
     // activations
     const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim;
-    h->ksplit_down = (c.ffn + LM_KSLICE - 1) / LM_KSLICE;
-    h->kslice_down = c.ffn <= LM_KSLICE ? c.ffn : LM_KSLICE;
     if ((rc = lm_alloc((void**)&h->x, (size_t)LM_MAXM * H * 4)) != RCA_OK) return rc;
-    if ((rc = lm_alloc((void**)&h->x2, (size_t)LM_MAXM * H * 4)) != RCA_OK) return rc;
     if ((rc = lm_alloc((void**)&h->xn, (size_t)LM_MAXM * H * 4)) != RCA_OK) return rc;
     if ((rc = lm_alloc((void**)&h->qkv, (size_t)LM_MAXM * QKV * 4)) != RCA_OK) return rc;
     if ((rc = lm_alloc((void**)&h->attn, (size_t)LM_MAXM * AO * 4)) != RCA_OK) return rc;
-    if ((rc = lm_alloc((void**)&h->part_o, (size_t)LM_MAXM * H * 4)) != RCA_OK) return rc;
     if ((rc = lm_alloc((void**)&h->hbuf, (size_t)LM_MAXM * c.ffn * 4)) != RCA_OK) return rc;
-    if ((rc = lm_alloc((void**)&h->part_d, (size_t)LM_MAXSPLIT * LM_MAXM * H * 4)) != RCA_OK) return rc;
     if ((rc = lm_alloc((void**)&h->att_part, (size_t)(LM_MAXM / 2) * c.n_kv_heads * h->n_splits * 8 * 66 * 4)) != RCA_OK) return rc;
     h->logits_rows_cap = c.logits_all ? 64 : 1;
     if ((rc = lm_alloc((void**)&h->logits, (size_t)h->logits_rows_cap * c.vocab_size * 4)) != RCA_OK) return rc;
@@ -1388,33 +1317,60 @@ extern "C" int rca_lm_create_shared(rca_lm_t* parent, int32_t n_ctx, int32_t log
 }
 
 // ------------------------------------------------------------------------- forward pass (M tokens)
-template <int M, int PRO, int EPI, int KW, int XR = (M <= 2 ? 1 : 0)>
-static void launch_gemv_t(rca_lm* h, const bf16_t* W, const float* x, float* y, int N, int K, int kslice, int nsl, long yss, int ldy,
-                          const GemvPro& pro, const GemvRope& rope, hipStream_t st) {
-    // rows per workgroup: aim at ~512 workgroups (2 per CU).  KW kernels take 2 rows per iteration.
-    const int gran = 8;
-    const int groups = KW ? 1 : nsl;
-    const int tgt = 512;
-    long want = ((long)N * groups + tgt - 1) / tgt;
-    int rpw = (int)std::min<long>(64, std::max<long>(gran, (want + gran - 1) / gran * gran));
-    dim3 grid(cdiv(N, rpw), groups);
-    const size_t lds = XR ? 0 : (size_t)M * (KW ? K : kslice) * 4;
-    auto kern = lm_gemv_kernel<M, PRO, EPI, KW, XR>;
-    if (lds > 48 * 1024) {
-        static bool done = false;  // one-time opt-in above the default dynamic LDS size
-        if (!done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); done = true; }
+// Launch geometry of the decode GEMVs: R rows per batch (weights of a whole batch are in flight per wave before any is
+// consumed) and batches per workgroup.  Defaults are sized for the 256 CUs (>= 2 workgroups each, all resident at once);
+// RCA_GEMV_<QKV|O|GU|DOWN|HEAD>="R,batches" overrides one for tuning runs (scripts/lm_gemv_sweep.sh).  Results do not
+// depend on the choice.
+struct GemvGeom { int R, bpw; };
+enum { GEMV_QKV = 0, GEMV_O, GEMV_GU, GEMV_DOWN, GEMV_HEAD, GEMV_KINDS };
+static GemvGeom gemv_geom(int kind, int N) {
+    static GemvGeom tab[GEMV_KINDS];
+    static bool init = false;
+    if (!init) {
+        const GemvGeom def[GEMV_KINDS] = {{4, 1}, {4, 1}, {16, 2}, {4, 1}, {16, 8}};
+        const char* names[GEMV_KINDS] = {"RCA_GEMV_QKV", "RCA_GEMV_O", "RCA_GEMV_GU", "RCA_GEMV_DOWN", "RCA_GEMV_HEAD"};
+        for (int k = 0; k < GEMV_KINDS; ++k) {
+            tab[k] = def[k];
+            const char* e = getenv(names[k]);
+            int r = 0, bw = 0;
+            if (e && sscanf(e, "%d,%d", &r, &bw) == 2 && (r == 4 || r == 8 || r == 16) && bw >= 1) tab[k] = {r, bw};
+        }
+        init = true;
     }
-    kern<<<grid, 256, lds, st>>>(h->stt, W, x, y, N, K, kslice, rpw, yss, ldy, pro, rope);
+    GemvGeom g = tab[kind];
+    // small models: never fewer than ~64 workgroups while there are rows to hand out
+    while (g.bpw > 1 && (N + g.R * g.bpw - 1) / (g.R * g.bpw) < 64) g.bpw >>= 1;
+    return g;
 }
-template <int PRO, int EPI>
-static void launch_gemv(rca_lm* h, int M, const bf16_t* W, const float* x, float* y, int N, int K, int kslice, int nsl, long yss, int ldy,
-                        const GemvPro& pro, const GemvRope& rope, hipStream_t st) {
-    switch (M) {
-        case 1: launch_gemv_t<1, PRO, EPI, 0>(h, W, x, y, N, K, kslice, nsl, yss, ldy, pro, rope, st); break;
-        case 2: launch_gemv_t<2, PRO, EPI, 0>(h, W, x, y, N, K, kslice, nsl, yss, ldy, pro, rope, st); break;
-        case 3: case 4: launch_gemv_t<4, PRO, EPI, 0>(h, W, x, y, N, K, kslice, nsl, yss, ldy, pro, rope, st); break;
-        default: launch_gemv_t<8, PRO, EPI, 0>(h, W, x, y, N, K, kslice, nsl, yss, ldy, pro, rope, st); break;
+template <int M, int NIT, int PRO, int EPI>
+static void launch_gemv_r(const GemvGeom& g, rca_lm* h, const bf16_t* W, const float* x, float* y, int N, int K, int ldy, const GemvPro& pro,
+                          const GemvRope& rope, hipStream_t st) {
+    const int grid = cdiv(cdiv(N, g.R), g.bpw);
+    switch (g.R) {
+        case 4: lm_gemv_kernel<M, NIT, 4, PRO, EPI><<<grid, 256, 0, st>>>(h->stt, W, x, y, N, K, g.bpw, ldy, pro, rope); break;
+        case 8: lm_gemv_kernel<M, NIT, 8, PRO, EPI><<<grid, 256, 0, st>>>(h->stt, W, x, y, N, K, g.bpw, ldy, pro, rope); break;
+        default: lm_gemv_kernel<M, NIT, 16, PRO, EPI><<<grid, 256, 0, st>>>(h->stt, W, x, y, N, K, g.bpw, ldy, pro, rope); break;
     }
+}
+// M = 1 or 2 tokens.  Only the down projection (K = ffn) needs more than one chunk per lane and wave.
+template <int PRO, int EPI>
+static void launch_gemv(int kind, rca_lm* h, int M, const bf16_t* W, const float* x, float* y, int N, int K, int ldy, const GemvPro& pro,
+                        const GemvRope& rope, hipStream_t st) {
+    GemvGeom g = gemv_geom(kind, N);
+    const int nit = cdiv(cdiv(K >> 3, 4), 64);
+    while (g.R > 4 && g.R * (nit == 3 ? 4 : nit) > 16) g.R >>= 1;   // weights in flight per lane: at most 16 x 16 bytes (registers)
+    if (PRO == 0 && EPI == 3 && nit > 1) {
+        if (nit == 2) {
+            if (M == 1) launch_gemv_r<1, 2, 0, 3>(g, h, W, x, y, N, K, ldy, pro, rope, st);
+            else launch_gemv_r<2, 2, 0, 3>(g, h, W, x, y, N, K, ldy, pro, rope, st);
+        } else {
+            if (M == 1) launch_gemv_r<1, 4, 0, 3>(g, h, W, x, y, N, K, ldy, pro, rope, st);
+            else launch_gemv_r<2, 4, 0, 3>(g, h, W, x, y, N, K, ldy, pro, rope, st);
+        }
+        return;
+    }
+    if (M == 1) launch_gemv_r<1, 1, PRO, EPI>(g, h, W, x, y, N, K, ldy, pro, rope, st);
+    else launch_gemv_r<2, 1, PRO, EPI>(g, h, W, x, y, N, K, ldy, pro, rope, st);
 }
 
 // ------------------------------------------------------------------ attention on MFMA (decode steps and prefill tiles)
@@ -1677,62 +1633,34 @@ static void launch_attention_mfma(rca_lm* h, int M, int nsp_launch, const f16_t*
 // attention split blocks needed by a pass of m tokens on top of the current context
 static int lm_splits_needed(const rca_lm* h, int m) { return std::min(h->n_splits, (h->n_tokens + m + ATT_KEYS - 1) / ATT_KEYS); }
 
-// Enqueue one pass over the M tokens whose ids / position are already in h->stt (device).
+// Enqueue one decode pass over the M <= 2 tokens whose ids / position are already in h->stt (device).
 // want_logits: 0 none, 1 last token only, 2 every token (logits_all).
-// Per layer: [norm+QKV+RoPE/KV-write] -> [split attention] -> [combine] -> [O proj] -> [norm+gate/up+SwiGLU] -> [down]
+// Per layer: [norm+QKV+RoPE/KV-write] -> [split attention] -> [combine] -> [O proj + residual] -> [norm+gate/up+SwiGLU] -> [down + residual]
 // nsp_launch: attention split blocks to launch (>= ceil((n_tokens + M) / ATT_KEYS); later splits exit at once).
 static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st, int nsp_launch) {
     const rca_lm_config_t& c = h->cfg;
     const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim, F = c.ffn;
-    const int Mt = M <= 2 ? M : (M <= 4 ? 4 : 8);
-    const long ps = (long)LM_MAXM * H;
-    const GemvPro nopro{nullptr, nullptr, nullptr, 0, 0, nullptr, 0.0f, 0};
+    if (M < 1 || M > LM_GEMV_M) return fail(RCA_ERR_ARG, "decode pass of %d tokens", M);
+    const GemvPro nopro{nullptr, nullptr, 0.0f, 0};
     GemvRope rope{h->cos_t, h->sin_t, nullptr, nullptr, c.n_heads, c.n_kv_heads, c.n_ctx};
     const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
-    float* cur = h->x;
-    float* nxt = h->x2;
-    // decode passes (M <= 2) reduce the down projection's K inside the workgroup; needs ffn % 32 == 0 and
-    // [M][ffn] f32 in LDS
-    const bool in_wg_ksplit = Mt <= 2 && h->ksplit_down == 4 && (F % 32) == 0;
-    lm_embed_kernel<<<M, 256, 0, st>>>(h->stt, h->embed, cur, H, c.vocab_size);
+    float* x = h->x;
+    lm_embed_kernel<<<M, 256, 0, st>>>(h->stt, h->embed, x, H, c.vocab_size);
     for (int l = 0; l < c.n_layers; ++l) {
         const LmLayer& L = h->layers[l];
         f16_t* kc = h->kc + (long)l * h->kv_layer_stride;
         f16_t* vc = h->vc + (long)l * h->kv_layer_stride;
         rope.kc = kc; rope.vc = vc;
-        // the previous layer's down-projection partials join the residual stream inside this prologue
-        const int np1 = (l == 0 || in_wg_ksplit) ? 0 : h->ksplit_down;
-        if (Mt > 2) {
-            // prefill chunks: one norm kernel per token instead of a redundant prologue in every GEMV workgroup
-            lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, cur, np1 ? nxt : nullptr, h->part_d, np1, ps, L.attn_norm, h->xn, H, c.rms_eps);
-            launch_gemv<0, 2>(h, Mt, L.wqkv, h->xn, h->qkv, QKV, H, H, 1, 0, QKV, nopro, rope, st);
-        } else {
-            GemvPro p1{cur, np1 ? nxt : nullptr, h->part_d, np1, ps, L.attn_norm, c.rms_eps, 0};
-            launch_gemv<1, 2>(h, Mt, L.wqkv, nullptr, h->qkv, QKV, H, H, 1, 0, QKV, p1, rope, st);
-        }
-        if (np1) std::swap(cur, nxt);
+        launch_gemv<1, 2>(GEMV_QKV, h, M, L.wqkv, nullptr, h->qkv, QKV, H, QKV, GemvPro{x, L.attn_norm, c.rms_eps, 0}, rope, st);
         launch_attention_mfma(h, M, nsp_launch, kc, vc, st);
-        // O projection adds straight into the residual stream (one K slice: each output has a single writer)
-        launch_gemv<0, 3>(h, Mt, L.wo, h->attn, cur, H, AO, AO, 1, 0, H, nopro, norope, st);
-        if (Mt > 2) {
-            lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, cur, nullptr, nullptr, 0, 0, L.ffn_norm, h->xn, H, c.rms_eps);
-            launch_gemv<0, 1>(h, Mt, L.wgu, h->xn, h->hbuf, 2 * F, H, H, 1, 0, F, nopro, norope, st);
-        } else {
-            GemvPro p2{cur, nullptr, nullptr, 0, 0, L.ffn_norm, c.rms_eps, 0};
-            launch_gemv<1, 1>(h, Mt, L.wgu, nullptr, h->hbuf, 2 * F, H, H, 1, 0, F, p2, norope, st);
-        }
-        if (in_wg_ksplit) {
-            // decode: the 4 waves of a workgroup split K and add x + p0 + p1 + p2 + p3 in place
-            if (Mt == 1) launch_gemv_t<1, 0, 3, 1>(h, L.wdown, h->hbuf, cur, H, F, F / 4, 4, 0, H, nopro, norope, st);
-            else launch_gemv_t<2, 0, 3, 1>(h, L.wdown, h->hbuf, cur, H, F, F / 4, 4, 0, H, nopro, norope, st);
-        } else {
-            // prefill chunks: K slices across workgroups; the partials join the residual in the next prologue
-            launch_gemv<0, 0>(h, Mt, L.wdown, h->hbuf, h->part_d, H, F, h->kslice_down, h->ksplit_down, ps, H, nopro, norope, st);
-        }
+        launch_gemv<0, 3>(GEMV_O, h, M, L.wo, h->attn, x, H, AO, H, nopro, norope, st);
+        launch_gemv<1, 1>(GEMV_GU, h, M, L.wgu, nullptr, h->hbuf, 2 * F, H, F, GemvPro{x, L.ffn_norm, c.rms_eps, 0}, norope, st);
+        launch_gemv<0, 3>(GEMV_DOWN, h, M, L.wdown, h->hbuf, x, H, F, H, nopro, norope, st);
     }
     if (want_logits) {
-        GemvPro pf{cur, nullptr, h->part_d, in_wg_ksplit ? 0 : h->ksplit_down, ps, h->final_norm, c.rms_eps, want_logits == 1 ? 1 : 0};
-        launch_gemv<1, 0>(h, want_logits == 1 ? 1 : Mt, h->head, nullptr, h->logits, c.vocab_size, H, H, 1, 0, c.vocab_size, pf, norope, st);
+        const int only_last = want_logits == 1 ? 1 : 0;
+        launch_gemv<1, 0>(GEMV_HEAD, h, only_last ? 1 : M, h->head, nullptr, h->logits, c.vocab_size, H, c.vocab_size,
+                          GemvPro{x, h->final_norm, c.rms_eps, only_last}, norope, st);
     }
     RCA_LAUNCH_CHECK();
     return RCA_OK;
@@ -2056,6 +1984,15 @@ static int lm_enqueue_prefill_tile128(rca_lm* h, int M, hipStream_t st, int nsp_
     return RCA_OK;
 }
 
+// an rca_lm_eval_async pass may still own the pinned staging block and the activations: wait for it before anything else runs
+static int lm_settle(rca_lm* h) {
+    if (h->async_pending) {
+        RCA_HIP(hipSetDevice(h->device));
+        RCA_HIP(hipStreamSynchronize(h->stream));
+        h->async_pending = false;
+    }
+    return RCA_OK;
+}
 static int lm_push_state(rca_lm* h, const int32_t* ids, int m, hipStream_t st) {
     h->h_stt->n_tokens = h->n_tokens;
     h->h_stt->m = m;
@@ -2086,10 +2023,14 @@ extern "C" int rca_lm_sync(rca_lm_t* h) {
     if (!h) return fail(RCA_ERR_ARG, "null");
     RCA_HIP(hipSetDevice(h->device));
     RCA_HIP(hipStreamSynchronize(h->stream));
+    h->async_pending = false;
     return RCA_OK;
 }
 
-extern "C" int rca_lm_eval(rca_lm_t* h, const int32_t* ids, int32_t n) {
+// as_prefill: use the prefill tiles even for n <= LM_PREFILL_MIN (pieces of one long eval).
+// wait_last = false: return as soon as the LAST pass / tile is enqueued (everything before it has completed, because the
+// pinned staging block is reused per pass); the next call on the handle waits for it first.
+static int lm_eval_impl(rca_lm_t* h, const int32_t* ids, int32_t n, bool wait_last, bool as_prefill) {
     if (!h || (!ids && n > 0) || n < 0) return fail(RCA_ERR_ARG, "eval: bad argument");
     if (n == 0) return RCA_OK;
     if (h->n_tokens + n > h->cfg.n_ctx) return fail(RCA_ERR_STATE, "context overflow: %d + %d > n_ctx %d", h->n_tokens, n, h->cfg.n_ctx);
@@ -2098,6 +2039,7 @@ extern "C" int rca_lm_eval(rca_lm_t* h, const int32_t* ids, int32_t n) {
     RCA_HIP(hipSetDevice(h->device));
     hipStream_t st = h->stream;
     int rc;
+    if (h->async_pending) { RCA_HIP(hipStreamSynchronize(st)); h->async_pending = false; }
     const bool all = h->cfg.logits_all != 0;
     if (all && n > h->logits_rows_cap) {
         RCA_HIP(hipStreamSynchronize(st));
@@ -2108,7 +2050,7 @@ extern "C" int rca_lm_eval(rca_lm_t* h, const int32_t* ids, int32_t n) {
         if ((rc = lm_alloc((void**)&h->logits, (size_t)n * h->cfg.vocab_size * 4)) != RCA_OK) return rc;
     }
     float* logits_base = h->logits;
-    if (!all && n > LM_GEMV_M && h->mfma_prefill && lm_can_mfma_prefill(h)) {
+    if (!all && (n > LM_PREFILL_MIN || as_prefill) && h->mfma_prefill && lm_can_mfma_prefill(h)) {
         // long evals (session prefill, recompute_kv_cache): 32-token tiles on the bf16 MFMA path
         const bool big = lm_can_gemm128(h);
         const int tile = big ? LM_MAXM : LM_TILE32;
@@ -2121,8 +2063,8 @@ extern "C" int rca_lm_eval(rca_lm_t* h, const int32_t* ids, int32_t n) {
             if (last) {   // logits of the final token: final norm + head on the register GEMV path
                 const rca_lm_config_t& c = h->cfg;
                 const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
-                GemvPro pf{h->x, nullptr, nullptr, 0, 0, h->final_norm, c.rms_eps, 1};
-                launch_gemv<1, 0>(h, 1, h->head, nullptr, h->logits, c.vocab_size, c.hidden, c.hidden, 1, 0, c.vocab_size, pf, norope, st);
+                launch_gemv<1, 0>(GEMV_HEAD, h, 1, h->head, nullptr, h->logits, c.vocab_size, c.hidden, c.vocab_size,
+                                  GemvPro{h->x, h->final_norm, c.rms_eps, 1}, norope, st);
                 RCA_LAUNCH_CHECK();
             }
             h->n_tokens += m;
@@ -2143,7 +2085,58 @@ extern "C" int rca_lm_eval(rca_lm_t* h, const int32_t* ids, int32_t n) {
         }
     }
     h->logits_rows = all ? n : 1;
-    RCA_HIP(hipStreamSynchronize(st));
+    if (wait_last) RCA_HIP(hipStreamSynchronize(st));
+    else h->async_pending = true;
+    return RCA_OK;
+}
+extern "C" int rca_lm_eval(rca_lm_t* h, const int32_t* ids, int32_t n) { return lm_eval_impl(h, ids, n, true, false); }
+// Asynchronous, and with the arithmetic of a LONG eval whatever n is: a cache built piecewise with this call holds the same bits
+// as one rca_lm_eval of the whole sequence (short evals otherwise run as decode passes, which round differently from the tiles).
+extern "C" int rca_lm_eval_async(rca_lm_t* h, const int32_t* ids, int32_t n) { return lm_eval_impl(h, ids, n, false, true); }
+
+// ---- KV-cache plumbing between a handle and its weight-sharing twin (the shadow cache of the sliding-window trim)
+static int lm_same_cache_shape(const rca_lm* a, const rca_lm* b) {
+    return a->device == b->device && a->cfg.n_layers == b->cfg.n_layers && a->cfg.n_kv_heads == b->cfg.n_kv_heads &&
+           a->cfg.head_dim == b->cfg.head_dim && a->n_ctx_pad == b->n_ctx_pad && a->cfg.n_ctx == b->cfg.n_ctx;
+}
+extern "C" int rca_lm_copy_kv(rca_lm_t* dst, rca_lm_t* src, int32_t n_pos) {
+    if (!dst || !src || dst == src) return fail(RCA_ERR_ARG, "copy_kv: two different handles needed");
+    if (!lm_same_cache_shape(dst, src)) return fail(RCA_ERR_ARG, "copy_kv: the two KV caches differ in shape");
+    if (n_pos < 0 || n_pos > src->cfg.n_ctx) return fail(RCA_ERR_ARG, "copy_kv: %d positions outside [0, %d]", n_pos, src->cfg.n_ctx);
+    RCA_HIP(hipSetDevice(dst->device));
+    RCA_HIP(hipStreamSynchronize(src->stream));   // everything src has evaluated so far is in its cache
+    src->async_pending = false;
+    if (dst->async_pending) { RCA_HIP(hipStreamSynchronize(dst->stream)); dst->async_pending = false; }
+    const size_t bytes = (size_t)n_pos * src->cfg.n_kv_heads * src->cfg.head_dim * sizeof(f16_t);
+    for (int l = 0; l < src->cfg.n_layers && bytes; ++l) {
+        RCA_HIP(hipMemcpyAsync(dst->kc + (long)l * dst->kv_layer_stride, src->kc + (long)l * src->kv_layer_stride, bytes, hipMemcpyDeviceToDevice, dst->stream));
+        RCA_HIP(hipMemcpyAsync(dst->vc + (long)l * dst->kv_layer_stride, src->vc + (long)l * src->kv_layer_stride, bytes, hipMemcpyDeviceToDevice, dst->stream));
+    }
+    dst->async_pending = true;
+    return RCA_OK;
+}
+extern "C" int rca_lm_swap_kv(rca_lm_t* a, rca_lm_t* b) {
+    if (!a || !b || a == b) return fail(RCA_ERR_ARG, "swap_kv: two different handles needed");
+    if (!lm_same_cache_shape(a, b)) return fail(RCA_ERR_ARG, "swap_kv: the two KV caches differ in shape");
+    RCA_HIP(hipSetDevice(a->device));
+    RCA_HIP(hipStreamSynchronize(a->stream));
+    RCA_HIP(hipStreamSynchronize(b->stream));
+    a->async_pending = b->async_pending = false;
+    std::swap(a->kc, b->kc);
+    std::swap(a->vc, b->vc);
+    return RCA_OK;
+}
+extern "C" int rca_lm_set_low_priority(rca_lm_t* h, int32_t enable) {
+    if (!h) return fail(RCA_ERR_ARG, "null");
+    RCA_HIP(hipSetDevice(h->device));
+    int lo = 0, hi = 0;
+    RCA_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));   // numerically lower = higher priority
+    hipStream_t ns = nullptr;
+    RCA_HIP(hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, enable ? lo : hi));
+    RCA_HIP(hipStreamSynchronize(h->stream));
+    h->async_pending = false;
+    (void)hipStreamDestroy(h->stream);
+    h->stream = ns;
     return RCA_OK;
 }
 
@@ -2155,6 +2148,7 @@ extern "C" int rca_lm_logits_dev(rca_lm_t* h, const float** out) {
 }
 extern "C" int rca_lm_get_logits(rca_lm_t* h, float* out_host) {
     if (!h || !out_host) return fail(RCA_ERR_ARG, "null");
+    { const int src = lm_settle(h); if (src != RCA_OK) return src; }
     const float* src;
     int rc;
     if ((rc = rca_lm_logits_dev(h, &src)) != RCA_OK) return rc;
@@ -2165,6 +2159,7 @@ extern "C" int rca_lm_get_logits(rca_lm_t* h, float* out_host) {
 }
 extern "C" int rca_lm_get_logits_row(rca_lm_t* h, int32_t row, float* out_host) {
     if (!h || !out_host) return fail(RCA_ERR_ARG, "null");
+    { const int src = lm_settle(h); if (src != RCA_OK) return src; }
     if (row < 0 || row >= h->logits_rows) return fail(RCA_ERR_ARG, "row %d outside the %d rows of the last eval", row, h->logits_rows);
     RCA_HIP(hipSetDevice(h->device));
     RCA_HIP(hipMemcpyAsync(out_host, h->logits + (long)row * h->cfg.vocab_size, (size_t)h->cfg.vocab_size * 4, hipMemcpyDeviceToHost, h->stream));
@@ -2209,6 +2204,7 @@ static int lm_fetch_token(rca_lm* h, int32_t* token, hipStream_t st) {
 
 extern "C" int rca_lm_sample(rca_lm_t* h, int32_t* token) {
     if (!h || !token) return fail(RCA_ERR_ARG, "null");
+    { const int src = lm_settle(h); if (src != RCA_OK) return src; }
     if (!h->sampler_set) return fail(RCA_ERR_STATE, "sampler not initialised");
     if (h->logits_rows < 1) return fail(RCA_ERR_STATE, "no logits: call eval first");
     RCA_HIP(hipSetDevice(h->device));
@@ -2222,6 +2218,7 @@ extern "C" int rca_lm_sample(rca_lm_t* h, int32_t* token) {
 // logits_all) handle the whole step is one hipGraph replay.
 extern "C" int rca_lm_step(rca_lm_t* h, const int32_t* ids, int32_t n, int32_t* token) {
     if (!h || !ids || !token || n < 1) return fail(RCA_ERR_ARG, "step: bad argument");
+    { const int src = lm_settle(h); if (src != RCA_OK) return src; }
     if (!h->sampler_set) return fail(RCA_ERR_STATE, "sampler not initialised");
     if (h->n_tokens + n > h->cfg.n_ctx) return fail(RCA_ERR_STATE, "context overflow: %d + %d > n_ctx %d", h->n_tokens, n, h->cfg.n_ctx);
     for (int i = 0; i < n; ++i)
@@ -2241,7 +2238,8 @@ extern "C" int rca_lm_step(rca_lm_t* h, const int32_t* ids, int32_t n, int32_t* 
     const int need = lm_splits_needed(h, n);
     while (bucket + 1 < LM_GRAPH_BUCKETS && (4 << bucket) < need) ++bucket;
     const int nsp_launch = bucket + 1 == LM_GRAPH_BUCKETS ? h->n_splits : std::min(h->n_splits, 4 << bucket);
-    if (!h->graph[n][bucket]) {
+    hipGraphExec_t& gexec = lm_graph_set(h).g[n][bucket];
+    if (!gexec) {
         hipGraph_t g = nullptr;
         RCA_HIP(hipStreamSynchronize(st));
         RCA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -2255,11 +2253,11 @@ extern "C" int rca_lm_step(rca_lm_t* h, const int32_t* ids, int32_t n, int32_t* 
         hipError_t e2 = hipStreamEndCapture(st, &g);
         if (rc != RCA_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
         if (e2 != hipSuccess) return fail(RCA_ERR_HIP, "end capture: %s", hipGetErrorString(e2));
-        e2 = hipGraphInstantiate(&h->graph[n][bucket], g, nullptr, nullptr, 0);
+        e2 = hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
-        if (e2 != hipSuccess) { h->graph[n][bucket] = nullptr; return fail(RCA_ERR_HIP, "graph instantiate: %s", hipGetErrorString(e2)); }
+        if (e2 != hipSuccess) { gexec = nullptr; return fail(RCA_ERR_HIP, "graph instantiate: %s", hipGetErrorString(e2)); }
     }
-    RCA_HIP(hipGraphLaunch(h->graph[n][bucket], st));
+    RCA_HIP(hipGraphLaunch(gexec, st));
     RCA_HIP(hipStreamSynchronize(st));
     h->n_tokens += n;
     h->logits_rows = 1;
@@ -2269,6 +2267,7 @@ extern "C" int rca_lm_step(rca_lm_t* h, const int32_t* ids, int32_t n, int32_t* 
 
 extern "C" int rca_lm_token_probs(rca_lm_t* h, const int32_t* token_ids, int32_t n, float* probs_out) {
     if (!h || !token_ids || !probs_out || n < 1 || n > 64) return fail(RCA_ERR_ARG, "token_probs: 1..64 ids");
+    { const int src = lm_settle(h); if (src != RCA_OK) return src; }
     if (h->logits_rows < 1) return fail(RCA_ERR_STATE, "no logits: call eval first");
     RCA_HIP(hipSetDevice(h->device));
     hipStream_t st = h->stream;

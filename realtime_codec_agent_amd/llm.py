@@ -253,6 +253,7 @@ class LlamaForAlternatingCodeChannels:
         self._sampler = None
         self._seed = seed
         self._sampler_params = None
+        self._mfma_prefill = True
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -445,6 +446,41 @@ class LlamaForAlternatingCodeChannels:
     def sync(self) -> None:
         N.check(self._lib.rca_lm_sync(self._h), "rca_lm_sync")
 
+    # ------------------------------------------------------------------ shadow KV cache (sliding-window trim without a prefill spike)
+    def make_kv_shadow(self, low_priority: bool = True) -> "LlamaForAlternatingCodeChannels":
+        """A twin over the same device weights with its own KV cache, workspace and (low-priority) stream: the place where the
+        post-trim cache is built while this handle keeps stepping (kv_shadow.py; reference behaviour it replaces:
+        recompute_kv_cache inside the trimming frame, realtime_agent_v2.py:187-190,725-733)."""
+        twin = LlamaForAlternatingCodeChannels(model_path=self.model_path, n_ctx=self._n_ctx, share_weights_with=self, device=self._device)
+        if low_priority:
+            N.check(self._lib.rca_lm_set_low_priority(twin._h, 1), "rca_lm_set_low_priority")
+        return twin
+
+    def eval_async(self, tokens: Sequence[int]) -> None:
+        """eval() that returns once its last tile / pass is enqueued; the next call on this handle waits for it."""
+        tokens = list(tokens)
+        if not tokens:
+            return
+        n0 = self.n_tokens
+        arr = (C.c_int32 * len(tokens))(*tokens)
+        N.check(self._lib.rca_lm_eval_async(self._h, arr, len(tokens)), "rca_lm_eval_async")
+        self._input_ids[n0:n0 + len(tokens)] = tokens
+        self._logits_valid = False
+
+    def copy_kv_from(self, other: "LlamaForAlternatingCodeChannels", n_positions: int) -> None:
+        """KV entries [0, n_positions) of every layer, device to device, from `other`'s cache into this one's."""
+        N.check(self._lib.rca_lm_copy_kv(self._h, other._h, int(n_positions)), "rca_lm_copy_kv")
+        self._input_ids[:n_positions] = other._input_ids[:n_positions]
+
+    def swap_kv(self, other: "LlamaForAlternatingCodeChannels") -> None:
+        """Exchange the KV caches of the two handles (O(1); n_tokens stays with each handle and is set by the caller)."""
+        N.check(self._lib.rca_lm_swap_kv(self._h, other._h), "rca_lm_swap_kv")
+        n = max(self._n_ctx, other._n_ctx)
+        tmp = self._input_ids[:n].copy()
+        self._input_ids[:n] = other._input_ids[:n]
+        other._input_ids[:n] = tmp
+        self._logits_valid = other._logits_valid = False
+
     def mask_head_rows(self, row_begin: int, row_end: int) -> None:
         """Zero lm_head rows (random-init models: keep sampling on codec tokens like a trained model in audio mode)."""
         N.check(self._lib.rca_lm_mask_head_rows(self._h, int(row_begin), int(row_end)), "rca_lm_mask_head_rows")
@@ -478,8 +514,9 @@ class LlamaForAlternatingCodeChannels:
         return out
 
     def set_mfma_prefill(self, enable: bool) -> None:
-        """Long evals on bf16 MFMA tiles (default) or on the exact 8-token GEMV chunks."""
+        """Long evals on bf16 MFMA tiles (default) or on the exact path (the decode GEMV kernels, two tokens per pass)."""
         N.check(self._lib.rca_lm_set_mfma_prefill(self._h, 1 if enable else 0), "rca_lm_set_mfma_prefill")
+        self._mfma_prefill = bool(enable)
 
     def set_graphs(self, enable: bool) -> None:
         N.check(self._lib.rca_lm_set_graphs(self._h, 1 if enable else 0), "rca_lm_set_graphs")

@@ -147,3 +147,31 @@ def test_agent_over_hip_objects_equals_agent_over_oracle_objects(chunk, exact_pr
     print(f"last-step logits HIP vs oracle after {len(a_hip.input_ids)} tokens: max|d| = {d:.2e}")
     assert d < (2e-4 if exact_prefill else 6e-4)
     assert len(set(a_hip.input_ids[a_hip.context_start_pos + 8::2])) > 10           # the agent channel is not stuck on one code
+
+
+@pytest.mark.parametrize("mfma_prefill", [True, False])
+def test_trim_through_shadow_cache_equals_reference_recompute(mfma_prefill):
+    """a16 / SURVEY 8f-1: the same sampled session (seeded top-k sampling, several sliding-window trims) with the post-trim cache
+    built ahead of time on the twin LM and swapped in, and with the reference's in-frame recompute (realtime_agent_v2.py:187-190,
+    725-733).  Token streams, emitted audio and the final logits must be identical; the shadow run must really have swapped."""
+    runs = []
+    for shadow in (True, False):
+        agent, res = make_agent(chunk=0.08, max_context_secs=1.2, trim_by_secs=0.4)
+        res.llm.set_mfma_prefill(mfma_prefill)
+        agent.use_kv_shadow = shadow
+        agent.kv_shadow_tile = 16
+        agent.reset()
+        sig = rich_signal(1280 * 60, 33)
+        outs = [agent.process_audio(sig[s:s + 1280]) for s in range(0, len(sig), 1280)]
+        res.llm.eval(agent.input_ids[-2:])
+        runs.append((list(agent.input_ids), np.concatenate(outs), res.llm._scores[-1].copy(), agent.trim_to_secs))
+        if shadow:
+            st = agent._kv_shadow.stats
+            print("shadow stats:", st)
+            assert st["swaps"] >= 5 and st["tiles"] >= 5 and st["fallbacks"] == 0
+        else:
+            assert agent._kv_shadow is None
+    assert runs[0][3] == runs[1][3] >= 2.0
+    assert runs[0][0] == runs[1][0]
+    assert np.array_equal(runs[0][1], runs[1][1])
+    assert np.array_equal(runs[0][2], runs[1][2])

@@ -212,6 +212,53 @@ def test_sampler_and_token_ids_are_validated():
     assert llm.n_tokens == 4
 
 
+@pytest.mark.parametrize("mfma_prefill", [False, True])
+def test_shadow_cache_swap_equals_fresh_recompute(mfma_prefill):
+    """The sliding-window trim through a shadow cache (rca_lm_copy_kv / _eval_async / _swap_kv; kv_shadow.py) leaves the live handle in
+    exactly the state of the reference's recompute (realtime_agent_v2.py:725-733: n_tokens = header, eval(surviving suffix)):
+    next-step logits bit for bit equal, whatever way the suffix was cut into asynchronous evals, also after a rollback of the twin,
+    and graph steps keep working on both caches."""
+    llm, w, ids = make_llm("llama3")
+    llm.set_mfma_prefill(mfma_prefill)
+    ids = ids.tolist()
+    hdr, suffix, nxt = ids[:7], ids[12:27], ids[27:29]
+    llm.eval(ids[:27])                                      # the session so far: header + 20 tokens of dialogue
+    twin = llm.make_kv_shadow()
+    twin.set_mfma_prefill(mfma_prefill)
+    twin.copy_kv_from(llm, len(hdr))
+    twin.n_tokens = len(hdr)
+    twin.eval_async(suffix[:9])                             # fed ahead of time, in two pieces ...
+    llm.init_sampler_for_generate(top_k=20, top_p=1.0, min_p=0.0, temp=1.0, seed=5)
+    t_live = llm.step(ids[27:29])                           # ... while the live handle keeps stepping on its own cache
+    twin.eval_async(suffix[9:13])
+    twin.eval_async([3, 4])                                 # two tokens that turn out wrong (the sequence was edited):
+    twin.n_tokens = len(hdr) + 13                           # ... rolled back
+    twin.eval_async(suffix[13:])                            # (pieces of a long eval keep the prefill arithmetic whatever their size)
+    llm.swap_kv(twin)
+    llm.n_tokens = len(hdr) + len(suffix)
+    llm.eval(nxt)
+    got = llm._scores[-1].copy()
+    # the reference way on a fresh handle
+    ref, _, _ = make_llm("llama3")
+    ref.set_mfma_prefill(mfma_prefill)
+    ref.eval(ids[:27])
+    ref.n_tokens = len(hdr)
+    ref.eval(suffix)
+    ref.eval(nxt)
+    assert np.array_equal(got, ref._scores[-1])
+    # graph steps on the swapped-in cache, then swap back: the set captured over the first cache is still valid
+    llm.init_sampler_for_generate(top_k=20, top_p=1.0, min_p=0.0, temp=1.0, seed=5)
+    ref.init_sampler_for_generate(top_k=20, top_p=1.0, min_p=0.0, temp=1.0, seed=5)
+    llm.n_tokens = ref.n_tokens = len(hdr) + len(suffix)
+    assert llm.step(nxt) == ref.step(nxt)
+    llm.swap_kv(twin)                                       # back on the original cache (27 tokens + the live step above)
+    llm.n_tokens = 27
+    llm.init_sampler_for_generate(top_k=20, top_p=1.0, min_p=0.0, temp=1.0, seed=5)
+    assert llm.step(ids[27:29]) == t_live
+    with pytest.raises(Exception):
+        llm.swap_kv(make_llm("llama3", n_ctx=256)[0])       # different cache shape
+
+
 def test_context_overflow_and_bad_args():
     from realtime_codec_agent_amd._native import RcaError
     llm, w, ids = make_llm("default", n_ctx=16)
