@@ -275,6 +275,14 @@ int rca_lm_sample(rca_lm_t* h, int32_t* token);
 /* next(generate(tokens, reset=False)) (llamacpp_utils.py:145-161; realtime_agent_v2.py:355):
  * eval + sample with no host round trip in between; hipGraph-replayed for n<=2 */
 int rca_lm_step(rca_lm_t* h, const int32_t* ids, int32_t n, int32_t* token);
+/* One whole frame of process_audio_input_ids (realtime_agent_v2.py:332-372) as ONE hipGraph: n_steps (<= 8) S=2 steps, the
+ * agent token sampled by step i fed back on the device together with user_ids[i] as step i+1's input pair; first_pair is the
+ * pair step 0 evaluates (the last two ids of the sequence).  out_tokens[i] = token sampled by step i.  *n_done = number of steps
+ * whose result stands: n_steps, or j + 1 when step j sampled a token <= audio_id_floor (the loop leaves audio mode there,
+ * realtime_agent_v2.py:361-371); the KV position and the sampler's draw counter are then exactly what j + 1 single steps would
+ * have left, and the caller continues step by step.  The last logits are those of the last step that ran. */
+int rca_lm_frame(rca_lm_t* h, const int32_t* first_pair, const int32_t* user_ids, int32_t n_steps, int32_t audio_id_floor,
+                 int32_t* out_tokens, int32_t* n_done);
 /* softmax(logits)[token] of the last position, reduced on the device
  * (measure_event_prob, realtime_agent_v2.py:448-452) */
 int rca_lm_token_probs(rca_lm_t* h, const int32_t* token_ids, int32_t n, float* probs_out);

@@ -37,6 +37,8 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #define ATT_KEYS 256       // keys per attention workgroup (8 waves x 32 keys)
 #define LM_GRAPH_BUCKETS 8  // 4, 8, ..., 256 splits, the last bucket = all of them
 #define SAMP_MAXK 256
+#define LM_FRAME_MAX 8        // steps of one frame graph (a chunk is 4-5 frames per channel, realtime_agent_config.py:21,56)
+#define LM_FRAME_USER0 8     // LmDevState::ids[LM_FRAME_USER0 + i] = the user's token of frame i (ids[0..1] is the pair being evaluated)
 
 struct LmDevState {
     int n_tokens;      // KV position of the first token of the current pass
@@ -45,6 +47,7 @@ struct LmDevState {
     unsigned long long rng_counter;
     int out_token;
     int pad;
+    int frame_out[LM_FRAME_MAX];   // rca_lm_frame: the token sampled by each step of the frame
 };
 
 struct SamplerDev {
@@ -597,6 +600,15 @@ __global__ __launch_bounds__(256) void lm_gemm_mfma_kernel(const LmDevState* __r
 
 // advance the device-side KV position after a pass
 __global__ void lm_advance_kernel(LmDevState* stt) { stt->n_tokens += stt->m; }
+// between two steps of a frame graph: the pair just evaluated is in the cache, the next pair is [agent token just sampled,
+// user's token of this frame] (realtime_agent_v2.py:355-363)
+__global__ void lm_frame_next_kernel(LmDevState* stt, int i) {
+    const int tok = stt->out_token;
+    stt->frame_out[i] = tok;
+    stt->n_tokens += 2;
+    stt->ids[0] = tok;
+    stt->ids[1] = stt->ids[LM_FRAME_USER0 + i];
+}
 // steady-state step: next pass's first id is the token just sampled (realtime_agent_v2.py:355-363)
 __global__ void lm_copy_logits_row_kernel(const float* __restrict__ src, float* __restrict__ dst, int V) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) dst[i] = src[i];
@@ -974,10 +986,12 @@ struct rca_lm {
     // decode-step graphs per (tokens 1..2, context bucket): bucket b launches min(n_splits, 4 << b) attention splits
     // Two sets: the handle's KV cache can be exchanged with a twin's (rca_lm_swap_kv) and the cache address is baked into the
     // captured kernel nodes, so a set remembers the cache it was captured over (at most two caches ever rotate through a handle).
-    struct GraphSet { const f16_t* kc = nullptr; hipGraphExec_t g[3][LM_GRAPH_BUCKETS] = {}; unsigned long long last_use = 0; };
+    struct GraphSet { const f16_t* kc = nullptr; hipGraphExec_t g[3][LM_GRAPH_BUCKETS] = {}; hipGraphExec_t fg[LM_FRAME_MAX + 1][LM_GRAPH_BUCKETS] = {};
+                      unsigned long long last_use = 0; };
     GraphSet gset[2];
     unsigned long long gset_clock = 0;
     bool async_pending = false;   // an rca_lm_eval_async pass may still be running on the stream
+    unsigned long long rng_host = 0;   // host mirror of the device's draw counter (restored when a frame graph is cut short)
     bool graphs_enabled = true;
     bool mfma_prefill = true;   // evals longer than LM_GEMV_M tokens use the bf16 MFMA tiles
     // weight sharing (rca_lm_create_shared): a borrower points at the handle that owns the weights and the RoPE tables; an owner
@@ -1010,6 +1024,9 @@ static void lm_drop_graph_set(rca_lm::GraphSet& gs) {
     for (int i = 0; i < 3; ++i)
         for (int b = 0; b < LM_GRAPH_BUCKETS; ++b)
             if (gs.g[i][b]) { (void)hipGraphExecDestroy(gs.g[i][b]); gs.g[i][b] = nullptr; }
+    for (int i = 0; i <= LM_FRAME_MAX; ++i)
+        for (int b = 0; b < LM_GRAPH_BUCKETS; ++b)
+            if (gs.fg[i][b]) { (void)hipGraphExecDestroy(gs.fg[i][b]); gs.fg[i][b] = nullptr; }
     gs.kc = nullptr;
 }
 static void lm_drop_graphs(rca_lm* h) {
@@ -2184,6 +2201,7 @@ extern "C" int rca_lm_sampler_init(rca_lm_t* h, const rca_sampler_params_t* p) {
     // set_seed restarts the stream of draws (llamacpp_utils.py:58)
     const unsigned long long zero = 0;
     RCA_HIP(hipMemcpy(&h->stt->rng_counter, &zero, 8, hipMemcpyHostToDevice));
+    h->rng_host = 0;
     h->sampler_set = true;
     return RCA_OK;
 }
@@ -2211,6 +2229,7 @@ extern "C" int rca_lm_sample(rca_lm_t* h, int32_t* token) {
     const float* lg = h->logits + (long)(h->logits_rows - 1) * h->cfg.vocab_size;
     lm_enqueue_sample(h, lg, h->stream);
     RCA_LAUNCH_CHECK();
+    h->rng_host += 1;
     return lm_fetch_token(h, token, h->stream);
 }
 
@@ -2261,7 +2280,85 @@ extern "C" int rca_lm_step(rca_lm_t* h, const int32_t* ids, int32_t n, int32_t* 
     RCA_HIP(hipStreamSynchronize(st));
     h->n_tokens += n;
     h->logits_rows = 1;
+    h->rng_host += 1;
     *token = h->h_stt->out_token;
+    return RCA_OK;
+}
+
+// One frame of the duplex loop as ONE graph (process_audio_input_ids, realtime_agent_v2.py:332-372, while every sampled token is an
+// audio token): step i evaluates [agent_{i-1}, user_{i-1}] -- for i = 0 the pair the caller passes -- and samples agent_i, which
+// goes back into step i + 1 on the device together with the user's token of frame i.  One host synchronisation per frame instead
+// of one per step.  If step j samples a token <= audio_id_floor (the loop leaves audio mode there), steps after j have run on a
+// wrong guess: n_done = j + 1, the KV position and the draw counter are put back to what the step-by-step loop would have (their
+// cache slots are stale and get overwritten, exactly like a rollback), and the caller carries on step by step.
+extern "C" int rca_lm_frame(rca_lm_t* h, const int32_t* first_pair, const int32_t* user_ids, int32_t n_steps, int32_t audio_id_floor,
+                            int32_t* out_tokens, int32_t* n_done) {
+    if (!h || !first_pair || !user_ids || !out_tokens || !n_done) return fail(RCA_ERR_ARG, "frame: null argument");
+    if (n_steps < 1 || n_steps > LM_FRAME_MAX) return fail(RCA_ERR_ARG, "frame: %d steps (1..%d)", n_steps, LM_FRAME_MAX);
+    if (!h->sampler_set) return fail(RCA_ERR_STATE, "sampler not initialised");
+    if (h->cfg.logits_all) return fail(RCA_ERR_STATE, "frame: not on a logits_all handle");
+    if (h->n_tokens + 2 * n_steps > h->cfg.n_ctx) return fail(RCA_ERR_STATE, "context overflow: %d + %d > n_ctx %d", h->n_tokens, 2 * n_steps, h->cfg.n_ctx);
+    for (int i = 0; i < 2; ++i)
+        if (first_pair[i] < 0 || first_pair[i] >= h->cfg.vocab_size) return fail(RCA_ERR_ARG, "frame: token id %d outside the vocabulary", first_pair[i]);
+    for (int i = 0; i < n_steps; ++i)
+        if (user_ids[i] < 0 || user_ids[i] >= h->cfg.vocab_size) return fail(RCA_ERR_ARG, "frame: token id %d outside the vocabulary", user_ids[i]);
+    { const int src = lm_settle(h); if (src != RCA_OK) return src; }
+    RCA_HIP(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    int rc = RCA_OK;
+    h->h_stt->n_tokens = h->n_tokens;
+    h->h_stt->m = 2;
+    h->h_stt->ids[0] = first_pair[0];
+    h->h_stt->ids[1] = first_pair[1];
+    for (int i = 0; i < n_steps; ++i) h->h_stt->ids[LM_FRAME_USER0 + i] = user_ids[i];
+    int bucket = 0;
+    const int need = lm_splits_needed(h, 2 * n_steps);
+    while (bucket + 1 < LM_GRAPH_BUCKETS && (4 << bucket) < need) ++bucket;
+    const int nsp_launch = bucket + 1 == LM_GRAPH_BUCKETS ? h->n_splits : std::min(h->n_splits, 4 << bucket);
+    hipGraphExec_t& gexec = lm_graph_set(h).fg[n_steps][bucket];
+    if (!gexec || !h->graphs_enabled) {
+        // graphs disabled (tests): the same launches, eagerly
+        const bool capture = h->graphs_enabled;
+        hipGraph_t g = nullptr;
+        RCA_HIP(hipStreamSynchronize(st));
+        if (capture) RCA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        hipError_t e = hipMemcpyAsync(h->stt, h->h_stt, 8 + 4 * LM_MAXM, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) rc = fail(RCA_ERR_HIP, "frame memcpy: %s", hipGetErrorString(e));
+        for (int i = 0; i < n_steps && rc == RCA_OK; ++i) {
+            rc = lm_enqueue_pass(h, 2, 1, st, nsp_launch);
+            if (rc != RCA_OK) break;
+            lm_enqueue_sample(h, h->logits, st);
+            lm_frame_next_kernel<<<1, 1, 0, st>>>(h->stt, i);
+        }
+        if (rc == RCA_OK) {
+            e = hipMemcpyAsync(h->h_stt->frame_out, h->stt->frame_out, sizeof(int) * LM_FRAME_MAX, hipMemcpyDeviceToHost, st);
+            if (e != hipSuccess) rc = fail(RCA_ERR_HIP, "frame d2h: %s", hipGetErrorString(e));
+        }
+        if (capture) {
+            hipError_t e2 = hipStreamEndCapture(st, &g);
+            if (rc != RCA_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+            if (e2 != hipSuccess) return fail(RCA_ERR_HIP, "end capture: %s", hipGetErrorString(e2));
+            e2 = hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e2 != hipSuccess) { gexec = nullptr; return fail(RCA_ERR_HIP, "graph instantiate: %s", hipGetErrorString(e2)); }
+        } else if (rc != RCA_OK) {
+            return rc;
+        }
+    }
+    if (h->graphs_enabled) RCA_HIP(hipGraphLaunch(gexec, st));
+    RCA_HIP(hipStreamSynchronize(st));
+    int done = n_steps;
+    for (int i = 0; i < n_steps; ++i) {
+        out_tokens[i] = h->h_stt->frame_out[i];
+        if (out_tokens[i] <= audio_id_floor) { done = i + 1; break; }
+    }
+    *n_done = done;
+    h->n_tokens += 2 * done;
+    h->logits_rows = 1;
+    h->rng_host += (unsigned long long)done;
+    if (done < n_steps) {   // the device drew n_steps times: put its counter where the step-by-step loop would be
+        RCA_HIP(hipMemcpy(&h->stt->rng_counter, &h->rng_host, 8, hipMemcpyHostToDevice));
+    }
     return RCA_OK;
 }
 

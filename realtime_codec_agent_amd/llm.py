@@ -410,6 +410,26 @@ class LlamaForAlternatingCodeChannels:
         self._logits_valid = False
         return tok.value
 
+    def frame(self, first_pair: Sequence[int], user_ids: Sequence[int], audio_id_floor: int) -> List[int]:
+        """One chunk of process_audio_input_ids (realtime_agent_v2.py:332-372) as ONE graph replay: len(user_ids) S=2 steps with
+        the sampled agent token fed back on the device.  Returns the sampled tokens; the list is shorter than user_ids when a
+        step sampled a token <= audio_id_floor (it is the last element): n_tokens and the sampler state are then what the same
+        number of single steps would have left, and the caller continues step by step."""
+        first_pair, user_ids = [int(t) for t in first_pair], [int(t) for t in user_ids]
+        if len(first_pair) != 2:
+            raise ValueError("frame() starts from the last [agent, user] pair")
+        n, n0 = len(user_ids), self.n_tokens
+        fp = (C.c_int32 * 2)(*first_pair)
+        us = (C.c_int32 * n)(*user_ids)
+        out = (C.c_int32 * n)()
+        done = C.c_int32()
+        N.check(self._lib.rca_lm_frame(self._h, fp, us, n, int(audio_id_floor), out, C.byref(done)), "rca_lm_frame")
+        toks = list(out[:done.value])
+        evaluated = first_pair + [t for pair in zip(toks[:-1], user_ids) for t in pair]
+        self._input_ids[n0:n0 + len(evaluated)] = evaluated
+        self._logits_valid = False
+        return toks
+
     def generate(self, tokens: Sequence[int], reset: bool = True, stopping_criteria=None) -> Generator[int, Optional[Sequence[int]], None]:
         """llamacpp_utils.py:97-181.  The agent always calls next(generate(ids, reset=False)) and drops the
         generator, so the first yield is the fused step; continuing the generator keeps sampling."""

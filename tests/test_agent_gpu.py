@@ -175,3 +175,19 @@ def test_trim_through_shadow_cache_equals_reference_recompute(mfma_prefill):
     assert runs[0][0] == runs[1][0]
     assert np.array_equal(runs[0][1], runs[1][1])
     assert np.array_equal(runs[0][2], runs[1][2])
+
+
+def test_frame_graph_session_equals_step_by_step_session():
+    """N1 (north_star: the per-frame loop is hipGraph-captured): the same sampled session with one graph replay per chunk
+    (llm.frame) and with one replay per step -- identical token streams, audio and final logits, trims included."""
+    runs = []
+    for frame_graph in (True, False):
+        agent, res = make_agent(chunk=0.08, max_context_secs=1.2, trim_by_secs=0.4)
+        agent.use_frame_graph = frame_graph
+        sig = rich_signal(1280 * 50, 35)
+        outs = [agent.process_audio(sig[s:s + 1280]) for s in range(0, len(sig), 1280)]
+        res.llm.eval(agent.input_ids[-2:])
+        runs.append((list(agent.input_ids), np.concatenate(outs), res.llm._scores[-1].copy()))
+        assert agent.frame_graph_active == frame_graph
+    assert runs[0][0] == runs[1][0]
+    assert np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])

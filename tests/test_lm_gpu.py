@@ -259,6 +259,59 @@ def test_shadow_cache_swap_equals_fresh_recompute(mfma_prefill):
         llm.swap_kv(make_llm("llama3", n_ctx=256)[0])       # different cache shape
 
 
+def _frame_vs_steps(llm, ctx, pair, users, floor, params):
+    """tokens of frame() vs the same steps taken one at a time (fresh sampler each), plus the logits / next token afterwards"""
+    res = []
+    for use_frame in (True, False):
+        llm.reset()
+        llm.init_sampler_for_generate(**params)
+        llm.eval(ctx)
+        if use_frame:
+            toks = llm.frame(pair, users, floor)
+        else:
+            toks, cur = [], list(pair)
+            for u in users:
+                t = llm.step(cur)
+                toks.append(t)
+                if t <= floor:
+                    break
+                cur = [t, u]
+        n_after = llm.n_tokens
+        follow = [llm.step([toks[-1], users[len(toks) - 1]]) for _ in range(1)]       # the draw counter must be in the same place
+        follow.append(llm.step([follow[0], users[0]]))
+        res.append((toks, n_after, follow, llm._scores[-1].copy()))
+    return res
+
+
+@pytest.mark.parametrize("graphs", [True, False])
+def test_frame_graph_equals_single_steps(graphs):
+    """rca_lm_frame: 4 or 5 S=2 steps with the sampled agent token fed back on the device == the same steps one at a time
+    (process_audio_input_ids, realtime_agent_v2.py:332-372): same tokens, KV position, draw counter and logits -- also when a step
+    leaves audio mode in the middle of the frame (the frame is cut there and the caller continues step by step)."""
+    llm, w, ids = make_llm("llama3")
+    llm.set_graphs(graphs)
+    ids = ids.tolist()
+    params = dict(top_k=20, top_p=1.0, min_p=0.0, temp=1.0, seed=11)
+    for n in (4, 5):
+        a, b = _frame_vs_steps(llm, ids[:9], ids[9:11], ids[11:11 + n], -1, params)
+        assert a[0] == b[0] and len(a[0]) == n and a[1] == b[1] == 9 + 2 * n
+        assert a[2] == b[2] and np.array_equal(a[3], b[3])
+    # cut short: choose the floor so that the SECOND sampled token is "not audio"
+    full = _frame_vs_steps(llm, ids[:9], ids[9:11], ids[11:15], -1, params)[0][0]
+    floor = full[1] if full[1] < full[0] else None
+    if floor is None:
+        floor = full[1]        # then the first one is cut too: still a valid case
+    a, b = _frame_vs_steps(llm, ids[:9], ids[9:11], ids[11:15], floor, params)
+    assert a[0] == b[0] and len(a[0]) < 4 and a[0][-1] <= floor
+    assert a[1] == b[1] == 9 + 2 * len(a[0])
+    assert a[2] == b[2] and np.array_equal(a[3], b[3])
+    from realtime_codec_agent_amd._native import RcaError
+    with pytest.raises(RcaError):
+        llm.frame(ids[9:11], [1] * 9, -1)            # more steps than a frame graph holds
+    with pytest.raises(RcaError):
+        llm.frame(ids[9:11], [llm._n_vocab], -1)
+
+
 def test_context_overflow_and_bad_args():
     from realtime_codec_agent_amd._native import RcaError
     llm, w, ids = make_llm("default", n_ctx=16)
@@ -332,6 +385,15 @@ def test_full_size_1b_properties():
     assert outs[0] == outs[1]
     want = lm_ref.sample(llm._scores[-1], 100, 1.0, 0.0, 1.0, 42, 5)
     assert outs[1][-1] == want
+    # the same six steps as one 4-step frame graph + two single steps
+    llm.set_graphs(True)
+    llm.n_tokens = 520
+    llm.init_sampler_for_generate(top_k=100, top_p=1.0, min_p=0.0, temp=1.0, seed=42)
+    seq = llm.frame(ids[520:522], ids[530:534], 128265)
+    assert seq == outs[0][:4] and llm.n_tokens == 528
+    seq.append(llm.step([seq[-1], ids[533]]))
+    seq.append(llm.step([seq[-1], ids[534]]))
+    assert seq == outs[0]
 
 
 # ~1B dims (H=2048, ffn 8192, 16 layers, V=259 344): |logit| <= ~4.5, std 0.9.  Exact mode sums 2048- and 8192-long dot

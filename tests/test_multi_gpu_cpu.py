@@ -117,3 +117,50 @@ def test_c_abi_library_exports_every_declared_symbol():
     # error behaviour without a device: bad arguments are rejected before any HIP call
     lib.rca_codec_hop.restype = ctypes.c_int
     assert lib.rca_codec_hop(None, None) == -1 and b"null" in lib.rca_last_error()
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_gpus_flag_starts_one_rank_per_gpu(monkeypatch, capsys):
+    """`python bench.py --gpus N` as the driver invokes it (no launcher, WORLD_SIZE unset) must start N ranks itself -- as CHILD
+    processes through torch.distributed.run, before anything touches the GPU -- relay rank 0's JSON line and exit with the ranks'
+    status; under a launcher a --gpus / WORLD_SIZE mismatch is refused (the reference's parallelism is N pinned processes:
+    encode_audio_gpu_{1..4}.sh, realtime_agent_v2.py:832-836)."""
+    import subprocess
+    import types
+    bench = _load_bench()
+    seen = {}
+
+    def fake_run(cmd, env=None, stdout=None, text=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return types.SimpleNamespace(returncode=0, stdout='noise\n{"metric": "m", "value": 1.0, "n_gpus": 4}\n')
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    called = {"cuda": False}
+    import torch
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *a, **k: called.__setitem__("cuda", True))
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and not called["cuda"]
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"] and cmd[-7].endswith("bench.py")
+    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+    assert capsys.readouterr().out.strip() == '{"metric": "m", "value": 1.0, "n_gpus": 4}'
+    # a failing rank: non-zero exit even though nothing was printed
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: types.SimpleNamespace(returncode=0, stdout="no json here\n"))
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code != 0
+    # under a launcher with the wrong world size
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code not in (0, None) and not called["cuda"]
