@@ -118,6 +118,14 @@ int rca_codec_encode_chunk_range_dev(rca_codec_t* h, const float* audio_dev, int
                                      int64_t chunk_begin, int64_t chunk_end, int64_t* codes_dev,
                                      int64_t codes_per_channel, void* stream);
 
+/* The same per-window arithmetic for B windows of T samples taken ANYWHERE in one device buffer -- window b starts at
+ * audio_dev + src_off_dev[b] (elements), its last n_keep codes go to codes_dev + dst_off_dev[b]; `span` = largest offset + T.
+ * codec_bpe.audio_to_codes fills its --batch_size windows from one file at a time (encode_audio_gpu_1.sh:2-8 over corpora of
+ * short utterances); with this call a pass holds windows of many files, including every file's short warm-up windows
+ * (the rolling context is still shorter than context_secs, audio_tokenizer.py:72-74), grouped by length. */
+int rca_codec_encode_rows_dev(rca_codec_t* h, const float* audio_dev, const int64_t* src_off_dev, int32_t B, int32_t T, int32_t n_keep,
+                              int64_t* codes_dev, const int64_t* dst_off_dev, int64_t span, void* stream);
+
 /* Streaming tail of the encoder.  AudioTokenizer.tokenize_audio re-encodes the whole rolling
  * window for every chunk and keeps only the last int(secs*framerate) codes (audio_tokenizer.py:72-74,98-101).
  * This returns exactly those codes -- bit-identical to the last n_keep columns of rca_codec_encode_dev(pcm, B, T) --

@@ -116,7 +116,7 @@ _lib = None
 ABI_SYMBOLS = [
     "rca_last_error", "rca_device_count", "rca_device_sync", "rca_version",
     "rca_codec_create", "rca_codec_destroy", "rca_codec_hop", "rca_codec_num_frames",
-    "rca_codec_encode", "rca_codec_encode_dev", "rca_codec_encode_windows_dev", "rca_codec_encode_chunk_range_dev",
+    "rca_codec_encode", "rca_codec_encode_dev", "rca_codec_encode_windows_dev", "rca_codec_encode_chunk_range_dev", "rca_codec_encode_rows_dev",
     "rca_codec_decode", "rca_codec_decode_dev",
     "rca_codec_encode_tail_dev", "rca_codec_decode_tail_dev", "rca_codec_encode_tail", "rca_codec_decode_tail", "rca_codec_set_stream_graphs", "rca_codec_receptive_field", "rca_codec_set_window_trim",
     "rca_codec_encoder_dev", "rca_codec_quantize_dev", "rca_codec_decoder_dev", "rca_codec_codebook_dev",

@@ -15,16 +15,27 @@ equal what streaming AudioTokenizer.tokenize_audio emits.  Multi-GPU: one proces
 (`torchrun --nproc-per-node N` or RANK/WORLD_SIZE env); files are dealt to ranks by duration; no collective on
 the data path.  Inputs: .wav (PCM16/float32) and .npy ([N] or [C,N]); compressed formats need a decoder that is
 not part of this build.
+
+Throughput path (HipWindowEncoder.encode_many, used whenever the encoder offers it): the corpora of the reference are tens
+of thousands of 10-60 s utterances, so a 256-window pass must not stop at a file boundary.  Files are gathered into
+"super-batches" (a few hundred MB of PCM), uploaded once, and EVERY window of every file in the super-batch -- the full
+2.0 s windows and the shorter warm-up windows at the start of each file, grouped by length -- goes through
+rca_codec_encode_rows_dev in full passes.  Three stages overlap: reader threads (disk -> float32), the main thread
+(pack, H2D from pinned memory, enqueue), a writer thread (D2H'd codes -> .npy).  The output tree is byte-identical to the
+one-file-at-a-time path (tests compare the two).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import queue
 import sys
+import threading
 import time
 import wave
-from typing import List, Optional, Sequence, Tuple
+from concurrent.futures import ThreadPoolExecutor
+from typing import Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -83,6 +94,60 @@ class HipWindowEncoder:
         self.model, _, _ = load_magicodec_model(codec_model, self.device)
         self.cfg = self.model.cfg
 
+    def encode_many(self, audios: Sequence[np.ndarray], chunk: int, ctx: int, batch_windows: int):
+        """audios: float32 [C, N_f] per file (same C).  -> (pinned host int64 codes [total], [(a, b)] slice of every (file, channel) row,
+        wait()) -- wait() blocks until the codes have landed in the host buffer.  Everything up to the D2H copy is enqueued
+        asynchronously, so the caller can prepare the next super-batch while this one runs."""
+        torch, hip = self.torch, self.model.hip
+        C = audios[0].shape[0]
+        W = max(chunk, ctx)
+        fpc = hip.frames_per_chunk(chunk)
+        lengths = [a.shape[-1] for a in audios]
+        # one pinned staging buffer, rows back to back (file-major, channel-minor), each start aligned to 4 samples
+        row_len = [((n + 3) // 4) * 4 for n in lengths for _ in range(C)]
+        src_base = np.concatenate([[0], np.cumsum(row_len)[:-1]]).astype(np.int64)
+        total = int(sum(row_len))
+        n_codes = [(n // chunk) * fpc for n in lengths for _ in range(C)]
+        dst_base = np.concatenate([[0], np.cumsum(n_codes)[:-1]]).astype(np.int64)
+        total_codes = int(sum(n_codes))
+        slices = [(int(b), int(b + n)) for b, n in zip(dst_base, n_codes)]
+        stage = torch.empty(max(total, 1), dtype=torch.float32).pin_memory()
+        sv = stage.numpy()
+        r = 0
+        for a in audios:
+            for c in range(C):
+                sv[src_base[r]:src_base[r] + a.shape[-1]] = a[c]
+                r += 1
+        T, src, dst = window_table(lengths, C, chunk, W, fpc, src_base, dst_base)
+        host_codes = torch.empty(max(total_codes, 1), dtype=torch.int64).pin_memory()
+        if len(T) == 0:
+            return host_codes.numpy()[:0], slices, (lambda: None)
+        with torch.cuda.device(self.device):
+            st = torch.cuda.current_stream(self.device)
+            dev_audio = stage.to(self.device, non_blocking=True)
+            tables = torch.from_numpy(np.stack([src, dst])).pin_memory().to(self.device, non_blocking=True)   # [2, n] int64
+            dev_codes = torch.empty(max(total_codes, 1), dtype=torch.int64, device=self.device)
+            i, n = 0, len(T)
+            while i < n:
+                t = int(T[i])
+                j = i
+                while j < n and T[j] == t:
+                    j += 1                                        # rows [i, j): one window length
+                for k in range(i, j, batch_windows):
+                    b = min(batch_windows, j - k)
+                    hip.encode_rows_dev(dev_audio.data_ptr(), tables[0].data_ptr() + 8 * k, b, t, fpc, dev_codes.data_ptr(),
+                                        tables[1].data_ptr() + 8 * k, total, st.cuda_stream)
+                i = j
+            host_codes.copy_(dev_codes, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(st)
+            keep = (stage, dev_audio, tables, dev_codes)          # alive until the copy has landed
+        hc = host_codes.numpy()[:total_codes]
+
+        def wait(_keep=keep):
+            ev.synchronize()
+        return hc, slices, wait
+
     def encode(self, audio: np.ndarray, chunk: int, ctx: int, batch_windows: int) -> np.ndarray:
         torch = self.torch
         hip = self.model.hip
@@ -98,29 +163,42 @@ class HipWindowEncoder:
         return out.cpu().numpy()
 
 
+def window_table(lengths: Sequence[int], channels: int, chunk: int, W: int, fpc: int, src_base: Sequence[int], dst_base: Sequence[int]):
+    """Every window of every (file, channel) row of a super-batch.  Row r (file-major, channel-minor) holds lengths[r // channels]
+    samples at element offset src_base[r]; its codes start at dst_base[r].  Chunk i of a row is encoded from the window of
+    T_i = min((i + 1) * chunk, W) samples ending at (i + 1) * chunk (the rolling context of audio_tokenizer.py:72-74) and keeps its
+    last fpc codes.  -> (T [n], src_off [n], dst_off [n]) int64, sorted by T descending (full windows first), stable."""
+    Ts, srcs, dsts = [], [], []
+    for r, (sb, db) in enumerate(zip(src_base, dst_base)):
+        n_chunks = lengths[r // channels] // chunk
+        if n_chunks == 0:
+            continue
+        end = (np.arange(n_chunks, dtype=np.int64) + 1) * chunk
+        T = np.minimum(end, W)
+        Ts.append(T)
+        srcs.append(sb + end - T)
+        dsts.append(db + np.arange(n_chunks, dtype=np.int64) * fpc)
+    if not Ts:
+        z = np.zeros(0, np.int64)
+        return z, z, z
+    T, src, dst = np.concatenate(Ts), np.concatenate(srcs), np.concatenate(dsts)
+    order = np.argsort(-T, kind="stable")
+    return T[order], src[order], dst[order]
+
+
 def encode_files(files: Sequence[str], encoder, args, rank: int = 0) -> Tuple[float, int]:
     """Encode `files` with `encoder` (anything with .cfg and .encode(audio, chunk, ctx, batch)); returns
     (audio seconds, codes written)."""
+    if hasattr(encoder, "encode_many") and not getattr(args, "one_file_at_a_time", False):
+        return encode_files_pipelined(files, encoder, args, rank)
     cfg = encoder.cfg
     sr = cfg.sample_rate
     chunk = int(args.chunk_size_secs * sr)
     ctx = int(args.context_secs * sr)
-    sub = "stereo" if args.stereo else "mono"
-    out_root = os.path.join(args.codes_path, args.codec_model, f"{args.chunk_size_secs}s_{args.context_secs}s", sub)
-    os.makedirs(out_root, exist_ok=True)
-    # consumers call get_codec_info(<codes_path>/<model>/<chunk>s_<ctx>s/{mono,stereo}) (tools/total_duration_codes.py:6-7)
-    info = os.path.join(out_root, "codec_info.json")
-    if rank == 0 and not os.path.exists(info):
-        with open(info, "w") as f:
-            json.dump({"num_codebooks": 1, "codebook_size": cfg.codebook_size, "framerate": cfg.framerate}, f)
+    out_root = _out_root(args, cfg, rank)
     total_secs, total_codes = 0.0, 0
     for path in files:
-        fsr, audio = read_audio(path)
-        if fsr != sr:
-            from .audio_tokenizer import _resample
-            audio = _resample(audio, fsr, sr)
-        if not args.stereo and audio.shape[0] > 1:
-            audio = audio.mean(axis=0, keepdims=True)
+        audio = _prepare(path, sr, args.stereo)
         codes = encoder.encode(audio, chunk, ctx, args.batch_size)
         rel = os.path.splitext(os.path.relpath(path, args.audio_path))[0]
         for c in range(codes.shape[0]):
@@ -130,6 +208,104 @@ def encode_files(files: Sequence[str], encoder, args, rank: int = 0) -> Tuple[fl
         total_secs += audio.shape[-1] / sr
         total_codes += int(codes.size)
     return total_secs, total_codes
+
+
+def _prepare(path: str, sr: int, stereo: bool) -> np.ndarray:
+    fsr, audio = read_audio(path)
+    if fsr != sr:
+        from .audio_tokenizer import _resample
+        audio = _resample(audio, fsr, sr)
+    if not stereo and audio.shape[0] > 1:
+        audio = audio.mean(axis=0, keepdims=True)
+    return np.ascontiguousarray(audio, dtype=np.float32)
+
+
+def _super_batches(files: Sequence[str], sr: int, stereo: bool, budget_samples: int, readers: int) -> Iterator[List[Tuple[str, np.ndarray]]]:
+    """Reader stage: files are decoded by a small thread pool (disk and int16 -> float32 conversion release the GIL) a bounded
+    distance ahead of the consumer and handed over in groups of about budget_samples samples (all channels counted)."""
+    with ThreadPoolExecutor(max_workers=readers) as pool:
+        pending: "queue.Queue" = queue.Queue()
+        it = iter(files)
+        inflight = 0
+
+        def submit_more():
+            nonlocal inflight
+            while inflight < 4 * readers:
+                p = next(it, None)
+                if p is None:
+                    return
+                pending.put((p, pool.submit(_prepare, p, sr, stereo)))
+                inflight += 1
+        submit_more()
+        group, size = [], 0
+        while inflight:
+            p, fut = pending.get()
+            audio = fut.result()
+            inflight -= 1
+            submit_more()
+            if group and size + audio.size > budget_samples:
+                yield group
+                group, size = [], 0
+            group.append((p, audio))
+            size += audio.size
+        if group:
+            yield group
+
+
+def encode_files_pipelined(files: Sequence[str], encoder, args, rank: int = 0) -> Tuple[float, int]:
+    """The same output tree as the one-file-at-a-time loop below, with windows batched across files and the three stages
+    (read, encode, write) overlapped."""
+    cfg = encoder.cfg
+    sr = cfg.sample_rate
+    chunk = int(args.chunk_size_secs * sr)
+    ctx = int(args.context_secs * sr)
+    out_root = _out_root(args, cfg, rank)
+    done: "queue.Queue" = queue.Queue(maxsize=4)
+    totals = [0.0, 0]
+    errors: List[BaseException] = []
+
+    def writer():
+        while True:
+            item = done.get()
+            if item is None:
+                return
+            try:
+                names, wait, host_codes, slices = item
+                wait()                                        # the D2H copy of this super-batch has landed
+                for (rel, c), (a, b) in zip(names, slices):
+                    dst = os.path.join(out_root, f"{rel}_c{c}.npy")
+                    os.makedirs(os.path.dirname(dst), exist_ok=True)
+                    np.save(dst, host_codes[a:b][None, :])    # (num_codebooks, T)
+            except BaseException as e:                        # surfaced by the main thread after the join
+                errors.append(e)
+    wt = threading.Thread(target=writer, daemon=True)
+    wt.start()
+    try:
+        for group in _super_batches(files, sr, args.stereo, getattr(args, "super_batch_samples", 1 << 26), getattr(args, "reader_threads", 4)):
+            audios = [a for _, a in group]
+            host_codes, slices, wait = encoder.encode_many(audios, chunk, ctx, args.batch_size)
+            names = [(os.path.splitext(os.path.relpath(p, args.audio_path))[0], c) for p, a in group for c in range(a.shape[0])]
+            done.put((names, wait, host_codes, slices))
+            totals[0] += sum(a.shape[-1] for a in audios) / sr
+            totals[1] += int(sum(b - a for a, b in slices))
+    finally:
+        done.put(None)
+        wt.join()
+    if errors:
+        raise errors[0]
+    return totals[0], totals[1]
+
+
+def _out_root(args, cfg, rank: int) -> str:
+    sub = "stereo" if args.stereo else "mono"
+    out_root = os.path.join(args.codes_path, args.codec_model, f"{args.chunk_size_secs}s_{args.context_secs}s", sub)
+    os.makedirs(out_root, exist_ok=True)
+    # consumers call get_codec_info(<codes_path>/<model>/<chunk>s_<ctx>s/{mono,stereo}) (tools/total_duration_codes.py:6-7)
+    info = os.path.join(out_root, "codec_info.json")
+    if rank == 0 and not os.path.exists(info):
+        with open(info, "w") as f:
+            json.dump({"num_codebooks": 1, "codebook_size": cfg.codebook_size, "framerate": cfg.framerate}, f)
+    return out_root
 
 
 def build_parser() -> argparse.ArgumentParser:
@@ -142,6 +318,9 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--codec_model", default="MagiCodec-50Hz-Base")
     ap.add_argument("--stereo", action="store_true")
     ap.add_argument("--audio_filter", nargs="+")
+    ap.add_argument("--one_file_at_a_time", action="store_true", help="the simple loop (a pass never spans files, no overlap of read / encode / write)")
+    ap.add_argument("--super_batch_samples", type=int, default=1 << 26, help="PCM samples (all channels) uploaded and encoded per super-batch")
+    ap.add_argument("--reader_threads", type=int, default=4)
     ap.add_argument("--receptive_field_trim", action="store_true",
                     help="encode only what each chunk's kept frames can see instead of the whole context window: identical "
                          "codes for this build's conv codec, ~8x faster (rca_codec_set_window_trim)")

@@ -163,6 +163,12 @@ class HipCodec:
                                                            C.c_int64(codes_per_channel), C.c_void_p(stream)),
                 "rca_codec_encode_chunk_range_dev")
 
+    def encode_rows_dev(self, audio_ptr: int, src_off_ptr: int, B: int, T: int, n_keep: int, codes_ptr: int, dst_off_ptr: int, span: int,
+                        stream: int = 0) -> None:
+        """B windows of T samples at audio + src_off[b]; the last n_keep codes of window b land at codes + dst_off[b]."""
+        N.check(self._lib.rca_codec_encode_rows_dev(self._h, C.c_void_p(audio_ptr), C.c_void_p(src_off_ptr), B, T, n_keep, C.c_void_p(codes_ptr),
+                                                    C.c_void_p(dst_off_ptr), C.c_int64(span), C.c_void_p(stream)), "rca_codec_encode_rows_dev")
+
     def encoder_dev(self, pcm_ptr: int, B: int, T: int, ze_ptr: int, stream: int = 0) -> None:
         N.check(self._lib.rca_codec_encoder_dev(self._h, C.c_void_p(pcm_ptr), B, T, C.c_void_p(ze_ptr), C.c_void_p(stream)), "rca_codec_encoder_dev")
 

@@ -45,6 +45,13 @@ struct RowSrc {
     long chan_stride;
     long win_stride;
     int T;
+    // optional per-row table (device): row b starts at base + row_off[b] instead of the (channel, window) lattice above --
+    // windows of many files batched into one pass (rca_codec_encode_rows_dev); `span` = max offset + T (host-known)
+    const long* row_off = nullptr;
+    long span = 0;
+    __device__ __forceinline__ long off(long b) const {
+        return row_off ? row_off[b] : (b % C) * chan_stride + (b / C) * win_stride;
+    }
 };
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v >= 0.0f ? v : v * slope; }
@@ -60,7 +67,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(RowSrc src, const float* _
     if (idx >= (long)B * Lout) return;
     const int b = (int)(idx / Lout);
     const int t = (int)(idx - (long)b * Lout);
-    const float* xr = src.base + (long)(b % src.C) * src.chan_stride + (long)(b / src.C) * src.win_stride;
+    const float* xr = src.base + src.off(b);
     constexpr int padL = KS / 2;
     float xv[KS];
 #pragma unroll
@@ -301,11 +308,18 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
     rca_rsrc_t rs_pcm = rs_none;
     unsigned prow[2] = {0u, 0u};
     if (FUSE) {
-        const int C = fin.src.C;
-        const int c0 = b_base % C, w0 = b_base / C;
-        const int c1 = c0 + 1 == C ? 0 : c0 + 1, w1 = c0 + 1 == C ? w0 + 1 : w0;
-        const long o0 = (long)c0 * fin.src.chan_stride + (long)w0 * fin.src.win_stride;
-        const long o1 = (long)c1 * fin.src.chan_stride + (long)w1 * fin.src.win_stride;
+        long o0, o1;
+        if (fin.src.row_off) {   // rows of several files: two wave-uniform table reads (the row after the last one is never staged)
+            const long nrows = (Ncols + Lout - 1) / Lout;
+            o0 = fin.src.row_off[b_base];
+            o1 = fin.src.row_off[b_base + 1 < nrows ? b_base + 1 : b_base];
+        } else {
+            const int C = fin.src.C;
+            const int c0 = b_base % C, w0 = b_base / C;
+            const int c1 = c0 + 1 == C ? 0 : c0 + 1, w1 = c0 + 1 == C ? w0 + 1 : w0;
+            o0 = (long)c0 * fin.src.chan_stride + (long)w0 * fin.src.win_stride;
+            o1 = (long)c1 * fin.src.chan_stride + (long)w1 * fin.src.win_stride;
+        }
         const long om = o0 < o1 ? o0 : o1;
         rs_pcm = rca_make_rsrc(fin.src.base + om, 0x7FFFFFFF);
         prow[0] = (unsigned)(o0 - om);
@@ -679,7 +693,7 @@ __global__ __launch_bounds__(512) void conv1d_ws_kernel(const float* __restrict_
                 const long nn = s_ok[r] ? n : 0;
                 const long b = nn / Lout;
                 const int i = (int)(nn - b * Lout) * S + p;
-                const float* row = fin.src.base + (long)(b % fin.src.C) * fin.src.chan_stride + (long)(b / fin.src.C) * fin.src.win_stride;
+                const float* row = fin.src.base + fin.src.off(b);
 #pragma unroll
                 for (int kk = 0; kk < 7; ++kk) {
                     const int j = i + kk - 3;
@@ -1257,6 +1271,7 @@ struct RowDst {
     long chan_stride;
     long win_stride;
     int fc;           // frames kept per row
+    const long* row_off = nullptr;   // optional per-row table (device): row b's codes go to base + row_off[b]
 };
 __global__ __launch_bounds__(256) void vq_finalize_kernel(unsigned long long* __restrict__ keys, RowDst dst, long rows) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1265,7 +1280,7 @@ __global__ __launch_bounds__(256) void vq_finalize_kernel(unsigned long long* __
     keys[i] = 0ull;
     const long b = i / dst.fc;
     const int j = (int)(i - b * dst.fc);
-    dst.base[(b % dst.C) * dst.chan_stride + (b / dst.C) * dst.win_stride + j] =
+    dst.base[(dst.row_off ? dst.row_off[b] : (b % dst.C) * dst.chan_stride + (b / dst.C) * dst.win_stride) + j] =
         (int64_t)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
 }
 
@@ -1869,7 +1884,7 @@ static int run_encoder(rca_codec* h, RowSrc src, int B, hipStream_t st, float** 
     const bool fuse01 = !h->lat_mode && h->variant >= 1 && tap_layer != 0 && E0.k == 7 && E1.wp && E1.k == 2 * E1.s && (double)B * E1.cin * L < 4.0e9 &&
                         ((E1.k == 4 && E1.s == 2) || (E1.k == 8 && E1.s == 4) || (E1.k == 16 && E1.s == 8)) && L / E1.s >= 67 &&
                         (double)E1.cout * (L / E1.s) < 2.6e8 &&
-                        (double)src.C * (double)std::labs(src.chan_stride) + (double)std::labs(src.win_stride) + src.T < 5.0e8;
+                        (src.row_off ? (double)src.span : (double)src.C * (double)std::labs(src.chan_stride) + (double)std::labs(src.win_stride) + src.T) < 5.0e8;
     // LeakyReLU hand-off: when layer li+1 is pre-activated and runs on conv1d_mfma_kernel, layer li stores LeakyReLU(y) and
     // li+1 skips the activation while staging (max(v, slope*v) of the same value either way: bit-identical, but applied once
     // per element instead of once per element per consuming workgroup per chunk).  Off when a layer output is tapped.
@@ -1896,7 +1911,7 @@ static int run_encoder(rca_codec* h, RowSrc src, int B, hipStream_t st, float** 
         L = Lout;
         first = 2;
         if (tap_layer == 1) RCA_HIP(hipMemcpyAsync(tap_dev, y, (size_t)B * E1.cout * L * 4, hipMemcpyDeviceToDevice, st));
-    } else if (h->lat_mode && src.win_stride == 0 && src.C == B &&
+    } else if (h->lat_mode && !src.row_off && src.win_stride == 0 && src.C == B &&
                try_conv_lds(h, h->enc[0], src.base, src.chan_stride, src.T, h->act[cur].as<float>(), B, L, 0, st)) {
         RCA_LAUNCH_CHECK();   // streaming tail: conv_in through the same latency kernel (rows straight from the caller's window)
     } else {
@@ -2142,6 +2157,28 @@ extern "C" int rca_codec_encode_windows_dev(rca_codec_t* h, const float* audio, 
                                             int32_t batch_windows, int64_t* codes, int64_t codes_per_channel, void* stream) {
     if (chunk < 1) return fail(RCA_ERR_ARG, "encode_windows: bad argument");
     return rca_codec_encode_chunk_range_dev(h, audio, C, N, chunk, ctx, batch_windows, 0, N / chunk, codes, codes_per_channel, stream);
+}
+
+// B windows of T samples each, anywhere in one device buffer (any file, channel, position): window b starts at
+// audio + src_off[b]; the last n_keep codes of window b are stored at codes + dst_off[b].  Per window the same arithmetic as
+// rca_codec_encode_dev (window_trim applies as in the chunk-range call).  This is what lets the batch CLI fill its 256-window
+// passes from MANY files at once, including the short warm-up windows at the start of every file.
+extern "C" int rca_codec_encode_rows_dev(rca_codec_t* h, const float* audio, const int64_t* src_off, int32_t B, int32_t T, int32_t n_keep,
+                                         int64_t* codes, const int64_t* dst_off, int64_t span, void* stream) {
+    if (!h || !audio || !src_off || !codes || !dst_off || B < 1 || T < 1 || n_keep < 1 || span < T)
+        return fail(RCA_ERR_ARG, "encode_rows: bad argument");
+    RCA_HIP(hipSetDevice(h->device));
+    hipStream_t st = pick_stream(h, stream);
+    static_assert(sizeof(long) == sizeof(int64_t), "offset tables are 64-bit");
+    const int Ffull = (T + h->hop - 1) / h->hop;
+    if (Ffull < n_keep) return fail(RCA_ERR_ARG, "encode_rows: a window of %d samples has %d frames < %d kept", T, Ffull, n_keep);
+    const int jw = h->window_trim ? trimmable_frames(h, Ffull, n_keep) : 0;
+    RowSrc src{audio + (long)jw * h->hop, B, 0, 0, T - jw * h->hop, reinterpret_cast<const long*>(src_off), (long)span};
+    float* ze; int F;
+    int rc;
+    if ((rc = run_encoder(h, src, B, st, &ze, &F, -1, nullptr)) != RCA_OK) return rc;
+    RowDst dst{codes, B, 0, 0, n_keep, reinterpret_cast<const long*>(dst_off)};
+    return run_quantize(h, ze, 0, B, F, F - n_keep, n_keep, dst, st, nullptr);
 }
 
 extern "C" int rca_codec_encoder_dev(rca_codec_t* h, const float* pcm, int32_t B, int32_t T, float* ze_out, void* stream) {

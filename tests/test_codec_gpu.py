@@ -348,3 +348,40 @@ def test_fuzz_encode_against_oracle_short():
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_encode_oracle.py"), "20", "5"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "fuzz ok" in r.stdout
+
+
+def test_batch_cli_cross_file_pipeline_equals_per_file_loop(tmp_path):
+    """The batch CLI on the GPU (full codec): windows batched across files through rca_codec_encode_rows_dev -- warm-up windows of many
+    files grouped by length, fused first layer reading rows from a per-row offset table -- writes byte for byte the tree of the
+    one-file-at-a-time loop (which the existing tests pin to the oracle's streaming semantics); same with receptive-field trim."""
+    import os
+    import wave
+    from realtime_codec_agent_amd import audio_to_codes
+    raw = str(tmp_path / "raw")
+    os.makedirs(os.path.join(raw, "sub"))
+    rng = np.random.default_rng(3)
+    for i, n in enumerate([16000 * 3, 16000 * 5 + 700, 9000, 16000 * 2 + 1600, 40000, 1000]):
+        sig = np.stack([rich_signal(n, 40 + i), bench_signal(n, 50 + i)])
+        p = os.path.join(raw, "sub" if i % 2 else "", f"f{i}.wav")
+        with wave.open(p, "wb") as w:
+            w.setnchannels(2); w.setsampwidth(2); w.setframerate(16000)
+            w.writeframes((np.clip(sig.T, -1, 1) * 32767).astype("<i2").tobytes())
+
+    def tree(root):
+        out = {}
+        for r, _, fs in os.walk(root):
+            for f in fs:
+                with open(os.path.join(r, f), "rb") as fh:
+                    out[os.path.relpath(os.path.join(r, f), root)] = fh.read()
+        return out
+    for extra in ([], ["--receptive_field_trim"]):
+        for stereo in ([], ["--stereo"]):
+            a = str(tmp_path / f"a{len(extra)}{len(stereo)}")
+            b = str(tmp_path / f"b{len(extra)}{len(stereo)}")
+            s1 = audio_to_codes.main(["--audio_path", raw, "--codes_path", a, "--one_file_at_a_time"] + extra + stereo)
+            s2 = audio_to_codes.main(["--audio_path", raw, "--codes_path", b, "--super_batch_samples", "200000"] + extra + stereo)
+            ta, tb = tree(a), tree(b)
+            assert ta.keys() == tb.keys() and len(ta) == 1 + (2 if stereo else 1) * 6
+            bad = [k for k in ta if ta[k] != tb[k]]
+            assert not bad, bad
+            assert s1["codes"] == s2["codes"] > 0

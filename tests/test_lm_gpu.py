@@ -389,7 +389,7 @@ def test_full_size_1b_properties():
     llm.set_graphs(True)
     llm.n_tokens = 520
     llm.init_sampler_for_generate(top_k=100, top_p=1.0, min_p=0.0, temp=1.0, seed=42)
-    seq = llm.frame(ids[520:522], ids[530:534], 128265)
+    seq = llm.frame(ids[520:522], ids[530:534], -1)       # (no lm_head rows are masked in this model: every id counts as audio here)
     assert seq == outs[0][:4] and llm.n_tokens == 528
     seq.append(llm.step([seq[-1], ids[533]]))
     seq.append(llm.step([seq[-1], ids[534]]))

@@ -164,3 +164,79 @@ def test_bench_gpus_flag_starts_one_rank_per_gpu(monkeypatch, capsys):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code not in (0, None) and not called["cuda"]
+
+
+class _OracleRowsEncoder:
+    """CPU stand-in for HipWindowEncoder with the SAME two entry points: encode (one file) and encode_many (a super-batch through
+    the window table, every window encoded on its own by the C oracle, exactly what rca_codec_encode_rows_dev does per row)."""
+
+    def __init__(self):
+        from oracle.codec import OracleCodec
+        from realtime_codec_agent_amd.codec_model import init_codec_weights, tiny_codec_config
+        self.cfg = tiny_codec_config()
+        self.oc = OracleCodec(self.cfg, init_codec_weights(self.cfg, seed=0))
+        self.passes = []
+
+    def encode(self, audio, chunk, ctx, batch):
+        return self.oc.encode_windows(audio, chunk, ctx)
+
+    def encode_many(self, audios, chunk, ctx, batch_windows):
+        from realtime_codec_agent_amd.audio_to_codes import window_table
+        C = audios[0].shape[0]
+        W, fpc = max(chunk, ctx), int((chunk / self.cfg.sample_rate) * self.cfg.framerate)
+        lengths = [a.shape[-1] for a in audios]
+        src_base = np.cumsum([0] + [n for n in lengths for _ in range(C)])[:-1]
+        n_codes = [(n // chunk) * fpc for n in lengths for _ in range(C)]
+        dst_base = np.cumsum([0] + n_codes)[:-1]
+        flat = np.concatenate([a[c] for a in audios for c in range(C)])
+        T, src, dst = window_table(lengths, C, chunk, W, fpc, src_base, dst_base)
+        out = np.full(int(sum(n_codes)), -1, np.int64)
+        i = 0
+        while i < len(T):
+            j = i
+            while j < len(T) and T[j] == T[i]:
+                j += 1
+            for k in range(i, j, batch_windows):
+                rows = np.stack([flat[s:s + T[i]] for s in src[k:min(j, k + batch_windows)]])
+                self.passes.append(rows.shape)
+                codes = self.oc.encode(rows)[:, -fpc:]
+                for d, c in zip(dst[k:k + len(rows)], codes):
+                    out[d:d + fpc] = c
+            i = j
+        assert (out >= 0).all()
+        return out, [(int(b), int(b + n)) for b, n in zip(dst_base, n_codes)], (lambda: None)
+
+
+def _tree(root):
+    out = {}
+    for r, _, fs in os.walk(root):
+        for f in fs:
+            with open(os.path.join(r, f), "rb") as fh:
+                out[os.path.relpath(os.path.join(r, f), root)] = fh.read()
+    return out
+
+
+def test_cross_file_batching_writes_the_same_tree(tmp_path):
+    """audio_to_codes with windows batched ACROSS files (window table, warm-up windows grouped by length, reader / writer threads)
+    writes byte for byte the tree of the one-file-at-a-time loop; passes are filled from several files."""
+    from realtime_codec_agent_amd import audio_to_codes
+    tmp = str(tmp_path)
+    raw = _make_corpus(tmp)
+    enc = _OracleRowsEncoder()
+    base = ["--audio_path", raw, "--stereo", "--batch_size", "16", "--context_secs", "0.5"]
+    a = audio_to_codes.main(base + ["--codes_path", os.path.join(tmp, "simple"), "--one_file_at_a_time"], encoder=enc, backend="gloo")
+    assert not enc.passes
+    b = audio_to_codes.main(base + ["--codes_path", os.path.join(tmp, "piped"), "--super_batch_samples", "60000", "--reader_threads", "2"],
+                            encoder=enc, backend="gloo")
+    ta, tb = _tree(os.path.join(tmp, "simple")), _tree(os.path.join(tmp, "piped"))
+    assert ta.keys() == tb.keys() and len(ta) == 1 + 2 * 5
+    assert all(ta[k] == tb[k] for k in ta)
+    assert a["codes"] == b["codes"] and abs(a["audio_hours"] - b["audio_hours"]) < 1e-12
+    full = [p for p in enc.passes if p[1] == 8000]
+    assert full and max(p[0] for p in full) == 16                      # full passes of 16 windows ...
+    assert any(p[1] == 1600 and p[0] > 2 for p in enc.passes)          # ... and warm-up windows of several files in one pass
+    # mono down-mix and a window longer than any file's tail
+    c = audio_to_codes.main(["--audio_path", raw, "--codes_path", os.path.join(tmp, "m1"), "--one_file_at_a_time"], encoder=enc, backend="gloo")
+    d = audio_to_codes.main(["--audio_path", raw, "--codes_path", os.path.join(tmp, "m2")], encoder=enc, backend="gloo")
+    tc, td = _tree(os.path.join(tmp, "m1")), _tree(os.path.join(tmp, "m2"))
+    assert tc.keys() == td.keys() and all(tc[k] == td[k] for k in tc) and c["codes"] == d["codes"]
