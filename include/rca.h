@@ -40,13 +40,14 @@ typedef struct rca_lm rca_lm_t;
 /* dtype tags for rca_tensor_t */
 #define RCA_F32 0
 #define RCA_BF16 1
+#define RCA_Q8_0 2   /* GGUF block_q8_0 as stored in the file: per 32 values one fp16 scale then 32 int8 (34 bytes); numel = values */
 
 /* A named host tensor handed to a create() call (weights). */
 typedef struct {
     const char* name;
     const void* data;  /* host pointer */
     int64_t numel;
-    int32_t dtype;     /* RCA_F32 or RCA_BF16 */
+    int32_t dtype;     /* RCA_F32, RCA_BF16, or RCA_Q8_0 (LM projection matrices and lm_head only) */
 } rca_tensor_t;
 
 const char* rca_last_error(void);
@@ -220,6 +221,9 @@ typedef struct {
     float rope_high_freq_factor;  /* 4 */
     int32_t rope_orig_ctx;    /* 8192 */
     int32_t logits_all;       /* keep logits of every evaluated position (aux_llm) */
+    int32_t decode_weights;   /* 0 = as supplied (bf16; tensors given as RCA_Q8_0 stay packed for the decode step), 1 = quantise every
+                                 projection matrix and lm_head to q8_0 at load, the way llama-quantize writes the Q8_0 file the reference
+                                 deploys (prep_test_model.sh:29): the decode step then streams 8.5 bits per weight */
 } rca_lm_config_t;
 
 typedef struct {
@@ -315,6 +319,10 @@ int rca_lm_set_graphs(rca_lm_t* h, int32_t enable);
  * :725-733) run as 128-token tiles on bf16 MFMA with hi/lo-split activations (default; logits within ~1e-3 of the
  * decode path); 0 routes them through the 8-token GEMV chunks, which are bit-identical to decode */
 int rca_lm_set_mfma_prefill(rca_lm_t* h, int32_t enable);
+/* decode from the packed q8_0 matrices (1, default whenever they exist) or from their bf16(d*q) copies (0); _has_q8 reports whether
+ * the handle holds packed matrices */
+int rca_lm_set_q8_decode(rca_lm_t* h, int32_t enable);
+int rca_lm_has_q8(const rca_lm_t* h, int32_t* out);
 /* synchronise the handle's stream (timing) */
 int rca_lm_sync(rca_lm_t* h);
 int rca_codec_sync(rca_codec_t* h);

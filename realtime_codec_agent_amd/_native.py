@@ -20,11 +20,30 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"
                "-Wno-unused-result"]
 
 MAX_STAGES = 8
-RCA_F32, RCA_BF16 = 0, 1
+RCA_F32, RCA_BF16, RCA_Q8_0 = 0, 1, 2
 
 
 class RcaError(RuntimeError):
     pass
+
+
+class Q8Blocks:
+    """A GGUF Q8_0 tensor kept as its raw 34-byte blocks (fp16 scale + 32 int8): raw uint8 [rows, cols / 32 * 34], logical shape (rows, cols)."""
+
+    def __init__(self, raw: np.ndarray, shape):
+        self.shape = tuple(int(x) for x in shape)
+        self.raw = raw.reshape(self.shape[0], self.shape[1] // 32 * 34)
+        self.dtype = np.dtype(np.uint8)
+
+    def dequantize(self) -> np.ndarray:
+        blk = self.raw.reshape(-1, 34)
+        d = blk[:, :2].copy().view(np.float16).astype(np.float32)
+        q = blk[:, 2:].view(np.int8).astype(np.float32)
+        return (q * d).reshape(self.shape)
+
+    def take_rows(self, index) -> "Q8Blocks":
+        r = self.raw[index]
+        return Q8Blocks(np.ascontiguousarray(r), (r.shape[0], self.shape[1]))
 
 
 class Tensor(C.Structure):
@@ -65,6 +84,7 @@ class LMConfigC(C.Structure):
         ("rope_high_freq_factor", C.c_float),
         ("rope_orig_ctx", C.c_int32),
         ("logits_all", C.c_int32),
+        ("decode_weights", C.c_int32),
     ]
 
 
@@ -127,7 +147,7 @@ ABI_SYMBOLS = [
     "rca_lm_logits_dev", "rca_lm_sampler_init", "rca_lm_sample", "rca_lm_step", "rca_lm_token_probs",
     "rca_lm_sync", "rca_lm_set_graphs", "rca_lm_mask_head_rows", "rca_lm_set_mfma_prefill", "rca_lm_set_logits_all",
     "rca_lm_persist_codec_embeddings", "rca_lm_create_shared", "rca_lm_eval_async", "rca_lm_copy_kv", "rca_lm_swap_kv",
-    "rca_lm_set_low_priority", "rca_lm_frame",
+    "rca_lm_set_low_priority", "rca_lm_frame", "rca_lm_set_q8_decode", "rca_lm_has_q8",
 ]
 
 
@@ -165,6 +185,12 @@ def make_tensors(weights: Dict[str, np.ndarray]) -> Tuple[C.Array, list]:
     keep = []
     arr = (Tensor * len(weights))()
     for i, (name, a) in enumerate(weights.items()):
+        if isinstance(a, Q8Blocks):      # GGUF q8_0 blocks, handed over as they sit in the file
+            raw = np.ascontiguousarray(a.raw)
+            nb = name.encode()
+            keep += [raw, nb]
+            arr[i] = Tensor(nb, raw.ctypes.data, int(np.prod(a.shape)), RCA_Q8_0)
+            continue
         if a.dtype == np.uint16:
             dt = RCA_BF16
         else:

@@ -284,10 +284,21 @@ __device__ __forceinline__ void wave_reduce_transposed(float (&val)[V]) {
     for (int i = 0; i < V / 4; ++i) val[i] = row16_sum(val[i]);
 }
 
-template <int M, int NIT, int R, int PRO, int EPI>
+// Q = 1: weights are q8_0 (GGUF block_q8_0: 32 int8 + one fp16 scale, what the reference deploys besides F16 and Q4_K_M,
+// prep_test_model.sh:28-31) kept PACKED in HBM -- 8.5 bits per weight streamed instead of 16.  Device layout (built once at load
+// from the 34-byte blocks): slot pairs interleaved, qs[pair][chunk] = 8 int8 of the pair's first row + 8 of its second row for
+// the same 8 k (one 16-byte lane load feeds two rows with the x values the lane already holds), scales sc[k / 32][pair] =
+// (fp16, fp16) so a lane fetches the scales of a whole batch with one or two vector loads.  Arithmetic per lane and row:
+// p = fma chain of (float)q_j * x_j over its 8 elements, then d * p accumulated per chunk -- f32 activations throughout
+// (llama.cpp quantises the activations to q8_1 for this product; here only the weights are quantised).
+struct GemvQ8 {
+    const u32x4* qs;      // [N / 2][K / 8] 16-byte units
+    const unsigned* sc;   // [K / 32][N / 2]
+};
+template <int M, int NIT, int R, int PRO, int EPI, int Q = 0>
 __global__ __launch_bounds__(256) void lm_gemv_kernel(const LmDevState* __restrict__ stt, const bf16_t* __restrict__ W,
                                                       const float* __restrict__ x, float* __restrict__ y, int N, int K,
-                                                      int batches_per_wg, int ldy, GemvPro pro, GemvRope rope) {
+                                                      int batches_per_wg, int ldy, GemvPro pro, GemvRope rope, GemvQ8 q8 = GemvQ8{nullptr, nullptr}) {
     constexpr int V = R * M;
     static_assert(V % 4 == 0 && R % 2 == 0, "R * M must be a multiple of 4");
     __shared__ float kred[2][4][V];
@@ -310,25 +321,57 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const LmDevState* __restri
         }
         return b * R + r;
     };
-    u32x4 wq[R][NIT];
+    constexpr int NL = Q ? R / 2 : R;        // 16-byte weight loads per chunk: one per row, or one per slot pair (q8_0)
+    u32x4 wq[NL][NIT];
+    unsigned wsc[Q ? NIT : 1][Q ? R / 2 : 1];   // q8_0: (fp16, fp16) scales of the batch's pairs for this lane's 32-element block
+    const int npairs = N >> 1;
+    // Every lane loads from a VALID address, whatever its chunk: a lane past the wave's range (narrow test models) re-reads chunk 0
+    // and multiplies it by x = 0.  A select or an exec mask on the loaded value would be a vector instruction on the load's
+    // result, i.e. a wait for it right behind its issue -- and with it for every load issued before.
+    const int cbase = cn > 0 ? c0 : 0;
     auto load_batch = [&](int b) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int row = min(row_of(b, r), N - 1);
-            const u32x4* wr = reinterpret_cast<const u32x4*>(W + (long)row * K) + c0;
+        if (Q) {
+            const long p0 = (long)b * (R / 2);
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int c = lane + 64 * it;
-                if (c < cn) wq[r][it] = __builtin_nontemporal_load(wr + c);
-                else wq[r][it] = u32x4{0u, 0u, 0u, 0u};
+                const int cc = cbase + (c < cn ? c : 0);
+                const unsigned* sp = q8.sc + (long)(cc >> 2) * npairs + p0;
+#pragma unroll
+                for (int s2 = 0; s2 < R / 2; ++s2) {
+                    const long pp = min(p0 + s2, (long)npairs - 1);
+                    wq[s2][it] = __builtin_nontemporal_load(q8.qs + pp * nchunk + cc);
+                }
+                if ((npairs & 3) == 0 && R / 2 >= 4) {   // aligned: the batch's scales in 16-byte loads
+#pragma unroll
+                    for (int s4 = 0; s4 < R / 8; ++s4) {
+                        const u32x4 t = *reinterpret_cast<const u32x4*>(sp + 4 * s4);
+                        wsc[it][4 * s4 + 0] = t.x; wsc[it][4 * s4 + 1] = t.y; wsc[it][4 * s4 + 2] = t.z; wsc[it][4 * s4 + 3] = t.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int s2 = 0; s2 < R / 2; ++s2) wsc[it][s2] = sp[min((long)s2, (long)npairs - 1 - p0)];
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int r = 0; r < NL; ++r) {
+            const int row = min(row_of(b, r), N - 1);
+            const u32x4* wr = reinterpret_cast<const u32x4*>(W + (long)row * K) + cbase;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = lane + 64 * it;
+                wq[r][it] = __builtin_nontemporal_load(wr + (c < cn ? c : 0));
             }
         }
     };
-    // the first batch's weights do not depend on x: get them in flight before the prologue
-    if (b_beg < b_end) load_batch(b_beg);
-
-    // ---- this lane's x values
+    // ---- this lane's x values.  Vector-memory results return in issue order, so the (short, L2-served) loads of x and of the
+    // norm weights go out FIRST and the first batch of weight loads right behind them: the prologue below then waits for its own
+    // operands only while the weights stay in flight under it.  (Issued the other way round, the first use of x would wait for
+    // every weight load in front of it and the RMSNorm chain would run after the weights had landed instead of under them.)
     float xr[M][NIT][8];
+    float nw[PRO == 1 ? NIT : 1][8];
     {
         int mbase = 0;
         if (PRO == 1 && pro.only_last) mbase = stt->m - 1;
@@ -351,6 +394,27 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const LmDevState* __restri
             }
         if (PRO == 1) {
 #pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = lane + 64 * it;
+                if (c < cn) {
+                    const float* p = pro.norm_w + (long)(c0 + c) * 8;
+                    const float4 a = *reinterpret_cast<const float4*>(p);
+                    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+                    nw[it][0] = a.x; nw[it][1] = a.y; nw[it][2] = a.z; nw[it][3] = a.w;
+                    nw[it][4] = b.x; nw[it][5] = b.y; nw[it][6] = b.z; nw[it][7] = b.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) nw[it][j] = 0.0f;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the issue order: x / norm weights, then the weight stream
+        // unconditional (the grid never holds a workgroup without a batch): a branch here would join a path with and one without
+        // loads in flight, and the compiler would wait for ALL of them at the join
+        load_batch(min(b_beg, n_batches - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        if (PRO == 1) {
+#pragma unroll
             for (int m = 0; m < M; ++m) {
                 float ss = 0.0f;
 #pragma unroll
@@ -366,17 +430,9 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const LmDevState* __restri
                 const float tot = ((nred[m][0] + nred[m][1]) + nred[m][2]) + nred[m][3];
                 const float rstd = rsqrtf(tot / (float)K + pro.eps);
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const int c = lane + 64 * it;
-                    if (c < cn) {
-                        const float* p = pro.norm_w + (long)(c0 + c) * 8;
-                        const float4 a = *reinterpret_cast<const float4*>(p);
-                        const float4 b = *reinterpret_cast<const float4*>(p + 4);
-                        const float wv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                for (int it = 0; it < NIT; ++it)
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) xr[m][it][j] = (xr[m][it][j] * rstd) * wv[j];
-                    }
-                }
+                    for (int j = 0; j < 8; ++j) xr[m][it][j] = (xr[m][it][j] * rstd) * nw[it][j];
             }
         }
     }
@@ -387,8 +443,43 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const LmDevState* __restri
         float val[V];   // value index v = m * R + r
 #pragma unroll
         for (int v = 0; v < V; ++v) val[v] = 0.0f;
+        if (Q) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
+            for (int s2 = 0; s2 < R / 2; ++s2) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const u32x4 a = wq[s2][it];
+                    const unsigned wa[2] = {a.x, a.y}, wb[2] = {a.z, a.w};
+                    float pa[M], pb[M];
+#pragma unroll
+                    for (int m = 0; m < M; ++m) pa[m] = pb[m] = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        // signed byte j as a target bit-field extract: written with shifts and masks the optimiser turns the whole
+                        // 16-byte load into sixteen byte values unpacked the moment it lands (4x the registers, no loads in flight)
+                        const float fa = (float)__builtin_amdgcn_sbfe((int)wa[j >> 2], 8 * (j & 3), 8);
+                        const float fb = (float)__builtin_amdgcn_sbfe((int)wb[j >> 2], 8 * (j & 3), 8);
+#pragma unroll
+                        for (int m = 0; m < M; ++m) {
+                            pa[m] = __builtin_fmaf(fa, xr[m][it][j], pa[m]);
+                            pb[m] = __builtin_fmaf(fb, xr[m][it][j], pb[m]);
+                        }
+                    }
+                    const f16x2 d2 = __builtin_bit_cast(f16x2, wsc[it][s2]);
+                    const float da = (float)d2[0], db = (float)d2[1];
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+                        val[m * R + 2 * s2] = __builtin_fmaf(da, pa[m], val[m * R + 2 * s2]);
+                        val[m * R + 2 * s2 + 1] = __builtin_fmaf(db, pb[m], val[m * R + 2 * s2 + 1]);
+                    }
+                    // one pair at a time: without the fence the scheduler converts the bytes of EVERY load in flight up front
+                    // (16 floats each) and the kernel drops to one wave per SIMD
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+#pragma unroll
+        for (int r = 0; r < NL; ++r) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const u32x4 a = wq[r][it];
@@ -399,9 +490,9 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const LmDevState* __restri
                     for (int j = 0; j < 8; ++j) val[m * R + r] = __builtin_fmaf(f[j], xr[m][it][j], val[m * R + r]);
             }
         }
-        // the weight registers are free: request the next batch before the (latency-bound) reduction and epilogue
-        if (b + 1 < b_end) load_batch(b + 1);
-        // epilogue operands that do not depend on the sums (fetched under the reduction)
+        }
+        // epilogue operands that do not depend on the sums (fetched under the reduction; issued BEFORE the next batch's weights so
+        // that waiting for them does not mean waiting for those)
         float yv = 0.0f, cs = 0.0f, sn = 0.0f;
         if (EPI == 3 && tid < V) {
             const int m = tid / R, row = row_of(b, tid % R);
@@ -414,6 +505,8 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const LmDevState* __restri
             cs = rope.cos_t[pos * 32 + d];
             sn = rope.sin_t[pos * 32 + d];
         }
+        // the weight registers are free: request the next batch before the (latency-bound) reduction and epilogue
+        if (b + 1 < b_end) load_batch(b + 1);
         wave_reduce_transposed<V>(val);
         const int buf = (b - b_beg) & 1;
         if ((lane & 15) == 0) {
@@ -951,9 +1044,80 @@ __global__ __launch_bounds__(256) void lm_f32_to_bf16_kernel(const float* __rest
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = f32_to_bf16_rne(in[i]);
 }
 
+// ------------------------------------------------------------------------- q8_0 weights
+// GGUF block_q8_0 = { fp16 d; int8 qs[32] } (34 bytes), value = d * q.  "Plain" form on the device: q [N][K] int8 and
+// d [N][K / 32] fp16; from there the pair-interleaved layout the GEMV streams (GemvQ8) and a bf16(d * q) copy for the prefill tiles.
+__global__ __launch_bounds__(256) void lm_q8_unblock_kernel(const unsigned char* __restrict__ blocks, long nblocks, signed char* __restrict__ q,
+                                                            f16_t* __restrict__ d) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nblocks * 32; i += (long)gridDim.x * blockDim.x) {
+        const long blk = i >> 5;
+        const int j = (int)(i & 31);
+        const unsigned char* bp = blocks + blk * 34;
+        q[i] = (signed char)bp[2 + j];
+        if (j == 0) {
+            const unsigned short bits = (unsigned short)bp[0] | ((unsigned short)bp[1] << 8);
+            d[blk] = __builtin_bit_cast(f16_t, bits);
+        }
+    }
+}
+// llama.cpp's quantize_row_q8_0: d = amax / 127, q = round(x / d) (ties away from zero), d stored as fp16
+__global__ __launch_bounds__(256) void lm_q8_quantize_kernel(const bf16_t* __restrict__ w, long nblocks, signed char* __restrict__ q,
+                                                             f16_t* __restrict__ d) {
+    for (long blk = (long)blockIdx.x * blockDim.x + threadIdx.x; blk < nblocks; blk += (long)gridDim.x * blockDim.x) {
+        float v[32];
+        float amax = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            v[j] = __uint_as_float((unsigned)w[blk * 32 + j] << 16);
+            amax = fmaxf(amax, fabsf(v[j]));
+        }
+        const float dd = amax / 127.0f;
+        const float id = dd != 0.0f ? 1.0f / dd : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) q[blk * 32 + j] = (signed char)(int)roundf(v[j] * id);
+        d[blk] = (f16_t)dd;
+    }
+}
+__global__ __launch_bounds__(256) void lm_q8_dequant_bf16_kernel(const signed char* __restrict__ q, const f16_t* __restrict__ d, bf16_t* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = f32_to_bf16_rne((float)d[i >> 5] * (float)q[i]);
+}
+// rows of two byte matrices interleaved: dst row 2i = a row i, 2i+1 = b row i (gate/up, in q and in d)
+__global__ __launch_bounds__(256) void lm_interleave_rows_bytes_kernel(const unsigned char* __restrict__ a, const unsigned char* __restrict__ b,
+                                                                       unsigned char* __restrict__ dst, long rows, long row_bytes) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * rows * row_bytes; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / row_bytes, o = i - row * row_bytes;
+        dst[i] = (row & 1) ? b[(row >> 1) * row_bytes + o] : a[(row >> 1) * row_bytes + o];
+    }
+}
+// plain -> GemvQ8.  pair pp = rows (2pp, 2pp+1), or for the fused QKV matrix (qkv_pairs) rows (d, d+32) of one head.
+__global__ __launch_bounds__(256) void lm_q8_pack_kernel(const signed char* __restrict__ q, const f16_t* __restrict__ d, int N, int K, int qkv_pairs,
+                                                         u32x4* __restrict__ qs, unsigned* __restrict__ sc) {
+    const long nchunk = K >> 3, npairs = N >> 1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npairs * nchunk; i += (long)gridDim.x * blockDim.x) {
+        const long pp = i / nchunk;
+        const int c = (int)(i - pp * nchunk);
+        const long ra = qkv_pairs ? (pp >> 5) * 64 + (pp & 31) : 2 * pp;
+        const long rb = qkv_pairs ? ra + 32 : ra + 1;
+        const uint2 a = *reinterpret_cast<const uint2*>(q + ra * K + 8 * c);
+        const uint2 b = *reinterpret_cast<const uint2*>(q + rb * K + 8 * c);
+        qs[i] = u32x4{a.x, a.y, b.x, b.y};
+        if ((c & 3) == 0) {
+            const unsigned short da = __builtin_bit_cast(unsigned short, d[ra * (K >> 5) + (c >> 2)]);
+            const unsigned short db = __builtin_bit_cast(unsigned short, d[rb * (K >> 5) + (c >> 2)]);
+            sc[(long)(c >> 2) * npairs + pp] = (unsigned)da | ((unsigned)db << 16);
+        }
+    }
+}
+
 // =============================================================================================
+struct Q8Mat {
+    u32x4* qs = nullptr;
+    unsigned* sc = nullptr;
+};
 struct LmLayer {
     bf16_t *wqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wdown = nullptr;
+    Q8Mat qqkv, qo, qgu, qdown;   // set when the decode GEMVs stream q8_0 (rca_lm_config_t::decode_weights / RCA_Q8_0 tensors)
     float *attn_norm = nullptr, *ffn_norm = nullptr;
 };
 
@@ -962,6 +1126,7 @@ struct rca_lm {
     int device = 0;
     hipStream_t stream = nullptr;
     bf16_t *embed = nullptr, *head = nullptr;
+    Q8Mat qhead;
     float* final_norm = nullptr;
     std::vector<LmLayer> layers;
     float *cos_t = nullptr, *sin_t = nullptr;
@@ -993,7 +1158,8 @@ struct rca_lm {
     bool async_pending = false;   // an rca_lm_eval_async pass may still be running on the stream
     unsigned long long rng_host = 0;   // host mirror of the device's draw counter (restored when a frame graph is cut short)
     bool graphs_enabled = true;
-    bool mfma_prefill = true;   // evals longer than LM_GEMV_M tokens use the bf16 MFMA tiles
+    bool mfma_prefill = true;   // evals longer than LM_PREFILL_MIN tokens use the bf16 MFMA tiles
+    bool use_q8 = true;         // stream the packed q8_0 form of a matrix when it has one (rca_lm_set_q8_decode: tests compare with the bf16(d*q) copy)
     // weight sharing (rca_lm_create_shared): a borrower points at the handle that owns the weights and the RoPE tables; an owner
     // destroyed while borrowers are alive keeps those allocations (and its struct) until the last borrower is gone
     rca_lm* weights_of = nullptr;
@@ -1009,10 +1175,12 @@ static int lm_alloc(void** p, size_t bytes) {
 
 static void lm_free_weights(rca_lm* h) {
     for (auto& L : h->layers)
-        for (void* p : {(void*)L.wqkv, (void*)L.wo, (void*)L.wgu, (void*)L.wdown, (void*)L.attn_norm, (void*)L.ffn_norm})
+        for (void* p : {(void*)L.wqkv, (void*)L.wo, (void*)L.wgu, (void*)L.wdown, (void*)L.attn_norm, (void*)L.ffn_norm, (void*)L.qqkv.qs, (void*)L.qqkv.sc,
+                        (void*)L.qo.qs, (void*)L.qo.sc, (void*)L.qgu.qs, (void*)L.qgu.sc, (void*)L.qdown.qs, (void*)L.qdown.sc})
             if (p) (void)hipFree(p);
-    for (void* p : {(void*)h->embed, (void*)h->head, (void*)h->final_norm, (void*)h->cos_t, (void*)h->sin_t})
+    for (void* p : {(void*)h->embed, (void*)h->head, (void*)h->final_norm, (void*)h->cos_t, (void*)h->sin_t, (void*)h->qhead.qs, (void*)h->qhead.sc})
         if (p) (void)hipFree(p);
+    h->qhead = Q8Mat{};
     h->layers.clear();
     h->embed = h->head = nullptr;
     h->final_norm = h->cos_t = h->sin_t = nullptr;
@@ -1090,13 +1258,38 @@ static int lm_check_cfg(const rca_lm_config_t* c) {
     return RCA_OK;
 }
 
-// uploads a tensor as bf16 (converting from f32 on the device when needed)
-static int lm_upload_bf16(rca_lm* h, const rca_tensor_t* ts, int nt, const std::string& name, long numel, bf16_t** out) {
+struct Q8Plain {   // a matrix that arrived as q8_0 blocks, unblocked on the device: q [numel] int8, d [numel / 32] fp16
+    signed char* q = nullptr;
+    f16_t* d = nullptr;
+    void release() { if (q) (void)hipFree(q); if (d) (void)hipFree(d); q = nullptr; d = nullptr; }
+};
+// uploads a tensor as bf16 (converting from f32 on the device when needed).  A tensor supplied as RCA_Q8_0 (the 34-byte GGUF
+// blocks as they sit in the file) is unblocked on the device; its bf16 form is bf16(d * q) and, when `plain` is given, the
+// unblocked q / d stay for the packed decode layout.
+static int lm_upload_bf16(rca_lm* h, const rca_tensor_t* ts, int nt, const std::string& name, long numel, bf16_t** out, Q8Plain* plain = nullptr) {
     const rca_tensor_t* t = find_tensor(ts, nt, name);
     if (!t) return fail(RCA_ERR_MISSING, "tensor '%s' missing", name.c_str());
     if (t->numel != numel) return fail(RCA_ERR_ARG, "tensor '%s': numel %ld, expected %ld", name.c_str(), (long)t->numel, numel);
     int rc;
     if ((rc = lm_alloc((void**)out, (size_t)numel * 2)) != RCA_OK) return rc;
+    if (t->dtype == RCA_Q8_0) {
+        if (numel % 32) return fail(RCA_ERR_ARG, "tensor '%s': q8_0 needs a multiple of 32 elements", name.c_str());
+        const long nblk = numel / 32;
+        unsigned char* raw = nullptr;
+        Q8Plain pl;
+        if ((rc = lm_alloc((void**)&raw, (size_t)nblk * 34)) != RCA_OK) return rc;
+        if ((rc = lm_alloc((void**)&pl.q, (size_t)numel)) != RCA_OK || (rc = lm_alloc((void**)&pl.d, (size_t)nblk * 2)) != RCA_OK) { (void)hipFree(raw); pl.release(); return rc; }
+        hipError_t e = hipMemcpy(raw, t->data, (size_t)nblk * 34, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            lm_q8_unblock_kernel<<<4096, 256, 0, h->stream>>>(raw, nblk, pl.q, pl.d);
+            lm_q8_dequant_bf16_kernel<<<4096, 256, 0, h->stream>>>(pl.q, pl.d, *out, numel);
+            e = hipStreamSynchronize(h->stream);
+        }
+        (void)hipFree(raw);
+        if (e != hipSuccess) { pl.release(); return fail(RCA_ERR_HIP, "upload '%s': %s", name.c_str(), hipGetErrorString(e)); }
+        if (plain) *plain = pl; else pl.release();
+        return RCA_OK;
+    }
     if (t->dtype == RCA_BF16) {
         RCA_HIP(hipMemcpy(*out, t->data, (size_t)numel * 2, hipMemcpyHostToDevice));
     } else {
@@ -1229,6 +1422,36 @@ static int lm_new(const rca_lm_config_t* cfg, int device, rca_lm** out) {
     return RCA_OK;
 }
 
+// The packed decode form of one projection matrix [N][K] (rows in the order the GEMV's slots use them).  `plain` = its q8_0 values
+// if it arrived as blocks; otherwise, when the handle was asked to stream q8_0 (cfg.decode_weights), the bf16 matrix is quantised
+// here the way llama-quantize does and REPLACED by bf16(d * q), so that the prefill tiles and the decode GEMVs see one model.
+static int lm_finish_q8(rca_lm* h, bf16_t* w, Q8Plain plain, int N, int K, int qkv_pairs, Q8Mat* out, const char* what) {
+    const bool want = plain.q != nullptr || h->cfg.decode_weights == 1;
+    if (!want) return RCA_OK;
+    const bool fits = (K % 32) == 0 && (N % 2) == 0 && (!qkv_pairs || (N % 64) == 0);
+    if (!fits) {
+        plain.release();
+        if (h->cfg.decode_weights == 1) return fail(RCA_ERR_ARG, "q8_0 decode weights: %s is %d x %d (K must be a multiple of 32, N even)", what, N, K);
+        return RCA_OK;   // stays on the bf16(d * q) copy
+    }
+    int rc;
+    const long numel = (long)N * K;
+    if (!plain.q) {
+        if ((rc = lm_alloc((void**)&plain.q, (size_t)numel)) != RCA_OK || (rc = lm_alloc((void**)&plain.d, (size_t)(numel / 32) * 2)) != RCA_OK) { plain.release(); return rc; }
+        lm_q8_quantize_kernel<<<4096, 256, 0, h->stream>>>(w, numel / 32, plain.q, plain.d);
+        lm_q8_dequant_bf16_kernel<<<4096, 256, 0, h->stream>>>(plain.q, plain.d, w, numel);
+    }
+    const long npairs = N / 2, nchunk = K / 8;
+    if ((rc = lm_alloc((void**)&out->qs, (size_t)npairs * nchunk * 16)) != RCA_OK ||
+        (rc = lm_alloc((void**)&out->sc, (size_t)(K / 32) * npairs * 4 + 256)) != RCA_OK) { plain.release(); return rc; }   // + slack: the last batch's vector scale load
+    (void)hipMemsetAsync(out->sc, 0, (size_t)(K / 32) * npairs * 4 + 256, h->stream);
+    lm_q8_pack_kernel<<<4096, 256, 0, h->stream>>>(plain.q, plain.d, N, K, qkv_pairs, out->qs, out->sc);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    plain.release();
+    if (e != hipSuccess) return fail(RCA_ERR_HIP, "q8_0 pack of %s: %s", what, hipGetErrorString(e));
+    return RCA_OK;
+}
+
 extern "C" int rca_lm_create(const rca_lm_config_t* cfg, const rca_tensor_t* ts, int32_t nt, int32_t device, rca_lm_t** out) {
     if (!ts || !out) return fail(RCA_ERR_ARG, "null argument");
     rca_lm* h = nullptr;
@@ -1238,29 +1461,59 @@ extern "C" int rca_lm_create(const rca_lm_config_t* cfg, const rca_tensor_t* ts,
     const rca_lm_config_t& c = h->cfg;
     const long H = c.hidden, V = c.vocab_size, F = c.ffn, Q = (long)c.n_heads * c.head_dim, KVD = (long)c.n_kv_heads * c.head_dim;
     if ((rc = lm_upload_bf16(h, ts, nt, "model.embed_tokens.weight", V * H, &h->embed)) != RCA_OK) return bail(rc);
-    if ((rc = lm_upload_bf16(h, ts, nt, "lm_head.weight", V * H, &h->head)) != RCA_OK) return bail(rc);
+    {
+        Q8Plain ph;
+        if ((rc = lm_upload_bf16(h, ts, nt, "lm_head.weight", V * H, &h->head, &ph)) != RCA_OK) return bail(rc);
+        if ((rc = lm_finish_q8(h, h->head, ph, (int)V, (int)H, 0, &h->qhead, "lm_head")) != RCA_OK) return bail(rc);
+    }
     if ((rc = lm_upload_f32(ts, nt, "model.norm.weight", H, &h->final_norm)) != RCA_OK) return bail(rc);
     for (int l = 0; l < c.n_layers; ++l) {
         const std::string p = "model.layers." + std::to_string(l) + ".";
         LmLayer& L = h->layers[l];
         bf16_t *q = nullptr, *k = nullptr, *v = nullptr, *g = nullptr, *u = nullptr;
-        auto free5 = [&]() { for (bf16_t* t : {q, k, v, g, u}) if (t) (void)hipFree(t); };
-        if ((rc = lm_upload_bf16(h, ts, nt, p + "self_attn.q_proj.weight", Q * H, &q)) != RCA_OK ||
-            (rc = lm_upload_bf16(h, ts, nt, p + "self_attn.k_proj.weight", KVD * H, &k)) != RCA_OK ||
-            (rc = lm_upload_bf16(h, ts, nt, p + "self_attn.v_proj.weight", KVD * H, &v)) != RCA_OK ||
-            (rc = lm_upload_bf16(h, ts, nt, p + "mlp.gate_proj.weight", F * H, &g)) != RCA_OK ||
-            (rc = lm_upload_bf16(h, ts, nt, p + "mlp.up_proj.weight", F * H, &u)) != RCA_OK) { free5(); return bail(rc); }
+        Q8Plain pq, pk, pv, pg, pu;
+        auto free5 = [&]() { for (bf16_t* t : {q, k, v, g, u}) if (t) (void)hipFree(t); for (Q8Plain* t : {&pq, &pk, &pv, &pg, &pu}) t->release(); };
+        if ((rc = lm_upload_bf16(h, ts, nt, p + "self_attn.q_proj.weight", Q * H, &q, &pq)) != RCA_OK ||
+            (rc = lm_upload_bf16(h, ts, nt, p + "self_attn.k_proj.weight", KVD * H, &k, &pk)) != RCA_OK ||
+            (rc = lm_upload_bf16(h, ts, nt, p + "self_attn.v_proj.weight", KVD * H, &v, &pv)) != RCA_OK ||
+            (rc = lm_upload_bf16(h, ts, nt, p + "mlp.gate_proj.weight", F * H, &g, &pg)) != RCA_OK ||
+            (rc = lm_upload_bf16(h, ts, nt, p + "mlp.up_proj.weight", F * H, &u, &pu)) != RCA_OK) { free5(); return bail(rc); }
         // fused layouts: [q; k; v] rows, and gate/up rows interleaved for the SwiGLU epilogue
         if ((rc = lm_alloc((void**)&L.wqkv, (size_t)(Q + 2 * KVD) * H * 2)) != RCA_OK || (rc = lm_alloc((void**)&L.wgu, (size_t)2 * F * H * 2)) != RCA_OK) { free5(); return bail(rc); }
         (void)hipMemcpyAsync(L.wqkv, q, Q * H * 2, hipMemcpyDeviceToDevice, h->stream);
         (void)hipMemcpyAsync(L.wqkv + Q * H, k, KVD * H * 2, hipMemcpyDeviceToDevice, h->stream);
         (void)hipMemcpyAsync(L.wqkv + (Q + KVD) * H, v, KVD * H * 2, hipMemcpyDeviceToDevice, h->stream);
         lm_interleave_rows_kernel<<<cdiv(2 * F * H, 256), 256, 0, h->stream>>>(g, u, L.wgu, (int)F, (int)H);
+        // the same fusions on the q8_0 values when every part arrived as blocks
+        Q8Plain pqkv, pgu;
+        if (pq.q && pk.q && pv.q && (H % 32) == 0) {
+            const long Hb = H / 32;
+            if ((rc = lm_alloc((void**)&pqkv.q, (size_t)(Q + 2 * KVD) * H)) != RCA_OK || (rc = lm_alloc((void**)&pqkv.d, (size_t)(Q + 2 * KVD) * Hb * 2)) != RCA_OK) { pqkv.release(); free5(); return bail(rc); }
+            (void)hipMemcpyAsync(pqkv.q, pq.q, Q * H, hipMemcpyDeviceToDevice, h->stream);
+            (void)hipMemcpyAsync(pqkv.q + Q * H, pk.q, KVD * H, hipMemcpyDeviceToDevice, h->stream);
+            (void)hipMemcpyAsync(pqkv.q + (Q + KVD) * H, pv.q, KVD * H, hipMemcpyDeviceToDevice, h->stream);
+            (void)hipMemcpyAsync(pqkv.d, pq.d, Q * Hb * 2, hipMemcpyDeviceToDevice, h->stream);
+            (void)hipMemcpyAsync(pqkv.d + Q * Hb, pk.d, KVD * Hb * 2, hipMemcpyDeviceToDevice, h->stream);
+            (void)hipMemcpyAsync(pqkv.d + (Q + KVD) * Hb, pv.d, KVD * Hb * 2, hipMemcpyDeviceToDevice, h->stream);
+        }
+        if (pg.q && pu.q && (H % 32) == 0) {
+            const long Hb = H / 32;
+            if ((rc = lm_alloc((void**)&pgu.q, (size_t)2 * F * H)) != RCA_OK || (rc = lm_alloc((void**)&pgu.d, (size_t)2 * F * Hb * 2)) != RCA_OK) { pqkv.release(); pgu.release(); free5(); return bail(rc); }
+            lm_interleave_rows_bytes_kernel<<<4096, 256, 0, h->stream>>>((const unsigned char*)pg.q, (const unsigned char*)pu.q, (unsigned char*)pgu.q, F, H);
+            lm_interleave_rows_bytes_kernel<<<1024, 256, 0, h->stream>>>((const unsigned char*)pg.d, (const unsigned char*)pu.d, (unsigned char*)pgu.d, F, Hb * 2);
+        }
         hipError_t e = hipStreamSynchronize(h->stream);
         free5();
-        if (e != hipSuccess) return bail(fail(RCA_ERR_HIP, "layer %d pack: %s", l, hipGetErrorString(e)));
-        if ((rc = lm_upload_bf16(h, ts, nt, p + "self_attn.o_proj.weight", H * Q, &L.wo)) != RCA_OK) return bail(rc);
-        if ((rc = lm_upload_bf16(h, ts, nt, p + "mlp.down_proj.weight", H * F, &L.wdown)) != RCA_OK) return bail(rc);
+        if (e != hipSuccess) { pqkv.release(); pgu.release(); return bail(fail(RCA_ERR_HIP, "layer %d pack: %s", l, hipGetErrorString(e))); }
+        if ((rc = lm_finish_q8(h, L.wqkv, pqkv, (int)(Q + 2 * KVD), (int)H, 1, &L.qqkv, "the fused QKV projection")) != RCA_OK) { pgu.release(); return bail(rc); }
+        if ((rc = lm_finish_q8(h, L.wgu, pgu, (int)(2 * F), (int)H, 0, &L.qgu, "the fused gate/up projection")) != RCA_OK) return bail(rc);
+        {
+            Q8Plain po, pd;
+            if ((rc = lm_upload_bf16(h, ts, nt, p + "self_attn.o_proj.weight", H * Q, &L.wo, &po)) != RCA_OK) return bail(rc);
+            if ((rc = lm_finish_q8(h, L.wo, po, (int)H, (int)Q, 0, &L.qo, "o_proj")) != RCA_OK) return bail(rc);
+            if ((rc = lm_upload_bf16(h, ts, nt, p + "mlp.down_proj.weight", H * F, &L.wdown, &pd)) != RCA_OK) return bail(rc);
+            if ((rc = lm_finish_q8(h, L.wdown, pd, (int)H, (int)F, 0, &L.qdown, "down_proj")) != RCA_OK) return bail(rc);
+        }
         if ((rc = lm_upload_f32(ts, nt, p + "input_layernorm.weight", H, &L.attn_norm)) != RCA_OK) return bail(rc);
         if ((rc = lm_upload_f32(ts, nt, p + "post_attention_layernorm.weight", H, &L.ffn_norm)) != RCA_OK) return bail(rc);
     }
@@ -1301,6 +1554,17 @@ extern "C" int rca_lm_create_random(const rca_lm_config_t* cfg, uint64_t seed, f
             return bail(rc);
     }
     RCA_HIP(hipStreamSynchronize(h->stream));
+    if (c.decode_weights == 1) {   // the same hash-generated model, its projections quantised like llama-quantize q8_0 would
+        const Q8Plain none;
+        if ((rc = lm_finish_q8(h, h->head, none, (int)V, (int)H, 0, &h->qhead, "lm_head")) != RCA_OK) return bail(rc);
+        for (int l = 0; l < c.n_layers; ++l) {
+            LmLayer& L = h->layers[l];
+            if ((rc = lm_finish_q8(h, L.wqkv, none, (int)(Q + 2 * KVD), (int)H, 1, &L.qqkv, "the fused QKV projection")) != RCA_OK ||
+                (rc = lm_finish_q8(h, L.wo, none, (int)H, (int)Q, 0, &L.qo, "o_proj")) != RCA_OK ||
+                (rc = lm_finish_q8(h, L.wgu, none, (int)(2 * F), (int)H, 0, &L.qgu, "the fused gate/up projection")) != RCA_OK ||
+                (rc = lm_finish_q8(h, L.wdown, none, (int)H, (int)F, 0, &L.qdown, "down_proj")) != RCA_OK) return bail(rc);
+        }
+    }
     if ((rc = lm_common_init(h, nullptr, 0)) != RCA_OK) return bail(rc);
     *out = h;
     return RCA_OK;
@@ -1324,6 +1588,7 @@ extern "C" int rca_lm_create_shared(rca_lm_t* parent, int32_t n_ctx, int32_t log
     if ((rc = lm_new(&cfg, parent->device, &h)) != RCA_OK) return rc;
     h->embed = owner->embed;
     h->head = owner->head;
+    h->qhead = owner->qhead;
     h->final_norm = owner->final_norm;
     h->layers = owner->layers;
     h->weights_of = owner;
@@ -1340,54 +1605,72 @@ extern "C" int rca_lm_create_shared(rca_lm_t* parent, int32_t n_ctx, int32_t log
 // depend on the choice.
 struct GemvGeom { int R, bpw; };
 enum { GEMV_QKV = 0, GEMV_O, GEMV_GU, GEMV_DOWN, GEMV_HEAD, GEMV_KINDS };
-static GemvGeom gemv_geom(int kind, int N) {
-    static GemvGeom tab[GEMV_KINDS];
+static GemvGeom gemv_geom(int kind, int N, bool q8) {
+    static GemvGeom tab[2][GEMV_KINDS];
     static bool init = false;
     if (!init) {
-        const GemvGeom def[GEMV_KINDS] = {{4, 1}, {4, 1}, {16, 2}, {4, 1}, {16, 8}};
-        const char* names[GEMV_KINDS] = {"RCA_GEMV_QKV", "RCA_GEMV_O", "RCA_GEMV_GU", "RCA_GEMV_DOWN", "RCA_GEMV_HEAD"};
-        for (int k = 0; k < GEMV_KINDS; ++k) {
-            tab[k] = def[k];
-            const char* e = getenv(names[k]);
-            int r = 0, bw = 0;
-            if (e && sscanf(e, "%d,%d", &r, &bw) == 2 && (r == 4 || r == 8 || r == 16) && bw >= 1) tab[k] = {r, bw};
-        }
+        // q8_0 rows are half as long: twice the rows per batch keep the same bytes in flight
+        const GemvGeom def[2][GEMV_KINDS] = {{{4, 1}, {4, 1}, {16, 2}, {4, 1}, {16, 8}}, {{8, 1}, {8, 1}, {32, 1}, {8, 1}, {32, 4}}};
+        const char* names[2][GEMV_KINDS] = {{"RCA_GEMV_QKV", "RCA_GEMV_O", "RCA_GEMV_GU", "RCA_GEMV_DOWN", "RCA_GEMV_HEAD"},
+                                           {"RCA_GEMVQ_QKV", "RCA_GEMVQ_O", "RCA_GEMVQ_GU", "RCA_GEMVQ_DOWN", "RCA_GEMVQ_HEAD"}};
+        for (int f = 0; f < 2; ++f)
+            for (int k = 0; k < GEMV_KINDS; ++k) {
+                tab[f][k] = def[f][k];
+                const char* e = getenv(names[f][k]);
+                int r = 0, bw = 0;
+                if (e && sscanf(e, "%d,%d", &r, &bw) == 2 && (r == 4 || r == 8 || r == 16 || (f == 1 && r == 32)) && bw >= 1) tab[f][k] = {r, bw};
+            }
         init = true;
     }
-    GemvGeom g = tab[kind];
+    GemvGeom g = tab[q8 ? 1 : 0][kind];
     // small models: never fewer than ~64 workgroups while there are rows to hand out
     while (g.bpw > 1 && (N + g.R * g.bpw - 1) / (g.R * g.bpw) < 64) g.bpw >>= 1;
     return g;
 }
-template <int M, int NIT, int PRO, int EPI>
-static void launch_gemv_r(const GemvGeom& g, rca_lm* h, const bf16_t* W, const float* x, float* y, int N, int K, int ldy, const GemvPro& pro,
+template <int M, int NIT, int PRO, int EPI, int Q>
+static void launch_gemv_r(const GemvGeom& g, rca_lm* h, const bf16_t* W, const Q8Mat& q8, const float* x, float* y, int N, int K, int ldy, const GemvPro& pro,
                           const GemvRope& rope, hipStream_t st) {
     const int grid = cdiv(cdiv(N, g.R), g.bpw);
+    const GemvQ8 qa{q8.qs, q8.sc};
+    if (Q && g.R == 32) {
+        if constexpr (Q == 1) lm_gemv_kernel<M, NIT, 32, PRO, EPI, 1><<<grid, 256, 0, st>>>(h->stt, W, x, y, N, K, g.bpw, ldy, pro, rope, qa);
+        return;
+    }
     switch (g.R) {
-        case 4: lm_gemv_kernel<M, NIT, 4, PRO, EPI><<<grid, 256, 0, st>>>(h->stt, W, x, y, N, K, g.bpw, ldy, pro, rope); break;
-        case 8: lm_gemv_kernel<M, NIT, 8, PRO, EPI><<<grid, 256, 0, st>>>(h->stt, W, x, y, N, K, g.bpw, ldy, pro, rope); break;
-        default: lm_gemv_kernel<M, NIT, 16, PRO, EPI><<<grid, 256, 0, st>>>(h->stt, W, x, y, N, K, g.bpw, ldy, pro, rope); break;
+        case 4: lm_gemv_kernel<M, NIT, 4, PRO, EPI, Q><<<grid, 256, 0, st>>>(h->stt, W, x, y, N, K, g.bpw, ldy, pro, rope, qa); break;
+        case 8: lm_gemv_kernel<M, NIT, 8, PRO, EPI, Q><<<grid, 256, 0, st>>>(h->stt, W, x, y, N, K, g.bpw, ldy, pro, rope, qa); break;
+        default: lm_gemv_kernel<M, NIT, 16, PRO, EPI, Q><<<grid, 256, 0, st>>>(h->stt, W, x, y, N, K, g.bpw, ldy, pro, rope, qa); break;
     }
 }
-// M = 1 or 2 tokens.  Only the down projection (K = ffn) needs more than one chunk per lane and wave.
-template <int PRO, int EPI>
-static void launch_gemv(int kind, rca_lm* h, int M, const bf16_t* W, const float* x, float* y, int N, int K, int ldy, const GemvPro& pro,
-                        const GemvRope& rope, hipStream_t st) {
-    GemvGeom g = gemv_geom(kind, N);
+template <int PRO, int EPI, int Q>
+static void launch_gemv_q(GemvGeom g, rca_lm* h, int M, const bf16_t* W, const Q8Mat& q8, const float* x, float* y, int N, int K, int ldy, const GemvPro& pro,
+                          const GemvRope& rope, hipStream_t st) {
     const int nit = cdiv(cdiv(K >> 3, 4), 64);
-    while (g.R > 4 && g.R * (nit == 3 ? 4 : nit) > 16) g.R >>= 1;   // weights in flight per lane: at most 16 x 16 bytes (registers)
+    // 16-byte weight loads in flight per lane: at most 16 (registers); q8_0 needs one load per row PAIR
+    const int lpr = Q ? 2 : 1;
+    while (g.R > 4 && (g.R / lpr) * (nit == 3 ? 4 : nit) > 16) g.R >>= 1;
     if (PRO == 0 && EPI == 3 && nit > 1) {
         if (nit == 2) {
-            if (M == 1) launch_gemv_r<1, 2, 0, 3>(g, h, W, x, y, N, K, ldy, pro, rope, st);
-            else launch_gemv_r<2, 2, 0, 3>(g, h, W, x, y, N, K, ldy, pro, rope, st);
+            if (M == 1) launch_gemv_r<1, 2, 0, 3, Q>(g, h, W, q8, x, y, N, K, ldy, pro, rope, st);
+            else launch_gemv_r<2, 2, 0, 3, Q>(g, h, W, q8, x, y, N, K, ldy, pro, rope, st);
         } else {
-            if (M == 1) launch_gemv_r<1, 4, 0, 3>(g, h, W, x, y, N, K, ldy, pro, rope, st);
-            else launch_gemv_r<2, 4, 0, 3>(g, h, W, x, y, N, K, ldy, pro, rope, st);
+            if (M == 1) launch_gemv_r<1, 4, 0, 3, Q>(g, h, W, q8, x, y, N, K, ldy, pro, rope, st);
+            else launch_gemv_r<2, 4, 0, 3, Q>(g, h, W, q8, x, y, N, K, ldy, pro, rope, st);
         }
         return;
     }
-    if (M == 1) launch_gemv_r<1, 1, PRO, EPI>(g, h, W, x, y, N, K, ldy, pro, rope, st);
-    else launch_gemv_r<2, 1, PRO, EPI>(g, h, W, x, y, N, K, ldy, pro, rope, st);
+    if (M == 1) launch_gemv_r<1, 1, PRO, EPI, Q>(g, h, W, q8, x, y, N, K, ldy, pro, rope, st);
+    else launch_gemv_r<2, 1, PRO, EPI, Q>(g, h, W, q8, x, y, N, K, ldy, pro, rope, st);
+}
+// M = 1 or 2 tokens.  Only the down projection (K = ffn) needs more than one chunk per lane and wave.  A matrix that has a packed
+// q8_0 form streams that (half the bytes); the bf16 matrix is then only read by the prefill tiles.
+template <int PRO, int EPI>
+static void launch_gemv(int kind, rca_lm* h, int M, const bf16_t* W, const Q8Mat& q8, const float* x, float* y, int N, int K, int ldy, const GemvPro& pro,
+                        const GemvRope& rope, hipStream_t st) {
+    const bool use_q8 = q8.qs != nullptr && h->use_q8;
+    const GemvGeom g = gemv_geom(kind, N, use_q8);
+    if (use_q8) launch_gemv_q<PRO, EPI, 1>(g, h, M, W, q8, x, y, N, K, ldy, pro, rope, st);
+    else launch_gemv_q<PRO, EPI, 0>(g, h, M, W, q8, x, y, N, K, ldy, pro, rope, st);
 }
 
 // ------------------------------------------------------------------ attention on MFMA (decode steps and prefill tiles)
@@ -1668,15 +1951,15 @@ static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st, in
         f16_t* kc = h->kc + (long)l * h->kv_layer_stride;
         f16_t* vc = h->vc + (long)l * h->kv_layer_stride;
         rope.kc = kc; rope.vc = vc;
-        launch_gemv<1, 2>(GEMV_QKV, h, M, L.wqkv, nullptr, h->qkv, QKV, H, QKV, GemvPro{x, L.attn_norm, c.rms_eps, 0}, rope, st);
+        launch_gemv<1, 2>(GEMV_QKV, h, M, L.wqkv, L.qqkv, nullptr, h->qkv, QKV, H, QKV, GemvPro{x, L.attn_norm, c.rms_eps, 0}, rope, st);
         launch_attention_mfma(h, M, nsp_launch, kc, vc, st);
-        launch_gemv<0, 3>(GEMV_O, h, M, L.wo, h->attn, x, H, AO, H, nopro, norope, st);
-        launch_gemv<1, 1>(GEMV_GU, h, M, L.wgu, nullptr, h->hbuf, 2 * F, H, F, GemvPro{x, L.ffn_norm, c.rms_eps, 0}, norope, st);
-        launch_gemv<0, 3>(GEMV_DOWN, h, M, L.wdown, h->hbuf, x, H, F, H, nopro, norope, st);
+        launch_gemv<0, 3>(GEMV_O, h, M, L.wo, L.qo, h->attn, x, H, AO, H, nopro, norope, st);
+        launch_gemv<1, 1>(GEMV_GU, h, M, L.wgu, L.qgu, nullptr, h->hbuf, 2 * F, H, F, GemvPro{x, L.ffn_norm, c.rms_eps, 0}, norope, st);
+        launch_gemv<0, 3>(GEMV_DOWN, h, M, L.wdown, L.qdown, h->hbuf, x, H, F, H, nopro, norope, st);
     }
     if (want_logits) {
         const int only_last = want_logits == 1 ? 1 : 0;
-        launch_gemv<1, 0>(GEMV_HEAD, h, only_last ? 1 : M, h->head, nullptr, h->logits, c.vocab_size, H, c.vocab_size,
+        launch_gemv<1, 0>(GEMV_HEAD, h, only_last ? 1 : M, h->head, h->qhead, nullptr, h->logits, c.vocab_size, H, c.vocab_size,
                           GemvPro{x, h->final_norm, c.rms_eps, only_last}, norope, st);
     }
     RCA_LAUNCH_CHECK();
@@ -2080,7 +2363,7 @@ static int lm_eval_impl(rca_lm_t* h, const int32_t* ids, int32_t n, bool wait_la
             if (last) {   // logits of the final token: final norm + head on the register GEMV path
                 const rca_lm_config_t& c = h->cfg;
                 const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
-                launch_gemv<1, 0>(GEMV_HEAD, h, 1, h->head, nullptr, h->logits, c.vocab_size, c.hidden, c.vocab_size,
+                launch_gemv<1, 0>(GEMV_HEAD, h, 1, h->head, h->qhead, nullptr, h->logits, c.vocab_size, c.hidden, c.vocab_size,
                                   GemvPro{h->x, h->final_norm, c.rms_eps, 1}, norope, st);
                 RCA_LAUNCH_CHECK();
             }
@@ -2397,6 +2680,14 @@ extern "C" int rca_lm_set_graphs(rca_lm_t* h, int32_t enable) {
     return RCA_OK;
 }
 
+__global__ __launch_bounds__(256) void lm_q8_zero_row_scales_kernel(unsigned* __restrict__ sc, long npairs, int nblk, int row_begin, int row_end) {
+    const long total = (long)(row_end - row_begin) * nblk;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int row = row_begin + (int)(i / nblk), j = (int)(i % nblk);
+        unsigned short* half = reinterpret_cast<unsigned short*>(sc + (long)j * npairs + (row >> 1)) + (row & 1);
+        *half = 0;
+    }
+}
 __global__ __launch_bounds__(256) void lm_zero_rows_kernel(bf16_t* __restrict__ w, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) w[i] = 0;
 }
@@ -2407,6 +2698,8 @@ extern "C" int rca_lm_mask_head_rows(rca_lm_t* h, int32_t row_begin, int32_t row
     RCA_HIP(hipSetDevice(h->device));
     const long n = (long)(row_end - row_begin) * h->cfg.hidden;
     if (n > 0) lm_zero_rows_kernel<<<2048, 256, 0, h->stream>>>(h->head + (long)row_begin * h->cfg.hidden, n);
+    if (n > 0 && h->qhead.sc)   // the packed q8_0 head: a row is zero when its block scales are
+        lm_q8_zero_row_scales_kernel<<<256, 256, 0, h->stream>>>(h->qhead.sc, h->cfg.vocab_size / 2, h->cfg.hidden / 32, row_begin, row_end);
     RCA_LAUNCH_CHECK();
     RCA_HIP(hipStreamSynchronize(h->stream));
     return RCA_OK;
@@ -2496,6 +2789,22 @@ extern "C" int rca_lm_persist_codec_embeddings(rca_lm_t* h, const float* codec_e
         if (e != hipSuccess) { free_all(); return fail(RCA_ERR_HIP, "persist_codec_embeddings: %s", hipGetErrorString(e)); }
     }
     free_all();
+    return RCA_OK;
+}
+
+// test / bench knob: decode from the packed q8_0 matrices (1, default when they exist) or from their bf16(d * q) copies (0)
+extern "C" int rca_lm_set_q8_decode(rca_lm_t* h, int32_t enable) {
+    if (!h) return fail(RCA_ERR_ARG, "null");
+    { const int src = lm_settle(h); if (src != RCA_OK) return src; }
+    RCA_HIP(hipSetDevice(h->device));
+    RCA_HIP(hipStreamSynchronize(h->stream));
+    if (h->use_q8 != (enable != 0)) lm_drop_graphs(h);   // the captured steps hold the other set of kernels
+    h->use_q8 = enable != 0;
+    return RCA_OK;
+}
+extern "C" int rca_lm_has_q8(const rca_lm_t* h, int32_t* out) {
+    if (!h || !out) return fail(RCA_ERR_ARG, "null");
+    *out = h->qhead.qs != nullptr || (!h->layers.empty() && h->layers[0].qgu.qs != nullptr);
     return RCA_OK;
 }
 

@@ -6,9 +6,10 @@ This module reads such a file -- format v2/v3, little endian, architecture "llam
 `llm.load_weights` returns for a safetensors directory: an LMConfig and tensors under their Hugging Face
 names, so a GGUF path can be handed to LlamaForAlternatingCodeChannels / RealtimeAgentResources unchanged.
 
-Supported tensor types: F32, F16, BF16, Q8_0 (de-quantised on the host to f32; the device keeps bf16 weights --
-exact for F16 files converted from bf16 checkpoints, rounded to nearest-even otherwise).  K-quants (Q4_K_M ...)
-are rejected with a clear error.
+Supported tensor types: F32, F16, BF16 (the device keeps bf16 weights -- exact for F16 files converted from bf16 checkpoints,
+rounded to nearest-even otherwise) and Q8_0: the projection matrices and output.weight of a Q8_0 file are handed to the library
+as their raw 34-byte blocks (RCA_Q8_0) and stay packed in HBM for the decode step; the embedding table and anything else is
+de-quantised on the host.  K-quants (Q4_K_M ...) are rejected with a clear error.
 
 Two things convert_hf_to_gguf.py does to a Llama checkpoint are undone here:
   * q_proj / k_proj rows are permuted from the rotate-half layout to interleaved pairs (LlamaModel.permute);
@@ -102,8 +103,9 @@ def _nbytes(ttype: int, numel: int) -> int:
     raise GGUFError(f"tensor type {_TYPE_NAMES.get(ttype, ttype)} is not supported (F32, F16, BF16, Q8_0 are)")
 
 
-def read_gguf(path: str) -> Tuple[Dict[str, Any], Dict[str, np.ndarray]]:
-    """-> (metadata, tensors).  Tensors keep their GGUF names; shapes are row-major (reversed `ne`)."""
+def read_gguf(path: str, keep_q8_0: bool = False) -> Tuple[Dict[str, Any], Dict[str, np.ndarray]]:
+    """-> (metadata, tensors).  Tensors keep their GGUF names; shapes are row-major (reversed `ne`).  keep_q8_0: 2-D Q8_0 tensors
+    come back as _native.Q8Blocks (the raw 34-byte blocks) instead of being de-quantised."""
     with open(path, "rb") as f:
         if _read(f, "<I") != GGUF_MAGIC:
             raise GGUFError(f"{path}: not a GGUF file")
@@ -133,20 +135,35 @@ def read_gguf(path: str) -> Tuple[Dict[str, Any], Dict[str, np.ndarray]]:
             if base + off + nb > mm.shape[0]:
                 raise GGUFError(f"tensor '{name}' runs past the end of the file")
             raw = np.asarray(mm[base + off: base + off + nb])
+            if keep_q8_0 and ttype == GGML_Q8_0 and len(ne) == 2 and ne[0] % 32 == 0:
+                from ._native import Q8Blocks
+                tensors[name] = Q8Blocks(raw, tuple(reversed(ne)))
+                continue
             tensors[name] = _dequant(raw, ttype, numel).reshape(tuple(reversed(ne)) if ne else ())
         return meta, tensors
 
 
-def _unpermute(w: np.ndarray, n_head: int) -> np.ndarray:
-    """Inverse of convert_hf_to_gguf.py LlamaModel.permute: rows [head][hd/2][2] -> [head][2][hd/2]."""
+def _unpermute(w, n_head: int):
+    """Inverse of convert_hf_to_gguf.py LlamaModel.permute: rows [head][hd/2][2] -> [head][2][hd/2].  A Q8_0 tensor kept as blocks
+    is permuted row-wise on its raw bytes (a block never crosses a row)."""
     rows = w.shape[0]
+    if hasattr(w, "take_rows"):
+        idx = np.arange(rows).reshape(n_head, rows // n_head // 2, 2).swapaxes(1, 2).reshape(-1)
+        return w.take_rows(idx)
     return w.reshape(n_head, rows // n_head // 2, 2, *w.shape[1:]).swapaxes(1, 2).reshape(w.shape)
 
 
-def load_llama_gguf(path: str):
-    """-> (LMConfig, {HF tensor name: ndarray}, metadata) for a llama-architecture GGUF."""
+def load_llama_gguf(path: str, keep_q8_0: bool = True):
+    """-> (LMConfig, {HF tensor name: ndarray}, metadata) for a llama-architecture GGUF.  Q8_0 projection matrices and output.weight
+    stay packed (Q8Blocks): the device re-lays the blocks out and the decode step streams them as 8.5 bits per weight; everything
+    else (embedding table, norms) is de-quantised here."""
     from .llm import LMConfig, rope_inv_freq
-    meta, t = read_gguf(path)
+    meta, t = read_gguf(path, keep_q8_0=keep_q8_0)
+    for k in ("token_embd.weight",):
+        if hasattr(t.get(k), "dequantize"):
+            t[k] = t[k].dequantize()
+    if "output.weight" not in t and hasattr(t.get("token_embd.weight"), "dequantize"):
+        pass
     arch = meta.get("general.architecture", "llama")
     if arch != "llama":
         raise GGUFError(f"{path}: architecture '{arch}' is not supported (llama is)")

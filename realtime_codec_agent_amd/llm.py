@@ -189,8 +189,14 @@ class LlamaForAlternatingCodeChannels:
         random_seed: int = 0,
         init_std: float = 0.02,
         share_weights_with: Optional["LlamaForAlternatingCodeChannels"] = None,
+        weight_format: Optional[str] = None,
         **_ignored,
     ):
+        """weight_format="q8_0": every projection matrix and lm_head is quantised to GGUF Q8_0 at load (as llama-quantize writes the
+        Q8_0 file the reference deploys, prep_test_model.sh:29) and the decode step streams the packed form.  A .gguf whose tensors
+        are Q8_0 already keeps them packed without this flag."""
+        if weight_format not in (None, "bf16", "q8_0"):
+            raise ValueError(f"weight_format {weight_format!r}: 'bf16' (default) or 'q8_0'")
         self._lib = N.lib()
         self.model_path = model_path
         self.verbose = verbose
@@ -213,6 +219,7 @@ class LlamaForAlternatingCodeChannels:
             N.check(self._lib.rca_lm_create_shared(parent._h, self._n_ctx, 1 if logits_all else 0, C.byref(self._h)), "rca_lm_create_shared")
             self._weights_parent = parent   # (the library also copes with the parent being closed first)
             self._finish_init(seed)
+            self.weight_format = parent.weight_format
             return
         random_init = weights is None and (model_path is None or str(model_path).startswith("random:"))
         if weights is None and not random_init:
@@ -227,7 +234,7 @@ class LlamaForAlternatingCodeChannels:
             n_kv_heads=config.n_kv_heads, head_dim=config.head_dim, ffn=config.ffn, n_ctx=self._n_ctx, rms_eps=config.rms_eps,
             rope_theta=config.rope_theta, rope_scaling=1 if config.rope_scaling == "llama3" else 0, rope_factor=config.rope_factor,
             rope_low_freq_factor=config.rope_low_freq_factor, rope_high_freq_factor=config.rope_high_freq_factor,
-            rope_orig_ctx=config.rope_orig_ctx, logits_all=1 if logits_all else 0,
+            rope_orig_ctx=config.rope_orig_ctx, logits_all=1 if logits_all else 0, decode_weights=1 if weight_format == "q8_0" else 0,
         )
         self._h = C.c_void_p()
         if random_init:
@@ -243,6 +250,9 @@ class LlamaForAlternatingCodeChannels:
                 self.persist_codec_embeddings({k[len(CODEC_PREFIX):]: v for k, v in weights.items() if k.startswith(CODEC_PREFIX)},
                                               int(weights["codec.vocab_start"]), int(weights.get("codec.codebook_size", 0)) or None)
         self._finish_init(seed)
+        has = C.c_int32()
+        N.check(self._lib.rca_lm_has_q8(self._h, C.byref(has)), "rca_lm_has_q8")
+        self.weight_format = "q8_0" if has.value else "bf16"
 
     def _finish_init(self, seed: int) -> None:
         self._ctx = _Ctx(self)
@@ -537,6 +547,15 @@ class LlamaForAlternatingCodeChannels:
         """Long evals on bf16 MFMA tiles (default) or on the exact path (the decode GEMV kernels, two tokens per pass)."""
         N.check(self._lib.rca_lm_set_mfma_prefill(self._h, 1 if enable else 0), "rca_lm_set_mfma_prefill")
         self._mfma_prefill = bool(enable)
+
+    def set_q8_decode(self, enable: bool) -> None:
+        """Decode from the packed q8_0 matrices (default when the handle has them) or from their bf16(d*q) copies."""
+        N.check(self._lib.rca_lm_set_q8_decode(self._h, 1 if enable else 0), "rca_lm_set_q8_decode")
+
+    def weight_bytes_per_step(self) -> int:
+        """bytes of weights one decode step streams in the format this handle decodes from"""
+        b = self.config.weight_bytes_per_step()
+        return b * 34 // 64 if self.weight_format == "q8_0" else b
 
     def set_graphs(self, enable: bool) -> None:
         N.check(self._lib.rca_lm_set_graphs(self._h, 1 if enable else 0), "rca_lm_set_graphs")

@@ -8,7 +8,8 @@ ctx = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 eager = len(sys.argv) > 3 and sys.argv[3] == "eager"
 cfg = LMConfig.llama_3_2_1b()
-llm = LlamaForAlternatingCodeChannels(model_path="random:1b", config=cfg, n_ctx=16384, device=0)
+fmt = os.environ.get("RCA_LM_FORMAT")   # "q8_0": decode from packed q8_0 weights
+llm = LlamaForAlternatingCodeChannels(model_path="random:1b", config=cfg, n_ctx=16384, device=0, weight_format=fmt)
 llm.init_sampler_for_generate(top_k=100, top_p=1.0, min_p=0.0, temp=1.0, seed=42)
 rng = np.random.default_rng(0)
 ids = rng.integers(128266, 259338, ctx + 2).tolist()
@@ -20,5 +21,5 @@ llm.sync(); t0 = time.perf_counter()
 for _ in range(steps):
     llm.n_tokens = ctx; llm.step(ids[ctx:ctx + 2])
 llm.sync(); dt = (time.perf_counter() - t0) / steps
-wb = cfg.weight_bytes_per_step(); kv = 2 * 2 * cfg.n_layers * cfg.n_kv_heads * cfg.head_dim * ctx
-print(f"ctx={ctx} mode={'eager' if eager else 'graph'} step_ms={dt*1e3:.3f} GB/s={(wb+kv)/dt/1e9:.0f} prefill_s={t_prefill:.3f} ({ctx/t_prefill:.0f} tok/s)")
+wb = llm.weight_bytes_per_step(); kv = 2 * 2 * cfg.n_layers * cfg.n_kv_heads * cfg.head_dim * ctx
+print(f"fmt={llm.weight_format} ctx={ctx} mode={'eager' if eager else 'graph'} step_ms={dt*1e3:.3f} GB/s={(wb+kv)/dt/1e9:.0f} prefill_s={t_prefill:.3f} ({ctx/t_prefill:.0f} tok/s)")

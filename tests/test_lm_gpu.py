@@ -345,6 +345,73 @@ def test_mid_size_random_init_matches_oracle():
     assert got.argmax() == want.argmax()
 
 
+def test_q8_0_decode_matches_oracle_over_the_dequantised_model():
+    """packed q8_0 weights.  weight_format='q8_0' quantises every projection and lm_head on the device with llama.cpp's rule
+    and the decode GEMVs stream the packed blocks (8.5 bits / weight).  Against LMRef over the SAME blocks de-quantised on the host
+    (oracle/q8_ref.py): logits within the f32 summation-order tolerance; argmax equal; graph == eager; the bf16(d*q) copy used by
+    the prefill tiles agrees within bf16 rounding; masked head rows read exactly zero."""
+    from oracle import q8_ref
+    from realtime_codec_agent_amd.llm import LlamaForAlternatingCodeChannels, LMConfig
+    cfg = LMConfig(vocab_size=8192, hidden=512, n_layers=4, n_heads=8, n_kv_heads=2, head_dim=64, ffn=4096)
+    llm = LlamaForAlternatingCodeChannels(model_path="random:mid", config=cfg, n_ctx=1024, random_seed=11, init_std=0.05, device=0, weight_format="q8_0")
+    assert llm.weight_format == "q8_0" and llm.weight_bytes_per_step() < 0.54 * cfg.weight_bytes_per_step()
+    llm.set_mfma_prefill(False)
+    ref = lm_ref.LMRef(cfg, q8_ref.quantized_model(lm_ref.random_weights(cfg, 11, 0.05)), kv_dtype=torch.float16)
+    ids = np.random.default_rng(0).integers(0, 8192, 41)
+    llm.eval(ids[:39].tolist())
+    ref.eval(ids[:39])
+    llm.eval(ids[39:41].tolist())
+    got = llm._scores[-1].copy()
+    want = ref.eval(ids[39:41])[-1].numpy()
+    d = np.abs(got - want).max()
+    print(f"q8_0 decode vs LMRef over the de-quantised blocks: max|dlogit| = {d:.3e} (|logit| max {np.abs(want).max():.2f})")
+    assert d < 1e-3 * max(1.0, np.abs(want).max()) and got.argmax() == want.argmax()
+    # graph step == eager step on the packed weights
+    llm.init_sampler_for_generate(top_k=50, top_p=1.0, min_p=0.0, temp=1.0, seed=3)
+    llm.n_tokens = 39
+    t_graph = llm.step(ids[39:41].tolist())
+    assert np.array_equal(llm._scores[-1], got) and t_graph == lm_ref.sample(got, 50, 1.0, 0.0, 1.0, 3, 0)
+    # the bf16(d*q) matrices (prefill tiles read these): same model up to bf16 rounding of the products
+    llm.set_q8_decode(False)
+    llm.n_tokens = 39
+    llm.eval(ids[39:41].tolist())
+    d2 = np.abs(llm._scores[-1] - got).max()
+    print(f"bf16(d*q) copy vs packed q8_0: max|dlogit| = {d2:.3e}")
+    assert 0 < d2 < 3e-2 * max(1.0, np.abs(want).max())
+    llm.set_q8_decode(True)
+    llm.mask_head_rows(0, 100)
+    llm.n_tokens = 39
+    llm.eval(ids[39:41].tolist())
+    assert np.all(llm._scores[-1][:100] == 0) and np.array_equal(llm._scores[-1][100:], got[100:])
+
+
+def test_q8_0_gguf_blocks_stay_packed_and_match_their_dequantisation(tmp_path):
+    """A Q8_0 GGUF (what prep_test_model.sh:29 produces) through model_path=: the 34-byte blocks of the projection matrices go to the
+    device as they are (RCA_Q8_0), are re-laid-out there and streamed packed; logits equal LMRef over the file's own blocks
+    de-quantised on the host, within the f32 summation-order tolerance."""
+    import gguf_writer as gw
+    from realtime_codec_agent_amd.gguf import load_llama_gguf
+    from realtime_codec_agent_amd.llm import LlamaForAlternatingCodeChannels, bf16_bits_to_f32
+    cfg = tiny_cfg("default")
+    w, ids = tiny_weights()
+    wf = {k: (bf16_bits_to_f32(v) if v.dtype == np.uint16 else v.astype(np.float32)) for k, v in w.items()}
+    path = str(tmp_path / "tiny-q8.gguf")
+    gw.write_llama_gguf(path, cfg, wf, matrix_type=gw.Q8_0)
+    g = LlamaForAlternatingCodeChannels(model_path=path, n_ctx=512, device=0)
+    assert g.weight_format == "q8_0"
+    g.set_mfma_prefill(False)
+    _, file_w, _ = load_llama_gguf(path)
+    deq = {k: (v.dequantize() if hasattr(v, "dequantize") else v) for k, v in file_w.items() if k != "rope.inv_freq"}
+    from realtime_codec_agent_amd.llm import f32_to_bf16_bits
+    deq["model.embed_tokens.weight"] = bf16_bits_to_f32(f32_to_bf16_bits(deq["model.embed_tokens.weight"]))   # the device table is bf16
+    ref = lm_ref.LMRef(cfg, deq, kv_dtype=torch.float16)
+    g.eval(ids.tolist())
+    want = ref.eval(ids)[-1].numpy()
+    d = np.abs(g._scores[-1] - want).max()
+    print(f"Q8_0 GGUF, packed decode vs LMRef over the file's blocks: max|dlogit| = {d:.3e}")
+    assert d < TOL_ORACLE and g._scores[-1].argmax() == want.argmax()
+
+
 def test_full_size_1b_properties():
     """BASELINE config 3 dims (Llama-3.2-1B, V=259344) with random-init weights: checks that do not
     need a CPU forward -- graph replay == eager, prefill == incremental, rollback, determinism."""
