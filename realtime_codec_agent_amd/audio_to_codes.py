@@ -42,10 +42,39 @@ import numpy as np
 from .dist_utils import env_rank_world, init_dist, max_over_ranks, shard_by_duration, sum_over_ranks
 
 AUDIO_EXTS = (".wav", ".npy")
+# The reference's corpora are mp3 (tools/sph_to_mp3.py:28-41) and codec_bpe reads them through librosa / soundfile.  Neither is part
+# of this image; when one of them is importable these extensions are picked up too, otherwise such files are reported and skipped.
+COMPRESSED_EXTS = (".mp3", ".flac", ".ogg", ".m4a")
+
+
+def _compressed_reader():
+    try:
+        import soundfile as sf
+
+        def rd(path):
+            a, sr = sf.read(path, dtype="float32", always_2d=True)
+            return sr, np.ascontiguousarray(a.T)
+        return rd
+    except Exception:
+        pass
+    try:
+        import librosa
+
+        def rd(path):
+            a, sr = librosa.load(path, sr=None, mono=False)
+            return sr, np.atleast_2d(a).astype(np.float32)
+        return rd
+    except Exception:
+        return None
 
 
 def read_audio(path: str) -> Tuple[int, np.ndarray]:
     """-> (sample_rate, float32 [C,N])."""
+    if path.lower().endswith(COMPRESSED_EXTS):
+        rd = _compressed_reader()
+        if rd is None:
+            raise RuntimeError(f"{path}: decoding compressed audio needs soundfile or librosa, neither is installed")
+        return rd(path)
     if path.endswith(".npy"):
         a = np.load(path)
         sr = 16000
@@ -66,6 +95,9 @@ def read_audio(path: str) -> Tuple[int, np.ndarray]:
 
 
 def probe_duration(path: str) -> float:
+    if path.lower().endswith(COMPRESSED_EXTS):
+        sr, a = read_audio(path)
+        return a.shape[-1] / float(sr)
     if path.endswith(".npy"):
         a = np.load(path, mmap_mode="r")
         return a.shape[-1] / 16000.0
@@ -74,12 +106,19 @@ def probe_duration(path: str) -> float:
 
 
 def list_audio_files(audio_path: str, audio_filter: Optional[Sequence[str]]) -> List[str]:
-    out = []
+    out, skipped = [], 0
+    exts = AUDIO_EXTS + (COMPRESSED_EXTS if _compressed_reader() is not None else ())
     for root, _, files in os.walk(audio_path):
         for f in sorted(files):
             p = os.path.join(root, f)
-            if f.lower().endswith(AUDIO_EXTS) and (not audio_filter or any(s in p for s in audio_filter)):
+            if audio_filter and not any(s in p for s in audio_filter):
+                continue
+            if f.lower().endswith(exts):
                 out.append(p)
+            elif f.lower().endswith(COMPRESSED_EXTS):
+                skipped += 1
+    if skipped:
+        print(f"audio_to_codes: {skipped} compressed file(s) skipped (no soundfile / librosa in this environment)", file=sys.stderr)
     return sorted(out)
 
 

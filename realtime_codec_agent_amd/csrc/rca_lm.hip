@@ -291,12 +291,26 @@ __device__ __forceinline__ void wave_reduce_transposed(float (&val)[V]) {
 // (fp16, fp16) so a lane fetches the scales of a whole batch with one or two vector loads.  Arithmetic per lane and row:
 // p = fma chain of (float)q_j * x_j over its 8 elements, then d * p accumulated per chunk -- f32 activations throughout
 // (llama.cpp quantises the activations to q8_1 for this product; here only the weights are quantised).
+// (float)(int8) of byte `b` of a dword.  The dword must have passed through q8_opaque() first:
+//   * if the optimiser can see that a loaded 16-byte value is only ever used byte by byte, it re-types the LOAD as sixteen byte
+//     values and unpacks them the moment it lands -- 4x the registers and nothing left in flight;
+//   * __builtin_amdgcn_sbfe + cast makes this compiler (ROCm 7.2) emit v_cvt_f32_u32_sdwa sext(...): the UNSIGNED conversion of
+//     the sign-extended byte (4.29e9 for -1).
+// Behind the opaque copy the plain shift / mask / cast form selects v_cvt_f32_i32_sdwa sext(BYTE_n): one instruction per element.
+__device__ __forceinline__ unsigned q8_opaque(unsigned w) {
+    asm volatile("" : "+v"(w));
+    return w;
+}
+__device__ __forceinline__ float q8_byte_to_f32(unsigned w, int b) { return (float)(signed char)((w >> (8 * b)) & 0xffu); }
 struct GemvQ8 {
     const u32x4* qs;      // [N / 2][K / 8] 16-byte units
     const unsigned* sc;   // [K / 32][N / 2]
 };
+// minimum waves per SIMD asked of the register allocator.  The q8_0 bodies otherwise spread over 200+ registers (one wave per
+// SIMD) although their live set is ~130: a streaming kernel wants the occupancy.
+constexpr int gemv_min_waves(int Q, int R, int NIT) { return !Q ? 1 : (R * NIT >= 32 ? 2 : (R * NIT >= 16 ? 2 : 4)); }
 template <int M, int NIT, int R, int PRO, int EPI, int Q = 0>
-__global__ __launch_bounds__(256) void lm_gemv_kernel(const LmDevState* __restrict__ stt, const bf16_t* __restrict__ W,
+__global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel(const LmDevState* __restrict__ stt, const bf16_t* __restrict__ W,
                                                       const float* __restrict__ x, float* __restrict__ y, int N, int K,
                                                       int batches_per_wg, int ldy, GemvPro pro, GemvRope rope, GemvQ8 q8 = GemvQ8{nullptr, nullptr}) {
     constexpr int V = R * M;
@@ -449,16 +463,14 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const LmDevState* __restri
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     const u32x4 a = wq[s2][it];
-                    const unsigned wa[2] = {a.x, a.y}, wb[2] = {a.z, a.w};
+                    const unsigned wa[2] = {q8_opaque(a.x), q8_opaque(a.y)}, wb[2] = {q8_opaque(a.z), q8_opaque(a.w)};
                     float pa[M], pb[M];
 #pragma unroll
                     for (int m = 0; m < M; ++m) pa[m] = pb[m] = 0.0f;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        // signed byte j as a target bit-field extract: written with shifts and masks the optimiser turns the whole
-                        // 16-byte load into sixteen byte values unpacked the moment it lands (4x the registers, no loads in flight)
-                        const float fa = (float)__builtin_amdgcn_sbfe((int)wa[j >> 2], 8 * (j & 3), 8);
-                        const float fb = (float)__builtin_amdgcn_sbfe((int)wb[j >> 2], 8 * (j & 3), 8);
+                        const float fa = q8_byte_to_f32(wa[j >> 2], j & 3);
+                        const float fb = q8_byte_to_f32(wb[j >> 2], j & 3);
 #pragma unroll
                         for (int m = 0; m < M; ++m) {
                             pa[m] = __builtin_fmaf(fa, xr[m][it][j], pa[m]);
@@ -1853,45 +1865,72 @@ __global__ __launch_bounds__(512) void lm_attn_mfma_kernel(const LmDevState* __r
         if (d == 0) { pout[r * 66] = m2; pout[r * 66 + 1] = L; }
     }
 }
-// merges the splits of lm_attn_mfma_kernel in split order: one wave per (token, head), lane <-> dim
+// merges the splits of lm_attn_mfma_kernel in split order: one wave per (token, head), lane <-> dim.
+// Latency kernel: every load it will ever need is issued in the first instructions -- the (m, l) pair of split `lane` and this lane's
+// output element of up to CMB_PRE splits -- and none of them depends on the step state (the bound is the number of splits the
+// attention kernel was LAUNCHED with; a split beyond the visible context carries m = -inf and weighs 0, its o is never used), so
+// the kernel is one memory round trip deep instead of one per group of splits.  Same arithmetic and order as before.
+#define CMB_PRE 32
 template <int G>
 __global__ __launch_bounds__(64) void lm_attn_mfma_combine_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ part,
-                                                                  float* __restrict__ attn, int nh, int nkv, int n_splits,
+                                                                  float* __restrict__ attn, int nh, int nkv, int n_splits, int nsp_launch,
                                                                   bf16_t* __restrict__ hi = nullptr, bf16_t* __restrict__ lo = nullptr) {
     constexpr int TPB = 32 / G;
     const int m = blockIdx.x / nh, head = blockIdx.x % nh;
-    if (m >= stt->m) return;
     const int g = head / G, hq = head % G;
     const int qb = m / TPB, tl = m % TPB;
     const int r = tl * G + hq;
     const int d = threadIdx.x;
-    const int nsp = min(n_splits, (stt->n_tokens + m) / ATT_KEYS + 1);
     const float* base = part + ((long)(qb * nkv + g) * n_splits) * 32 * 66 + r * 66;
     const long sstride = 32L * 66;
+    const int nsp = min(nsp_launch, n_splits);
+    float pv[CMB_PRE];
+#pragma unroll
+    for (int j = 0; j < CMB_PRE; ++j) pv[j] = base[(long)min(j, nsp - 1) * sstride + 2 + d];
     float mx = -INFINITY;
-    for (int s0 = 0; s0 < nsp; s0 += 64) {
+    float ml0 = -INFINITY, ll0 = 0.0f;
+    {
+        const int sp = min(d, nsp - 1);
+        ml0 = base[sp * sstride];
+        ll0 = base[sp * sstride + 1];
+        if (d >= nsp) { ml0 = -INFINITY; ll0 = 0.0f; }
+        mx = ml0;
+    }
+    for (int s0 = 64; s0 < nsp; s0 += 64) {   // more than 64 splits (contexts beyond 16 k): the rare, slower tail
         const int sp = s0 + d;
         mx = fmaxf(mx, sp < nsp ? base[sp * sstride] : -INFINITY);
     }
+    if (m >= stt->m) return;
     mx = wave_max(mx);
     float L = 0.0f, O = 0.0f;
-    for (int s0 = 0; s0 < nsp; s0 += 64) {
+    {
+        const float fl = (ml0 == -INFINITY) ? 0.0f : __expf(ml0 - mx);
+        const int cnt = min(64, nsp);
+#pragma unroll
+        for (int j = 0; j < CMB_PRE; ++j) {
+            if (j < cnt) {
+                const float f = __shfl(fl, j), l = __shfl(ll0, j);
+                L = __builtin_fmaf(l, f, L);
+                O = __builtin_fmaf(f == 0.0f ? 0.0f : pv[j], f, O);
+            }
+        }
+        for (int j = CMB_PRE; j < cnt; ++j) {
+            const float f = __shfl(fl, j), l = __shfl(ll0, j);
+            const float p = base[(long)j * sstride + 2 + d];
+            L = __builtin_fmaf(l, f, L);
+            O = __builtin_fmaf(f == 0.0f ? 0.0f : p, f, O);
+        }
+    }
+    for (int s0 = 64; s0 < nsp; s0 += 64) {
         const int spl = min(s0 + d, nsp - 1);
         const float ml = base[spl * sstride], ll = base[spl * sstride + 1];
         const float fl = (ml == -INFINITY) ? 0.0f : __expf(ml - mx);
         const int cnt = min(64, nsp - s0);
-        for (int j0 = 0; j0 < cnt; j0 += 4) {
-            float pv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pv[j] = base[(s0 + min(j0 + j, cnt - 1)) * sstride + 2 + d];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j0 + j < cnt) {
-                    const float f = __shfl(fl, j0 + j), l = __shfl(ll, j0 + j);
-                    L = __builtin_fmaf(l, f, L);
-                    O = __builtin_fmaf(pv[j], f, O);
-                }
-            }
+        for (int j = 0; j < cnt; ++j) {
+            const float f = __shfl(fl, j), l = __shfl(ll, j);
+            const float p = base[(long)(s0 + j) * sstride + 2 + d];
+            L = __builtin_fmaf(l, f, L);
+            O = __builtin_fmaf(f == 0.0f ? 0.0f : p, f, O);
         }
     }
     const float ov = O / L;
@@ -1920,13 +1959,13 @@ static void launch_attention_mfma(rca_lm* h, int M, int nsp_launch, const f16_t*
     }
     if (G == 4) {
         lm_attn_mfma_kernel<4><<<agm, 512, ATTM_LDS, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
-        lm_attn_mfma_combine_kernel<4><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits, hi, lo);
+        lm_attn_mfma_combine_kernel<4><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits, nsp_launch, hi, lo);
     } else if (G == 2) {
         lm_attn_mfma_kernel<2><<<agm, 512, ATTM_LDS, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
-        lm_attn_mfma_combine_kernel<2><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits, hi, lo);
+        lm_attn_mfma_combine_kernel<2><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits, nsp_launch, hi, lo);
     } else {
         lm_attn_mfma_kernel<1><<<agm, 512, ATTM_LDS, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
-        lm_attn_mfma_combine_kernel<1><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits, hi, lo);
+        lm_attn_mfma_combine_kernel<1><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits, nsp_launch, hi, lo);
     }
 }
 
