@@ -308,7 +308,7 @@ struct GemvQ8 {
 };
 // minimum waves per SIMD asked of the register allocator.  The q8_0 bodies otherwise spread over 200+ registers (one wave per
 // SIMD) although their live set is ~130: a streaming kernel wants the occupancy.
-constexpr int gemv_min_waves(int Q, int R, int NIT) { return !Q ? 1 : (R * NIT >= 32 ? 2 : (R * NIT >= 16 ? 2 : 4)); }
+constexpr int gemv_min_waves(int Q, int R, int NIT) { return !Q ? 1 : (R * NIT >= 16 ? 2 : 4); }
 template <int M, int NIT, int R, int PRO, int EPI, int Q = 0>
 __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel(const LmDevState* __restrict__ stt, const bf16_t* __restrict__ W,
                                                       const float* __restrict__ x, float* __restrict__ y, int N, int K,
@@ -1621,8 +1621,8 @@ static GemvGeom gemv_geom(int kind, int N, bool q8) {
     static GemvGeom tab[2][GEMV_KINDS];
     static bool init = false;
     if (!init) {
-        // q8_0 rows are half as long: twice the rows per batch keep the same bytes in flight
-        const GemvGeom def[2][GEMV_KINDS] = {{{4, 1}, {4, 1}, {16, 2}, {4, 1}, {16, 8}}, {{8, 1}, {8, 1}, {32, 1}, {8, 1}, {32, 4}}};
+        // measured (scripts/lm_gemv_sweep.sh, profiles/r02): the same geometry serves both formats; a q8_0 batch of R rows is R / 2 loads
+        const GemvGeom def[2][GEMV_KINDS] = {{{4, 1}, {4, 1}, {16, 2}, {4, 1}, {16, 8}}, {{4, 1}, {4, 1}, {16, 2}, {4, 1}, {16, 8}}};
         const char* names[2][GEMV_KINDS] = {{"RCA_GEMV_QKV", "RCA_GEMV_O", "RCA_GEMV_GU", "RCA_GEMV_DOWN", "RCA_GEMV_HEAD"},
                                            {"RCA_GEMVQ_QKV", "RCA_GEMVQ_O", "RCA_GEMVQ_GU", "RCA_GEMVQ_DOWN", "RCA_GEMVQ_HEAD"}};
         for (int f = 0; f < 2; ++f)
@@ -1630,7 +1630,7 @@ static GemvGeom gemv_geom(int kind, int N, bool q8) {
                 tab[f][k] = def[f][k];
                 const char* e = getenv(names[f][k]);
                 int r = 0, bw = 0;
-                if (e && sscanf(e, "%d,%d", &r, &bw) == 2 && (r == 4 || r == 8 || r == 16 || (f == 1 && r == 32)) && bw >= 1) tab[f][k] = {r, bw};
+                if (e && sscanf(e, "%d,%d", &r, &bw) == 2 && (r == 4 || r == 8 || r == 16) && bw >= 1) tab[f][k] = {r, bw};
             }
         init = true;
     }
@@ -1644,10 +1644,6 @@ static void launch_gemv_r(const GemvGeom& g, rca_lm* h, const bf16_t* W, const Q
                           const GemvRope& rope, hipStream_t st) {
     const int grid = cdiv(cdiv(N, g.R), g.bpw);
     const GemvQ8 qa{q8.qs, q8.sc};
-    if (Q && g.R == 32) {
-        if constexpr (Q == 1) lm_gemv_kernel<M, NIT, 32, PRO, EPI, 1><<<grid, 256, 0, st>>>(h->stt, W, x, y, N, K, g.bpw, ldy, pro, rope, qa);
-        return;
-    }
     switch (g.R) {
         case 4: lm_gemv_kernel<M, NIT, 4, PRO, EPI, Q><<<grid, 256, 0, st>>>(h->stt, W, x, y, N, K, g.bpw, ldy, pro, rope, qa); break;
         case 8: lm_gemv_kernel<M, NIT, 8, PRO, EPI, Q><<<grid, 256, 0, st>>>(h->stt, W, x, y, N, K, g.bpw, ldy, pro, rope, qa); break;

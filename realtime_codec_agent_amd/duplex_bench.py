@@ -21,7 +21,7 @@ def synth_signal(n: int, seed: int = 0) -> np.ndarray:
 
 
 def run_duplex_bench(dev=None, secs: float = 125.0, chunk_size_secs: float = 0.08, n_ctx: int = 16384, lm_steps_probe: int = 64,
-                     max_context_secs: float = 80.0, trim_by_secs: float = 20.0) -> dict:
+                     max_context_secs: float = 80.0, trim_by_secs: float = 20.0, weight_format=None) -> dict:
     import torch
     from .llm import LMConfig
     from .realtime_agent_config import RealtimeAgentConfig
@@ -30,7 +30,8 @@ def run_duplex_bench(dev=None, secs: float = 125.0, chunk_size_secs: float = 0.0
 
     cfg = LMConfig.llama_3_2_1b()
     t0 = time.perf_counter()
-    res = RealtimeAgentResources(llm_model_path="random:Llama-3.2-1B-codec", llm_n_ctx=n_ctx, llm_config=cfg, with_aux_llm=False)
+    res = RealtimeAgentResources(llm_model_path="random:Llama-3.2-1B-codec", llm_n_ctx=n_ctx, llm_config=cfg, with_aux_llm=False,
+                                 llm_weight_format=weight_format)
     config = RealtimeAgentConfig(chunk_size_secs=chunk_size_secs, use_whisper=False, top_k=100, temperature=1.0, seed=42,
                                  max_context_secs=max_context_secs, trim_by_secs=trim_by_secs,
                                  force_trans_after_inactivity_secs=0.0, force_response_after_inactivity_secs=0.0)
@@ -70,12 +71,12 @@ def run_duplex_bench(dev=None, secs: float = 125.0, chunk_size_secs: float = 0.0
         llm.step(toks)
     llm.sync()
     lm_ms = (time.perf_counter() - t2) * 1e3 / lm_steps_probe
-    wbytes = cfg.weight_bytes_per_step()
+    wbytes = llm.weight_bytes_per_step()
     kv_bytes = 2 * 2 * cfg.n_layers * cfg.n_kv_heads * cfg.head_dim * n0
     gbs = (wbytes + kv_bytes) / (lm_ms * 1e-3) / 1e9
     out_ids_ok = all(t > agent.end_header_token_id for t in agent.input_ids[-8:])
     return {
-        "workload": f"1 duplex stream, Llama-3.2-1B dims (V={cfg.vocab_size}) random-init bf16, {int(chunk_size_secs * 1000)} ms frames, "
+        "workload": f"1 duplex stream, Llama-3.2-1B dims (V={cfg.vocab_size}) random-init {llm.weight_format}, {int(chunk_size_secs * 1000)} ms frames, "
                     f"top_k=100 T=1.0 seed=42, {secs:.0f} s of audio, context {max_context_secs:.0f} s trimmed by {trim_by_secs:.0f} s",
         "xRT": summ["total"]["xrt_median"],
         "xRT_wall": nchunks * chunk_size_secs / wall,
@@ -101,7 +102,8 @@ def run_duplex_bench(dev=None, secs: float = 125.0, chunk_size_secs: float = 0.0
             "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
             "bytes_per_step": wbytes + kv_bytes, "weight_bytes_per_step": wbytes, "kv_bytes_per_step": kv_bytes, "ms_per_step": lm_ms,
             "context_tokens": n0, "floor_ms_at_peak": (wbytes + kv_bytes) / (HBM_PEAK_GBS * 1e9) * 1e3,
-            "note": "algorithmic bytes = every bf16 weight once + the fp16 KV of the live context; timed as wall time over "
+            "weight_format": llm.weight_format,
+            "note": "algorithmic bytes = every weight once in the format the step streams (bf16: 2 B, q8_0: 34 B per 32) + the fp16 KV of the live context; timed as wall time over "
                     f"{lm_steps_probe} replays incl. the host round trip of the sampled token",
         },
     }

@@ -29,10 +29,11 @@ class RealtimeAgentResources:
         with_aux_llm: bool = True,
         llm_random_seed: int = 0,
         share_llm_weights_with: Optional[LlamaForAlternatingCodeChannels] = None,
+        llm_weight_format: Optional[str] = None,
     ):
         self.llm_model_dir = os.path.dirname(llm_model_path) if not llm_model_path.startswith("random:") else ""
         kw = dict(model_path=llm_model_path, n_ctx=llm_n_ctx, n_gpu_layers=-1, verbose=False, flash_attn=True,
-                  config=llm_config, random_seed=llm_random_seed)
+                  config=llm_config, random_seed=llm_random_seed, weight_format=llm_weight_format)
         if share_llm_weights_with is not None:   # clone_for_self_play: a fresh model state over the weights already on the device
             self.llm = LlamaForAlternatingCodeChannels(model_path=llm_model_path, n_ctx=llm_n_ctx, share_weights_with=share_llm_weights_with)
         else:

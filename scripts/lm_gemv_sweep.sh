@@ -17,9 +17,4 @@ run() {
   rm -rf $OUT/*/*kernel_trace.csv
 }
 run base
-run A RCA_GEMV_GU=8,2 RCA_GEMV_HEAD=16,4
-run B RCA_GEMV_GU=8,4 RCA_GEMV_QKV=4,2 RCA_GEMV_O=4,2
 run q8 RCA_LM_FORMAT=q8_0
-run q8A RCA_LM_FORMAT=q8_0 RCA_GEMVQ_GU=16,2 RCA_GEMVQ_HEAD=16,8 RCA_GEMVQ_QKV=4,1 RCA_GEMVQ_O=4,1 RCA_GEMVQ_DOWN=4,1
-run q8B RCA_LM_FORMAT=q8_0 RCA_GEMVQ_GU=32,2 RCA_GEMVQ_HEAD=32,8 RCA_GEMVQ_QKV=16,1 RCA_GEMVQ_O=16,1
-run q8C RCA_LM_FORMAT=q8_0 RCA_GEMVQ_GU=16,4 RCA_GEMVQ_HEAD=16,16 RCA_GEMVQ_QKV=8,2 RCA_GEMVQ_O=8,2 RCA_GEMVQ_DOWN=4,2
