@@ -47,6 +47,7 @@ def pmc(sub):
 
 stats("bench")
 stats("lm")
+stats("lm_q8")
 sq = pmc("pmc_sq")
 if sq:
     print("== pmc_sq: per-dispatch averages (profiled run; SQ_* are per-XCD sums, quad-cycles for WAVE/WAIT)")
