@@ -323,6 +323,9 @@ int rca_lm_set_mfma_prefill(rca_lm_t* h, int32_t enable);
  * the handle holds packed matrices */
 int rca_lm_set_q8_decode(rca_lm_t* h, int32_t enable);
 int rca_lm_has_q8(const rca_lm_t* h, int32_t* out);
+/* decode steps merge the attention splits inside the attention launch (1, default: the workgroup that publishes its partial last
+ * merges them; bit-identical to the separate merge launch) or in a launch of its own (0); tests compare the two */
+int rca_lm_set_attn_fuse(rca_lm_t* h, int32_t enable);
 /* synchronise the handle's stream (timing) */
 int rca_lm_sync(rca_lm_t* h);
 int rca_codec_sync(rca_codec_t* h);

@@ -147,7 +147,7 @@ ABI_SYMBOLS = [
     "rca_lm_logits_dev", "rca_lm_sampler_init", "rca_lm_sample", "rca_lm_step", "rca_lm_token_probs",
     "rca_lm_sync", "rca_lm_set_graphs", "rca_lm_mask_head_rows", "rca_lm_set_mfma_prefill", "rca_lm_set_logits_all",
     "rca_lm_persist_codec_embeddings", "rca_lm_create_shared", "rca_lm_eval_async", "rca_lm_copy_kv", "rca_lm_swap_kv",
-    "rca_lm_set_low_priority", "rca_lm_frame", "rca_lm_set_q8_decode", "rca_lm_has_q8",
+    "rca_lm_set_low_priority", "rca_lm_frame", "rca_lm_set_q8_decode", "rca_lm_has_q8", "rca_lm_set_attn_fuse",
 ]
 
 

@@ -1149,6 +1149,7 @@ struct rca_lm {
     float *x = nullptr, *xn = nullptr, *qkv = nullptr, *attn = nullptr, *hbuf = nullptr,
           *att_part = nullptr, *logits = nullptr, *probs_dev = nullptr;
     int* probe_ids_dev = nullptr;
+    int* att_arrive = nullptr;   // per kv head: workgroups of the current attention launch that have published their partial
     bf16_t *xh = nullptr, *xl = nullptr;   // prefill: bf16 hi / lo split of the current GEMM input [LM_MAXM][max K]
     float* gpart = nullptr;                // prefill: k-split partial sums of the narrow projections [8][LM_MAXM][hidden]
     long logits_rows_cap = 0;   // rows allocated in `logits` (1, or more when logits_all)
@@ -1171,6 +1172,7 @@ struct rca_lm {
     unsigned long long rng_host = 0;   // host mirror of the device's draw counter (restored when a frame graph is cut short)
     bool graphs_enabled = true;
     bool mfma_prefill = true;   // evals longer than LM_PREFILL_MIN tokens use the bf16 MFMA tiles
+    bool fuse_attn = true;      // decode steps merge the attention splits inside the attention launch (rca_lm_set_attn_fuse)
     bool use_q8 = true;         // stream the packed q8_0 form of a matrix when it has one (rca_lm_set_q8_decode: tests compare with the bf16(d*q) copy)
     // weight sharing (rca_lm_create_shared): a borrower points at the handle that owns the weights and the RoPE tables; an owner
     // destroyed while borrowers are alive keeps those allocations (and its struct) until the last borrower is gone
@@ -1232,12 +1234,12 @@ extern "C" int rca_lm_destroy(rca_lm_t* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     lm_drop_graphs(h);
     for (void* p : {(void*)h->kc, (void*)h->vc, (void*)h->x, (void*)h->xn, (void*)h->qkv, (void*)h->attn, (void*)h->hbuf,
-                    (void*)h->att_part, (void*)h->logits, (void*)h->probs_dev, (void*)h->probe_ids_dev, (void*)h->xh, (void*)h->xl,
+                    (void*)h->att_part, (void*)h->logits, (void*)h->probs_dev, (void*)h->probe_ids_dev, (void*)h->att_arrive, (void*)h->xh, (void*)h->xl,
                     (void*)h->gpart, (void*)h->stt, (void*)h->samp, (void*)h->swork})
         if (p) (void)hipFree(p);
     h->kc = h->vc = nullptr;
     h->x = h->xn = h->qkv = h->attn = h->hbuf = h->att_part = h->logits = h->probs_dev = h->gpart = nullptr;
-    h->probe_ids_dev = nullptr; h->xh = h->xl = nullptr; h->stt = nullptr; h->samp = nullptr; h->swork = nullptr;
+    h->probe_ids_dev = nullptr; h->att_arrive = nullptr; h->xh = h->xl = nullptr; h->stt = nullptr; h->samp = nullptr; h->swork = nullptr;
     if (h->h_stt) { (void)hipHostFree(h->h_stt); h->h_stt = nullptr; }
     if (h->stream) { (void)hipStreamDestroy(h->stream); h->stream = nullptr; }
     if (h->weights_of) {            // borrower: the weights belong to someone else
@@ -1397,6 +1399,8 @@ static int lm_common_init(rca_lm* h, const rca_tensor_t* ts, int nt, const rca_l
     if ((rc = lm_alloc((void**)&h->logits, (size_t)h->logits_rows_cap * c.vocab_size * 4)) != RCA_OK) return rc;
     if ((rc = lm_alloc((void**)&h->probs_dev, (64 + 2 * PROBS_SLICES) * 4)) != RCA_OK) return rc;   // [64 probs][slice (max, sum) pairs]
     if ((rc = lm_alloc((void**)&h->probe_ids_dev, 64 * 4)) != RCA_OK) return rc;
+    if ((rc = lm_alloc((void**)&h->att_arrive, 64 * 4)) != RCA_OK) return rc;
+    RCA_HIP(hipMemsetAsync(h->att_arrive, 0, 64 * 4, h->stream));
     {
         const size_t kmax = (size_t)std::max(std::max(H, AO), c.ffn);
         if ((rc = lm_alloc((void**)&h->xh, (size_t)LM_MAXM * kmax * 2)) != RCA_OK) return rc;
@@ -1681,6 +1685,69 @@ static void launch_gemv(int kind, rca_lm* h, int M, const bf16_t* W, const Q8Mat
     else launch_gemv_q<PRO, EPI, 0>(g, h, M, W, q8, x, y, N, K, ldy, pro, rope, st);
 }
 
+// Merge of the splits of one (token, head) row by ONE wave, lane <-> dim, in split order.  Latency code: every load it will ever
+// need is issued in the first instructions -- the (m, l) pair of split `lane` and this lane's output element of up to CMB_PRE
+// splits -- and none of them depends on the step state (the bound is the number of splits the attention kernel was LAUNCHED
+// with; a split beyond the visible context carries m = -inf and weighs 0, its o is never used).  COHERENT: the partials were
+// written by other workgroups of the SAME launch (fused path): every load is an agent-scope (sc1) load.
+#define CMB_PRE 32
+template <bool COHERENT>
+__device__ __forceinline__ float attn_part_load(const float* p) {
+    if (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool COHERENT>
+__device__ __forceinline__ float attn_merge_row(const float* __restrict__ base, int nsp, int d) {
+    const long sstride = 32L * 66;
+    float pv[CMB_PRE];
+#pragma unroll
+    for (int j = 0; j < CMB_PRE; ++j) pv[j] = attn_part_load<COHERENT>(base + (long)min(j, nsp - 1) * sstride + 2 + d);
+    float mx, ml0, ll0;
+    {
+        const int sp = min(d, nsp - 1);
+        ml0 = attn_part_load<COHERENT>(base + sp * sstride);
+        ll0 = attn_part_load<COHERENT>(base + sp * sstride + 1);
+        if (d >= nsp) { ml0 = -INFINITY; ll0 = 0.0f; }
+        mx = ml0;
+    }
+    for (int s0 = 64; s0 < nsp; s0 += 64) {   // more than 64 splits (contexts beyond 16 k): the rare, slower tail
+        const int sp = s0 + d;
+        mx = fmaxf(mx, sp < nsp ? attn_part_load<COHERENT>(base + sp * sstride) : -INFINITY);
+    }
+    mx = wave_max(mx);
+    float L = 0.0f, O = 0.0f;
+    {
+        const float fl = (ml0 == -INFINITY) ? 0.0f : __expf(ml0 - mx);
+        const int cnt = min(64, nsp);
+#pragma unroll
+        for (int j = 0; j < CMB_PRE; ++j) {
+            if (j < cnt) {
+                const float f = __shfl(fl, j), l = __shfl(ll0, j);
+                L = __builtin_fmaf(l, f, L);
+                O = __builtin_fmaf(f == 0.0f ? 0.0f : pv[j], f, O);
+            }
+        }
+        for (int j = CMB_PRE; j < cnt; ++j) {
+            const float f = __shfl(fl, j), l = __shfl(ll0, j);
+            const float p = attn_part_load<COHERENT>(base + (long)j * sstride + 2 + d);
+            L = __builtin_fmaf(l, f, L);
+            O = __builtin_fmaf(f == 0.0f ? 0.0f : p, f, O);
+        }
+    }
+    for (int s0 = 64; s0 < nsp; s0 += 64) {
+        const int spl = min(s0 + d, nsp - 1);
+        const float ml = attn_part_load<COHERENT>(base + spl * sstride), ll = attn_part_load<COHERENT>(base + spl * sstride + 1);
+        const float fl = (ml == -INFINITY) ? 0.0f : __expf(ml - mx);
+        const int cnt = min(64, nsp - s0);
+        for (int j = 0; j < cnt; ++j) {
+            const float f = __shfl(fl, j), l = __shfl(ll, j);
+            const float p = attn_part_load<COHERENT>(base + (long)(s0 + j) * sstride + 2 + d);
+            L = __builtin_fmaf(l, f, L);
+            O = __builtin_fmaf(f == 0.0f ? 0.0f : p, f, O);
+        }
+    }
+    return O / L;
+}
 // ------------------------------------------------------------------ attention on MFMA (decode steps and prefill tiles)
 // grid (kv head, 256-key split, block of 32 query rows); a query row is (token, q head of this kv head), 32 / G tokens
 // per block; 8 waves, each ONE block of 32 keys (so there is no online rescaling inside a wave):
@@ -1699,7 +1766,37 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 template <int G>
 __global__ __launch_bounds__(512) void lm_attn_mfma_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ qkv,
                                                            const f16_t* __restrict__ kc, const f16_t* __restrict__ vc,
-                                                           float* __restrict__ part, int nh, int nkv, int n_splits, float scale, int n_ctx) {
+                                                           float* __restrict__ part, int nh, int nkv, int n_splits, float scale, int n_ctx,
+                                                           int* __restrict__ arrive, float* __restrict__ attn_out) {
+    // arrive != nullptr (decode steps, one query block, at most one workgroup per CU): the merge of the splits happens HERE -- every
+    // workgroup publishes its partial with write-through (sc1) stores, drains them, and adds to its kv head's arrival counter; the
+    // workgroup whose add comes last re-reads all partials with sc1 loads and writes the attention output, one wave per
+    // (token, head) row with the arithmetic of the separate combine kernel (MI355X_MICROARCH.md, hand-off table row 1: every
+    // handed-off byte stored sc1, vmcnt(0) in every storing wave, workgroup barrier, ONE lane's agent-scope add; the last adder's
+    // waves load behind a barrier that lane joins; every load sc1).  Saves the combine launch (1.7 us dispatch + its round trip).
+    const bool fused = arrive != nullptr;
+    auto part_store = [&](float* p, float v) {
+        if (fused) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *p = v;
+    };
+    __shared__ int s_last;
+    auto arrive_and_merge = [&](int M_) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial stores have left the CU
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int old = __hip_atomic_fetch_add(arrive + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = old == (int)gridDim.y - 1;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        const int w = threadIdx.x >> 6, d = threadIdx.x & 63;       // wave <-> row (token_in_block * G + q head), lane <-> dim
+        if (w < M_ * G) {
+            const int m = w / G, head = blockIdx.x * G + w % G;
+            const float* base = part + ((long)blockIdx.x * n_splits) * 32 * 66 + w * 66;
+            attn_out[(long)m * nh * 64 + head * 64 + d] = attn_merge_row<true>(base, (int)gridDim.y, d);
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(arrive + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+    };
     constexpr int HD = 64;
     constexpr int TPB = 32 / G;   // tokens per query block
     extern __shared__ __attribute__((aligned(16))) float attm_lds[];
@@ -1742,8 +1839,9 @@ __global__ __launch_bounds__(512) void lm_attn_mfma_kernel(const LmDevState* __r
     const int kmax = pos0 + t0 + ntok;   // keys [0, kmax) are visible to the last token of the block
     float* pout = part + ((long)(qb * nkv + g) * n_splits + sp) * 32 * 66;
     if (kbase >= kmax) {   // nothing visible in this split
-        if (threadIdx.x < 32) { pout[threadIdx.x * 66] = -INFINITY; pout[threadIdx.x * 66 + 1] = 0.0f; }
+        if (threadIdx.x < 32) { part_store(pout + threadIdx.x * 66, -INFINITY); part_store(pout + threadIdx.x * 66 + 1, 0.0f); }
         pin_loads();
+        if (fused) arrive_and_merge(M);
         return;
     }
     // ---- V block of this wave, transposed into LDS: vt[wave][dim][key]
@@ -1844,8 +1942,9 @@ __global__ __launch_bounds__(512) void lm_attn_mfma_kernel(const LmDevState* __r
 #pragma unroll
         for (int r = 0; r < 16; ++r) wo[wave][(r & 3) + 8 * (r >> 2) + 4 * half][32 * nt + col] = oacc[nt][r];
     __syncthreads();
-    // ---- merge the 8 waves, write the split partial
-    for (int i = threadIdx.x; i < 32 * HD; i += 512) {
+    // ---- merge the 8 waves, write the split partial (a decode step has M * G <= 8 live rows of the 32: the others are skipped)
+    const int live_rows = fused ? M * G : 32;
+    for (int i = threadIdx.x; i < live_rows * HD; i += 512) {
         const int r = i / HD, d = i - r * HD;
         float m2 = wm[0][r];
 #pragma unroll
@@ -1857,16 +1956,13 @@ __global__ __launch_bounds__(512) void lm_attn_mfma_kernel(const LmDevState* __r
             L = __builtin_fmaf(wl[w][r], f, L);
             O = __builtin_fmaf(wo[w][r][d], f, O);
         }
-        pout[r * 66 + 2 + d] = O;
-        if (d == 0) { pout[r * 66] = m2; pout[r * 66 + 1] = L; }
+        part_store(pout + r * 66 + 2 + d, O);
+        if (d == 0) { part_store(pout + r * 66, m2); part_store(pout + r * 66 + 1, L); }
     }
+    if (fused) arrive_and_merge(M);
 }
-// merges the splits of lm_attn_mfma_kernel in split order: one wave per (token, head), lane <-> dim.
-// Latency kernel: every load it will ever need is issued in the first instructions -- the (m, l) pair of split `lane` and this lane's
-// output element of up to CMB_PRE splits -- and none of them depends on the step state (the bound is the number of splits the
-// attention kernel was LAUNCHED with; a split beyond the visible context carries m = -inf and weighs 0, its o is never used), so
-// the kernel is one memory round trip deep instead of one per group of splits.  Same arithmetic and order as before.
-#define CMB_PRE 32
+// merges the splits of lm_attn_mfma_kernel as its own launch (prefill tiles, and decode steps whose grid exceeds one workgroup per
+// CU): one wave per (token, head)
 template <int G>
 __global__ __launch_bounds__(64) void lm_attn_mfma_combine_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ part,
                                                                   float* __restrict__ attn, int nh, int nkv, int n_splits, int nsp_launch,
@@ -1878,58 +1974,8 @@ __global__ __launch_bounds__(64) void lm_attn_mfma_combine_kernel(const LmDevSta
     const int r = tl * G + hq;
     const int d = threadIdx.x;
     const float* base = part + ((long)(qb * nkv + g) * n_splits) * 32 * 66 + r * 66;
-    const long sstride = 32L * 66;
-    const int nsp = min(nsp_launch, n_splits);
-    float pv[CMB_PRE];
-#pragma unroll
-    for (int j = 0; j < CMB_PRE; ++j) pv[j] = base[(long)min(j, nsp - 1) * sstride + 2 + d];
-    float mx = -INFINITY;
-    float ml0 = -INFINITY, ll0 = 0.0f;
-    {
-        const int sp = min(d, nsp - 1);
-        ml0 = base[sp * sstride];
-        ll0 = base[sp * sstride + 1];
-        if (d >= nsp) { ml0 = -INFINITY; ll0 = 0.0f; }
-        mx = ml0;
-    }
-    for (int s0 = 64; s0 < nsp; s0 += 64) {   // more than 64 splits (contexts beyond 16 k): the rare, slower tail
-        const int sp = s0 + d;
-        mx = fmaxf(mx, sp < nsp ? base[sp * sstride] : -INFINITY);
-    }
+    const float ov = attn_merge_row<false>(base, min(nsp_launch, n_splits), d);
     if (m >= stt->m) return;
-    mx = wave_max(mx);
-    float L = 0.0f, O = 0.0f;
-    {
-        const float fl = (ml0 == -INFINITY) ? 0.0f : __expf(ml0 - mx);
-        const int cnt = min(64, nsp);
-#pragma unroll
-        for (int j = 0; j < CMB_PRE; ++j) {
-            if (j < cnt) {
-                const float f = __shfl(fl, j), l = __shfl(ll0, j);
-                L = __builtin_fmaf(l, f, L);
-                O = __builtin_fmaf(f == 0.0f ? 0.0f : pv[j], f, O);
-            }
-        }
-        for (int j = CMB_PRE; j < cnt; ++j) {
-            const float f = __shfl(fl, j), l = __shfl(ll0, j);
-            const float p = base[(long)j * sstride + 2 + d];
-            L = __builtin_fmaf(l, f, L);
-            O = __builtin_fmaf(f == 0.0f ? 0.0f : p, f, O);
-        }
-    }
-    for (int s0 = 64; s0 < nsp; s0 += 64) {
-        const int spl = min(s0 + d, nsp - 1);
-        const float ml = base[spl * sstride], ll = base[spl * sstride + 1];
-        const float fl = (ml == -INFINITY) ? 0.0f : __expf(ml - mx);
-        const int cnt = min(64, nsp - s0);
-        for (int j = 0; j < cnt; ++j) {
-            const float f = __shfl(fl, j), l = __shfl(ll, j);
-            const float p = base[(long)(s0 + j) * sstride + 2 + d];
-            L = __builtin_fmaf(l, f, L);
-            O = __builtin_fmaf(f == 0.0f ? 0.0f : p, f, O);
-        }
-    }
-    const float ov = O / L;
     if (hi) {   // prefill tiles: the O-projection GEMM reads bf16 hi + lo
         const bf16_t hb = f32_to_bf16_rne(ov);
         hi[(long)m * nh * 64 + head * 64 + d] = hb;
@@ -1953,16 +1999,18 @@ static void launch_attention_mfma(rca_lm* h, int M, int nsp_launch, const f16_t*
         (void)hipFuncSetAttribute((const void*)lm_attn_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTM_LDS);
         attr_done = true;
     }
-    if (G == 4) {
-        lm_attn_mfma_kernel<4><<<agm, 512, ATTM_LDS, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
-        lm_attn_mfma_combine_kernel<4><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits, nsp_launch, hi, lo);
-    } else if (G == 2) {
-        lm_attn_mfma_kernel<2><<<agm, 512, ATTM_LDS, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
-        lm_attn_mfma_combine_kernel<2><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits, nsp_launch, hi, lo);
-    } else {
-        lm_attn_mfma_kernel<1><<<agm, 512, ATTM_LDS, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx);
-        lm_attn_mfma_combine_kernel<1><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits, nsp_launch, hi, lo);
-    }
+    // decode steps: the merge of the splits is fused into the attention launch while the grid is at most one workgroup per CU (the
+    // regime the sc1 hand-off is measured for); prefill tiles and longer contexts keep the separate combine launch
+    const bool fuse = h->fuse_attn && !hi && agm.z == 1 && c.n_kv_heads * nsp_launch <= 256 && M * G <= 8;
+    int* arrive = fuse ? h->att_arrive : nullptr;
+#define RCA_ATTN_LAUNCH(GG)                                                                                                                        \
+    lm_attn_mfma_kernel<GG><<<agm, 512, ATTM_LDS, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx, \
+                                                        arrive, h->attn);                                                                          \
+    if (!fuse) lm_attn_mfma_combine_kernel<GG><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits, nsp_launch, hi, lo);
+    if (G == 4) { RCA_ATTN_LAUNCH(4) }
+    else if (G == 2) { RCA_ATTN_LAUNCH(2) }
+    else { RCA_ATTN_LAUNCH(1) }
+#undef RCA_ATTN_LAUNCH
 }
 
 // attention split blocks needed by a pass of m tokens on top of the current context
@@ -2835,6 +2883,16 @@ extern "C" int rca_lm_set_q8_decode(rca_lm_t* h, int32_t enable) {
     RCA_HIP(hipStreamSynchronize(h->stream));
     if (h->use_q8 != (enable != 0)) lm_drop_graphs(h);   // the captured steps hold the other set of kernels
     h->use_q8 = enable != 0;
+    return RCA_OK;
+}
+// test / bench knob: merge the attention splits inside the attention launch (1, default) or in a launch of its own (0)
+extern "C" int rca_lm_set_attn_fuse(rca_lm_t* h, int32_t enable) {
+    if (!h) return fail(RCA_ERR_ARG, "null");
+    { const int src = lm_settle(h); if (src != RCA_OK) return src; }
+    RCA_HIP(hipSetDevice(h->device));
+    RCA_HIP(hipStreamSynchronize(h->stream));
+    if (h->fuse_attn != (enable != 0)) lm_drop_graphs(h);
+    h->fuse_attn = enable != 0;
     return RCA_OK;
 }
 extern "C" int rca_lm_has_q8(const rca_lm_t* h, int32_t* out) {

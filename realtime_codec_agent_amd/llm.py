@@ -548,6 +548,10 @@ class LlamaForAlternatingCodeChannels:
         N.check(self._lib.rca_lm_set_mfma_prefill(self._h, 1 if enable else 0), "rca_lm_set_mfma_prefill")
         self._mfma_prefill = bool(enable)
 
+    def set_attn_fuse(self, enable: bool) -> None:
+        """Merge the attention splits inside the attention launch (default) or in a launch of its own."""
+        N.check(self._lib.rca_lm_set_attn_fuse(self._h, 1 if enable else 0), "rca_lm_set_attn_fuse")
+
     def set_q8_decode(self, enable: bool) -> None:
         """Decode from the packed q8_0 matrices (default when the handle has them) or from their bf16(d*q) copies."""
         N.check(self._lib.rca_lm_set_q8_decode(self._h, 1 if enable else 0), "rca_lm_set_q8_decode")

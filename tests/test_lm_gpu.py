@@ -312,6 +312,42 @@ def test_frame_graph_equals_single_steps(graphs):
         llm.frame(ids[9:11], [llm._n_vocab], -1)
 
 
+def test_fused_attention_merge_equals_separate_merge_launch():
+    """Decode steps merge the attention splits inside the attention launch: every workgroup publishes its partial with write-through
+    stores and the one that arrives last merges them (sc1 hand-off).  Must equal the separate merge launch bit for bit: the 1B model,
+    contexts on both sides of the 256-key split and the graph-bucket boundaries, 1- and 2-token steps, graph and eager, and a few
+    hundred consecutive steps at 3 k context (a stale or torn partial would show up as a different token or logit)."""
+    from realtime_codec_agent_amd.llm import LlamaForAlternatingCodeChannels, LMConfig
+    cfg = LMConfig.llama_3_2_1b()
+    llm = LlamaForAlternatingCodeChannels(model_path="random:1b", config=cfg, n_ctx=8192, random_seed=0, device=0)
+    rng = np.random.default_rng(5)
+    ids = rng.integers(128266, 259338, 3400).tolist()
+    llm.eval(ids[:3000])
+    params = dict(top_k=100, top_p=1.0, min_p=0.0, temp=1.0, seed=9)
+
+    def run(fuse, graphs, start, steps, n):
+        llm.set_attn_fuse(fuse)
+        llm.set_graphs(graphs)
+        llm.n_tokens = start
+        llm.init_sampler_for_generate(**params)
+        toks, cur = [], ids[start:start + n]
+        for s in range(steps):
+            t = llm.step(cur)
+            toks.append(t)
+            cur = ([t] + [ids[start + 2 + s]])[:n] if n == 2 else [t]
+        return toks, llm._scores[-1].copy()
+    for start in (250, 255, 256, 511, 1023, 1024, 2040, 2047):        # split and bucket boundaries
+        for n in (1, 2):
+            a = run(True, True, start, 3, n)
+            b = run(False, True, start, 3, n)
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]), (start, n)
+    a = run(True, True, 3000, 300, 2)
+    b = run(False, False, 3000, 300, 2)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1])
+    c = run(True, False, 3000, 40, 2)
+    assert c[0] == a[0][:40]
+
+
 def test_context_overflow_and_bad_args():
     from realtime_codec_agent_amd._native import RcaError
     llm, w, ids = make_llm("default", n_ctx=16)
