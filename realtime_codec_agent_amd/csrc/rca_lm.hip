@@ -28,7 +28,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-#define LM_MAXM 128        // tokens per forward pass (activation buffers); the 128-token prefill tiles use all of them
+#define LM_MAXM 1024       // tokens per prefill pass (activation buffers): up to 8 token blocks of 128 share one launch per GEMM
+#define LM_STATE_DECODE_BYTES (8 + 4 * 16)   // n_tokens, m and the ids a decode step / frame graph needs (LmDevState prefix)
 #define LM_TILE32 32       // token tile of the small-model prefill kernels (lm_gemm_mfma_kernel)
 #define LM_GEMV_M 2        // tokens per decode pass (GEMV kernels); evals longer than LM_PREFILL_MIN go through the MFMA prefill path
 #define LM_PREFILL_MIN 8    // evals of up to this many tokens are decode passes, longer ones prefill tiles
@@ -1339,6 +1340,8 @@ static int lm_upload_f32(const rca_tensor_t* ts, int nt, const std::string& name
     return RCA_OK;
 }
 
+static int g128_splits(int N, int K);
+static bool lm_can_gemm128(const rca_lm* h);
 static int lm_common_init(rca_lm* h, const rca_tensor_t* ts, int nt, const rca_lm* rope_src = nullptr) {
     const rca_lm_config_t& c = h->cfg;
     int rc;
@@ -1407,8 +1410,17 @@ static int lm_common_init(rca_lm* h, const rca_tensor_t* ts, int nt, const rca_l
         if ((rc = lm_alloc((void**)&h->xl, (size_t)LM_MAXM * kmax * 2)) != RCA_OK) return rc;
         RCA_HIP(hipMemsetAsync(h->xh, 0, (size_t)LM_MAXM * kmax * 2, h->stream));
         RCA_HIP(hipMemsetAsync(h->xl, 0, (size_t)LM_MAXM * kmax * 2, h->stream));
-        // k-split partial sums: splits x N stays below 1024 x 128 for every GEMM (see lm_enqueue_prefill_tile128)
-        if ((rc = lm_alloc((void**)&h->gpart, (size_t)LM_MAXM * 1024 * 128 * 4)) != RCA_OK) return rc;
+        // k-split partial sums [split][N][LM_MAXM] of the 128-row GEMMs (lm_enqueue_prefill_tile128); other models never touch the buffer
+        size_t part_rows = 64;   // largest split count x N over the four projections
+        if (lm_can_gemm128(h)) {
+            const int Fq = c.ffn;
+            const int nk[4][2] = {{QKV, H}, {H, AO}, {2 * Fq, H}, {H, Fq}};
+            for (int i = 0; i < 4; ++i) {
+                const int ns = g128_splits(nk[i][0], nk[i][1]);
+                if (ns > 1) part_rows = std::max(part_rows, (size_t)ns * nk[i][0]);
+            }
+        }
+        if ((rc = lm_alloc((void**)&h->gpart, part_rows * LM_MAXM * 4)) != RCA_OK) return rc;
     }
     if ((rc = lm_alloc((void**)&h->stt, sizeof(LmDevState))) != RCA_OK) return rc;
     if ((rc = lm_alloc((void**)&h->samp, sizeof(SamplerDev))) != RCA_OK) return rc;
@@ -2077,12 +2089,14 @@ __global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __
     const int wr = wave >> 1, wc = wave & 1;
     const int n0 = blockIdx.x * 128;
     const int ks = blockIdx.y * kslice;
+    const int tb = blockIdx.z * 128;   // token block of this workgroup: a pass holds up to LM_MAXM / 128 of them, the weights are
+                                       // fetched from HBM by the first and served from L2 / Infinity Cache to the others
     const int nstage = kslice >> 5;
     // staging role: two 16-byte chunks per tile and thread: rows c >> 2, k offset (c & 3) * 8
     const int srow0 = tid >> 2, skc = (tid & 3) * 8;
     const bf16_t* gW = W + (long)(n0 + srow0) * K + ks + skc;
-    const bf16_t* gH = xh + (long)srow0 * K + ks + skc;
-    const bf16_t* gL = xl + (long)srow0 * K + ks + skc;
+    const bf16_t* gH = xh + (long)(tb + srow0) * K + ks + skc;
+    const bf16_t* gL = xl + (long)(tb + srow0) * K + ks + skc;
     const long rstep = 64L * K;     // second chunk: row + 64
     const int soff0 = srow0 * G128_PITCH + skc, soff1 = soff0 + 64 * G128_PITCH;
     // Software pipeline.  A workgroup's stage needs 8 KB of weights straight from HBM (~2 us away) and 16 KB of
@@ -2156,7 +2170,7 @@ __global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __
     const int nsplit = gridDim.y;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int tok = wc * 64 + j * 32 + (lane & 31);
+        const int tok = tb + wc * 64 + j * 32 + (lane & 31);
         if (tok >= Mv) continue;
         if (nsplit > 1) {   // partial sums of this k slice, token-contiguous [split][n][LM_MAXM]: lanes are tokens -> 128-byte runs
             float* p = part + ((long)blockIdx.y * N + n0 + wr * 64) * LM_MAXM + tok;
@@ -2321,6 +2335,14 @@ static int lm_enqueue_prefill_tile(rca_lm* h, int M, hipStream_t st, int nsp_lau
     RCA_LAUNCH_CHECK();
     return RCA_OK;
 }
+// Every 128-row GEMM is cut along k until ~512 workgroups per token block are in flight (a workgroup's stage is one exposed
+// HBM round trip: parallel slices are what hides it), slices of >= 256 k, powers of two so they divide K / 32.  The count
+// depends on the matrix only -- never on the tokens of the pass -- so any tiling of a prompt adds the same partial sums.
+static int g128_splits(int N, int K) {
+    int ns = 1;
+    while (ns * (N / 128) < 512 && K % (ns * 2 * 32) == 0 && K / (ns * 2) >= 256) ns *= 2;
+    return ns;
+}
 static bool lm_can_gemm128(const rca_lm* h) {
     const rca_lm_config_t& c = h->cfg;
     const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim, F = c.ffn;
@@ -2332,14 +2354,8 @@ static int lm_enqueue_prefill_tile128(rca_lm* h, int M, hipStream_t st, int nsp_
     const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim, F = c.ffn;
     GemvRope rope{h->cos_t, h->sin_t, nullptr, nullptr, c.n_heads, c.n_kv_heads, c.n_ctx};
     const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
-    // Every GEMM is cut along k until ~512 workgroups are in flight (a workgroup's stage is one exposed HBM round
-    // trip: parallel slices are what hides it), slices of >= 256 k, powers of two so they divide K / 32.
-    auto splits = [](int N, int K) {
-        int ns = 1;
-        while (ns * (N / 128) < 512 && K % (ns * 2 * 32) == 0 && K / (ns * 2) >= 256) ns *= 2;
-        return ns;
-    };
-    const int sq = splits(QKV, H), so = splits(H, AO), sg = splits(2 * F, H), sd = splits(H, F);
+    const int sq = g128_splits(QKV, H), so = g128_splits(H, AO), sg = g128_splits(2 * F, H), sd = g128_splits(H, F);
+    const int tbz = cdiv(M, 128);   // token blocks of this pass
     float* x = h->x;
     lm_embed_kernel<<<M, 256, 0, st>>>(h->stt, h->embed, x, H, c.vocab_size);
     for (int l = 0; l < c.n_layers; ++l) {
@@ -2348,19 +2364,19 @@ static int lm_enqueue_prefill_tile128(rca_lm* h, int M, hipStream_t st, int nsp_
         f16_t* vc = h->vc + (long)l * h->kv_layer_stride;
         rope.kc = kc; rope.vc = vc;
         lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.attn_norm, h->xn, H, c.rms_eps, h->xh, h->xl);
-        lm_gemm128_kernel<GEMM_EPI_ROPE><<<dim3(QKV / 128, sq), 256, G128_LDS, st>>>(h->stt, L.wqkv, h->xh, h->xl, QKV, H, H / sq, h->qkv, QKV, nullptr, nullptr, h->gpart, rope);
+        lm_gemm128_kernel<GEMM_EPI_ROPE><<<dim3(QKV / 128, sq, tbz), 256, G128_LDS, st>>>(h->stt, L.wqkv, h->xh, h->xl, QKV, H, H / sq, h->qkv, QKV, nullptr, nullptr, h->gpart, rope);
         if (sq > 1) lm_gemm128_epilogue_kernel<GEMM_EPI_ROPE><<<dim3(QKV / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sq, QKV, h->qkv, nullptr, nullptr, rope);
         launch_attention_mfma(h, M, nsp_launch, kc, vc, st, h->xh, h->xl);
-        lm_gemm128_kernel<GEMM_EPI_RESID><<<dim3(H / 128, so), 256, G128_LDS, st>>>(h->stt, L.wo, h->xh, h->xl, H, AO, AO / so, x, H, nullptr, nullptr, h->gpart, norope);
+        lm_gemm128_kernel<GEMM_EPI_RESID><<<dim3(H / 128, so, tbz), 256, G128_LDS, st>>>(h->stt, L.wo, h->xh, h->xl, H, AO, AO / so, x, H, nullptr, nullptr, h->gpart, norope);
         if (so > 1) lm_gemm128_epilogue_kernel<GEMM_EPI_RESID><<<dim3(H / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, so, H, x, nullptr, nullptr, norope);
         lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.ffn_norm, h->xn, H, c.rms_eps, h->xh, h->xl);
         // SwiGLU epilogue writes the hi/lo split of h straight into the (ffn-wide) split buffers of the down projection:
         // it reads xh/xl [M][H] and writes [M][F] -- distinct regions are needed, so h goes to the second half of hbuf
         bf16_t* hh = reinterpret_cast<bf16_t*>(h->hbuf);
         bf16_t* hl = hh + (long)LM_MAXM * F;
-        lm_gemm128_kernel<GEMM_EPI_SWIGLU><<<dim3(2 * F / 128, sg), 256, G128_LDS, st>>>(h->stt, L.wgu, h->xh, h->xl, 2 * F, H, H / sg, nullptr, F, hh, hl, h->gpart, norope);
+        lm_gemm128_kernel<GEMM_EPI_SWIGLU><<<dim3(2 * F / 128, sg, tbz), 256, G128_LDS, st>>>(h->stt, L.wgu, h->xh, h->xl, 2 * F, H, H / sg, nullptr, F, hh, hl, h->gpart, norope);
         if (sg > 1) lm_gemm128_epilogue_kernel<GEMM_EPI_SWIGLU><<<dim3(2 * F / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sg, 2 * F, nullptr, hh, hl, norope);
-        lm_gemm128_kernel<GEMM_EPI_RESID><<<dim3(H / 128, sd), 256, G128_LDS, st>>>(h->stt, L.wdown, hh, hl, H, F, F / sd, x, H, nullptr, nullptr, h->gpart, norope);
+        lm_gemm128_kernel<GEMM_EPI_RESID><<<dim3(H / 128, sd, tbz), 256, G128_LDS, st>>>(h->stt, L.wdown, hh, hl, H, F, F / sd, x, H, nullptr, nullptr, h->gpart, norope);
         if (sd > 1) lm_gemm128_epilogue_kernel<GEMM_EPI_RESID><<<dim3(H / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sd, H, x, nullptr, nullptr, norope);
     }
     RCA_LAUNCH_CHECK();
@@ -2380,8 +2396,8 @@ static int lm_push_state(rca_lm* h, const int32_t* ids, int m, hipStream_t st) {
     h->h_stt->n_tokens = h->n_tokens;
     h->h_stt->m = m;
     for (int i = 0; i < m; ++i) h->h_stt->ids[i] = ids[i];
-    // n_tokens, m, ids only (first 8 + 4*LM_MAXM bytes); rng counter / out_token stay device-owned
-    RCA_HIP(hipMemcpyAsync(h->stt, h->h_stt, 8 + 4 * LM_MAXM, hipMemcpyHostToDevice, st));
+    // n_tokens, m and the m ids only; rng counter / out_token stay device-owned
+    RCA_HIP(hipMemcpyAsync(h->stt, h->h_stt, 8 + 4 * (size_t)std::max(m, 16), hipMemcpyHostToDevice, st));
     return RCA_OK;
 }
 
@@ -2628,7 +2644,7 @@ extern "C" int rca_lm_step(rca_lm_t* h, const int32_t* ids, int32_t n, int32_t* 
         hipGraph_t g = nullptr;
         RCA_HIP(hipStreamSynchronize(st));
         RCA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        hipError_t e = hipMemcpyAsync(h->stt, h->h_stt, 8 + 4 * LM_MAXM, hipMemcpyHostToDevice, st);
+        hipError_t e = hipMemcpyAsync(h->stt, h->h_stt, LM_STATE_DECODE_BYTES, hipMemcpyHostToDevice, st);
         rc = e == hipSuccess ? lm_enqueue_pass(h, n, 1, st, nsp_launch) : fail(RCA_ERR_HIP, "capture memcpy: %s", hipGetErrorString(e));
         if (rc == RCA_OK) {
             lm_enqueue_sample(h, h->logits, st);
@@ -2688,7 +2704,7 @@ extern "C" int rca_lm_frame(rca_lm_t* h, const int32_t* first_pair, const int32_
         hipGraph_t g = nullptr;
         RCA_HIP(hipStreamSynchronize(st));
         if (capture) RCA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        hipError_t e = hipMemcpyAsync(h->stt, h->h_stt, 8 + 4 * LM_MAXM, hipMemcpyHostToDevice, st);
+        hipError_t e = hipMemcpyAsync(h->stt, h->h_stt, LM_STATE_DECODE_BYTES, hipMemcpyHostToDevice, st);
         if (e != hipSuccess) rc = fail(RCA_ERR_HIP, "frame memcpy: %s", hipGetErrorString(e));
         for (int i = 0; i < n_steps && rc == RCA_OK; ++i) {
             rc = lm_enqueue_pass(h, 2, 1, st, nsp_launch);

@@ -469,6 +469,24 @@ def test_full_size_1b_properties():
     llm.reset(); llm.eval(ids[:520]); m1 = llm._scores[-1].copy()
     llm.reset(); llm.eval(ids[:300]); llm.eval(ids[300:520]); m2 = llm._scores[-1].copy()
     assert np.array_equal(m1, m2)
+    # a pass holds up to 1024 tokens (8 token blocks per GEMM launch): 1500 tokens as 1024 + 476, as 128-token pieces (the shadow
+    # cache's feeding pattern) and as ragged pieces give the same bits
+    long_ids = rng.integers(128266, 259338, 1500).tolist()
+
+    def next_logits(pieces):
+        llm.reset()
+        off = 0
+        for n in pieces:
+            llm.eval_async(long_ids[off:off + n])
+            off += n
+        assert off == 1499
+        llm.eval(long_ids[1499:])          # one decode pass over the cache the pieces built
+        return llm._scores[-1].copy()
+    one = next_logits([1499])
+    assert np.array_equal(one, next_logits([128] * 11 + [91]))
+    assert np.array_equal(one, next_logits([1030, 7, 1, 461]))
+    llm.reset(); llm.eval(long_ids[:1499]); llm.eval(long_ids[1499:])
+    assert np.array_equal(one, llm._scores[-1])
     d = np.abs(m1 - a).max()
     print(f"1B: mfma prefill vs exact GEMV path max|dlogit| = {d:.3e} (std {a.std():.3f})")
     assert d < 5e-3 * max(1.0, np.abs(a).max())
