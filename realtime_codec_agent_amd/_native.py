@@ -14,7 +14,8 @@ import numpy as np
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_PKG_DIR, "csrc")
-LIB_PATH = os.path.join(_PKG_DIR, "librca_hip.so")
+# RCA_LIB_PATH: load / build another copy of the library (kernel A/B experiments: RCA_EXTRA_HIPCC_FLAGS=-D... RCA_LIB_PATH=...)
+LIB_PATH = os.environ.get("RCA_LIB_PATH") or os.path.join(_PKG_DIR, "librca_hip.so")
 HIP_SOURCES = ["rca_codec.hip", "rca_lm.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
                "-Wno-unused-result"]

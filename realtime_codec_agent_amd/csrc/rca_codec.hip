@@ -227,8 +227,13 @@ struct FuseIn {
 struct TrInfo {
     int s, padL, Lout, n_co;   // upsampling stride, left pad, output length per row, real channel tiles
 };
+// waves per workgroup of conv1d_mfma_kernel: the waves never synchronise with each other, so the workgroup is only a unit of
+// dispatch -- with one wave per workgroup a finished wave's slot is refilled at once instead of when its three siblings are done
+#ifndef RCA_CONV_WPB
+#define RCA_CONV_WPB 1
+#endif
 template <int KS, int S, int CIC, int WM, int WN, int FUSE, int TR>
-__global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+__global__ __launch_bounds__(64 * RCA_CONV_WPB, 2) void conv1d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           int Cin, int Lin, int Cout, int Lout, long Ncols, int nchunks,
                                                           int pre, float slope, FuseIn fin, TrInfo tr) {
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
     constexpr int BUF = CIC * S * U + 4;   // + a spare word that absorbs the lanes past the window
     static_assert((CIC * KS) % 8 == 0, "chunk must hold whole weight quads");
 
-    extern __shared__ __attribute__((aligned(16))) float xs_all[];  // [4 waves][2][CIC][S][U]
+    extern __shared__ __attribute__((aligned(16))) float xs_all[];  // [RCA_CONV_WPB waves][2][CIC][S][U]
 #ifdef RCA_CONV_TIMELINE
     long* const tl_buf = rca_prof_buf;
 #endif
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
     const int phase = TR ? co_tile_x / n_co_real : 0;
     const int co_tile = TR ? co_tile_x % n_co_real : co_tile_x;
     const long col_tile = (seq / n_co) * 8 + xcd;
-    const long n0 = (col_tile * 4 + wave) * NW;   // first column of this wave
+    const long n0 = (col_tile * RCA_CONV_WPB + wave) * NW;   // first column of this wave
     const int co0 = co_tile * MT;
     if (n0 >= Ncols) return;  // whole wave out of range (no barriers: safe)
     // column -> (batch row, position): every column this wave touches is n_base + dn with 0 <= dn <= NW + 2, and the
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
     const rca_rsrc_t rs_x = rca_make_rsrc(FUSE ? fin.src.base : x + (long)b_base * Cin * Lin, 0x7FFFFFFF);
     const rca_rsrc_t rs_none = rca_make_rsrc(FUSE ? fin.src.base : x, 0);
     unsigned s_boff[RE];   // byte offset of x[b][0][t*S + p] from row b_base (< 2^31 by the host check), or OOB
-    int s_loff[RE];        // p*U + slot; -1: lane past the window (its write lands in the spare word)
+    int s_loff[RE];        // p*U + slot; lanes past the window: a padding slot, or -1 (write predicated) when the rows have none
     bool s_ok[FUSE ? RE : 1];
     // ---- fused conv_in: 7-sample PCM window per staged element (zero outside the row's valid samples).  The two batch
     // rows a wave can touch (b_base, b_base + 1: the host only fuses when a row is longer than the window) are addressed
@@ -334,7 +339,9 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
         int bb, t;
         rel_bt(ok ? dn : 0, bb, t);
         if (TR && t >= Lin) ok = false;   // column t0 = Lin exists (its x[t0-1] tap is valid) but has no x[t0]
-        s_loff[r] = e < E ? p * U + slot : -1;
+        // lanes past the window write into the padding slot at the end of a phase row (U > NW + 2) so the LDS write needs no predicate;
+        // where the rows have no padding (stride-1 layers) they keep -1 and the write is predicated
+        s_loff[r] = e < E ? p * U + slot : (U > NW + 2 ? U - 1 : -1);
         s_boff[r] = ok ? ((unsigned)bb * (unsigned)(Cin * Lin) + (unsigned)(t * S + p)) * 4u : OOB;
         if (FUSE) {
             s_ok[r] = ok;
@@ -445,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
                     if (ACT && !FUSE) v[j] = fmaxf(v[j], v[j] * slope);
                 }
                 // only the last group can hold lanes past the window: one LDS address per group plus immediates
-                if (64 * PW * (r + 1) <= E || s_loff[r] >= 0) {
+                if (U > NW + 2 || 64 * PW * (r + 1) <= E || s_loff[r] >= 0) {
 #pragma unroll
                     for (int j = 0; j < PW; ++j) dst[cl * S * U + s_loff[r] + j * U] = v[j];
                 }
@@ -506,10 +513,6 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
             }
         }
     };
-    auto compute = [&](int buf, int cn) __attribute__((always_inline)) {
-        if (edges) compute_t(buf, cn, std::true_type{});
-        else compute_t(buf, cn, std::false_type{});
-    };
 
     stage_load(0);
 #pragma unroll
@@ -525,6 +528,10 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
     long tl_load = 0, tl_mfma = 0, tl_write = 0;   // even chunks only: issue of the next loads / MFMA block / activation + LDS write
 #endif
     const int lastc = nchunks - 1;
+    // The whole chunk loop exists twice, with and without the edge selects, and the wave picks one ONCE: a branch per chunk joins
+    // two register allocations of the 64 accumulators behind every MFMA block (the compiler then copies them back -- 32 moves behind
+    // a drained matrix pipe per chunk -- and sinks the weight refills out of the block to the join).
+    auto chunk_loop = [&](auto edge_tag, auto act_tag) __attribute__((always_inline)) {
     for (int c = 0; c < nchunks; c += 2) {
         // The next chunk's loads are issued UNCONDITIONALLY (past the end they re-read the last chunk and the
         // result is never used): a branch around them would merge two paths in front of the MFMA block and
@@ -537,11 +544,11 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
         __builtin_amdgcn_sched_barrier(0);
         RCA_TL_STAMP(tb);
         __builtin_amdgcn_s_setprio(0);
-        compute(0, c1);
+        compute_t(0, c1, edge_tag);
         __builtin_amdgcn_s_setprio(2);  // staging phases run at raised priority (measured +2.4 %)
         __builtin_amdgcn_sched_barrier(0);
         RCA_TL_STAMP(tc);
-        stage_write(1);
+        stage_write_t(1, act_tag);
         __builtin_amdgcn_wave_barrier();
         RCA_TL_STAMP(td);
         RCA_TL_ADD(tl_load, ta, tb); RCA_TL_ADD(tl_mfma, tb, tc); RCA_TL_ADD(tl_write, tc, td);
@@ -550,11 +557,19 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
         stage_load(c2);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(0);
-        compute(1, c2);
+        compute_t(1, c2, edge_tag);
         __builtin_amdgcn_s_setprio(2);
         __builtin_amdgcn_sched_barrier(0);
-        stage_write(0);
+        stage_write_t(0, act_tag);
         __builtin_amdgcn_wave_barrier();
+    }
+    };
+    if (pre & 1) {
+        if (edges) chunk_loop(std::true_type{}, std::true_type{});
+        else chunk_loop(std::false_type{}, std::true_type{});
+    } else {
+        if (edges) chunk_loop(std::true_type{}, std::false_type{});
+        else chunk_loop(std::false_type{}, std::false_type{});
     }
 
     RCA_TL_STAMP(tl2);
@@ -609,7 +624,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const float* __rest
         const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);   // XCC_ID
         // one region of 65536 records per kernel size, indexed by wave: no atomics (a single counter serialises 64k waves)
         constexpr int region = KS == 4 ? 0 : KS == 8 ? 1 : KS == 10 ? 2 : KS == 16 ? 3 : KS == 3 ? 4 : 5;
-        long* o = tl_buf + ((long)region * 65536 + ((blockIdx.x * 4 + wave) & 0xFFFF)) * 8;
+        long* o = tl_buf + ((long)region * 65536 + ((blockIdx.x * RCA_CONV_WPB + wave) & 0xFFFF)) * 8;
         o[6] = tl_load | (tl_mfma << 32);
         o[7] = tl_write | ((long)nchunks << 32);
         o[0] = tl0; o[1] = tl1; o[2] = tl2; o[3] = tl3;
@@ -677,7 +692,9 @@ __global__ __launch_bounds__(512) void conv1d_ws_kernel(const float* __restrict_
             const int slot = e / S, p = e - slot * S;
             const long n = n0 - 1 + slot;
             s_ok[r] = active && e < E && n >= 0 && n < Ncols;
-            s_loff[r] = e < E ? p * U + slot : -1;
+            // lanes past the window write into the padding slot at the end of a phase row (U > NW + 2) so the LDS write needs no predicate;
+        // where the rows have no padding (stride-1 layers) they keep -1 and the write is predicated
+        s_loff[r] = e < E ? p * U + slot : -1;
             const long nn = s_ok[r] ? n : 0;
             const long b = nn / Lout;
             const int t = (int)(nn - b * Lout);
@@ -1669,13 +1686,13 @@ extern "C" int rca_codec_sync(rca_codec_t* h) {
 template <int KS, int S, int CIC, int WM, int WN, int FUSE, int TR>
 static void launch_conv_cfg(const ConvLayer& L, const float* wp, int nchunks, const float* x, float* y, int Lin, int Lc, long Ncols,
                             float slope, const FuseIn& fin, const TrInfo& tr, hipStream_t st, int act) {
-    constexpr int NT = 4 * WN * 32, MT = WM * 32;
-    constexpr int lds = 4 * 2 * (CIC * S * ConvLds<S>::stride(WN * 32) + 4) * 4;
+    constexpr int NT = RCA_CONV_WPB * WN * 32, MT = WM * 32;
+    constexpr int lds = RCA_CONV_WPB * 2 * (CIC * S * ConvLds<S>::stride(WN * 32) + 4) * 4;
     static_assert(lds <= 65536, "LDS budget");
     // 1-D grid: column tiles padded to a multiple of 8 (one per XCD), times the channel tiles (times the phases)
     const long col_tiles = (cdiv(Ncols, NT) + 7) / 8 * 8;
     dim3 grid((unsigned)(col_tiles * cdiv(L.cout, MT) * (TR ? tr.s : 1)));
-    conv1d_mfma_kernel<KS, S, CIC, WM, WN, FUSE, TR><<<grid, 256, lds, st>>>(x, wp, L.bp, y, L.cin, Lin, L.cout, Lc, Ncols, nchunks, act, slope, fin, tr);
+    conv1d_mfma_kernel<KS, S, CIC, WM, WN, FUSE, TR><<<grid, 64 * RCA_CONV_WPB, lds, st>>>(x, wp, L.bp, y, L.cin, Lin, L.cout, Lc, Ncols, nchunks, act, slope, fin, tr);
 }
 
 template <int KS, int S, int CIC>
