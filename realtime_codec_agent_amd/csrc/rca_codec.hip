@@ -232,6 +232,17 @@ struct TrInfo {
 #ifndef RCA_CONV_WPB
 #define RCA_CONV_WPB 1
 #endif
+#ifndef RCA_CONV_PIPE
+#define RCA_CONV_PIPE 1
+#endif
+#ifndef RCA_CONV_PRIO
+#define RCA_CONV_PRIO 1
+#endif
+#ifdef RCA_ABL_NOBREAD   // timing experiment: B fragments from a register instead of LDS
+#define RCA_ABL_BREAD(x) (slope)
+#else
+#define RCA_ABL_BREAD(x) (x)
+#endif
 template <int KS, int S, int CIC, int WM, int WN, int FUSE, int TR>
 __global__ __launch_bounds__(64 * RCA_CONV_WPB, 2) void conv1d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                           const float* __restrict__ bias, float* __restrict__ y,
@@ -421,7 +432,11 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, 2) void conv1d_mfma_kernel(const
             } else {
                 // raw value only: nothing consumes it before the MFMA block.  A channel past Cin (last chunk of a layer
                 // whose Cin is not a multiple of CIC) reads through the empty descriptor: zeros.
+#ifdef RCA_ABL_NOXLOAD   // timing experiment: every input load reads through the empty descriptor (returns 0 without touching memory)
+                const rca_rsrc_t rs = rs_none;
+#else
                 const rca_rsrc_t rs = ci < Cin ? rs_x : rs_none;
+#endif
                 const int soff = (ci < Cin ? ci : 0) * Lin * 4;
 #pragma unroll
                 for (int r = 0; r < RE; ++r) {
@@ -439,6 +454,9 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, 2) void conv1d_mfma_kernel(const
     // pre-activation applied here (ACT) unless the layer that produced x already stored activated values
     auto stage_write_t = [&](int buf, auto act_tag) __attribute__((always_inline)) {
         constexpr bool ACT = decltype(act_tag)::value;
+#ifdef RCA_ABL_NOWRITE   // timing experiment: the staged values never reach LDS (and nothing waits for their loads)
+        return;
+#endif
         float* dst = xs + buf * BUF;
 #pragma unroll
         for (int cl = 0; cl < CIC; ++cl) {
@@ -514,6 +532,66 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, 2) void conv1d_mfma_kernel(const
         }
     };
 
+    // The same chunk as an explicit software pipeline (RCA_CONV_PIPE, the default): the B fragments run RD k pairs ahead of the
+    // MFMAs that consume them -- the first RD of a block are requested as soon as its window is in LDS, a whole staging phase
+    // earlier -- the weight quad is refilled right behind its last MFMA, and a scheduling barrier per k pair keeps that order
+    // (left alone, the scheduler issues each batch of reads right in front of its first use and sinks the refills to the end of the block).
+    constexpr int RD = KPC >= 8 ? 4 : 2;
+    float bhead[RD][WN];
+    auto read_head = [&](int buf) __attribute__((always_inline)) {
+        const float* xb = xs + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < RD; ++i)
+#pragma unroll
+            for (int wn = 0; wn < WN; ++wn) bhead[i][wn] = RCA_ABL_BREAD(xb[b_off[i] + wn * 32]);
+    };
+    auto compute_p = [&](int buf, int cn, auto edge_tag) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        const float* xb = xs + buf * BUF;
+        const float4* pn[WM];
+#pragma unroll
+        for (int wm = 0; wm < WM; ++wm) pn[wm] = w_ptr(wm, cn);
+        float ring[KPC][WN];   // statically indexed: RD + 1 entries live at a time
+#pragma unroll
+        for (int i = 0; i < RD; ++i)
+#pragma unroll
+            for (int wn = 0; wn < WN; ++wn) ring[i][wn] = bhead[i][wn];
+#pragma unroll
+        for (int kp = 0; kp < KPC; ++kp) {
+#if RCA_CONV_PRIO
+            // Priority rises with progress through the block: of the two waves that share a SIMD the one further along wins the matrix
+            // pipe, finishes, and does its staging while the other has the pipe to itself -- the pair settles into alternation instead of
+            // entering and leaving their MFMA blocks together (round-robin issue keeps two waves that started together in lock step:
+            // both then stage at the same time and the pipe idles)
+            if (kp == KPC / 4) __builtin_amdgcn_s_setprio(1);
+            if (kp == KPC / 2) __builtin_amdgcn_s_setprio(2);
+            if (kp == 3 * KPC / 4) __builtin_amdgcn_s_setprio(3);
+#endif
+            if (kp + RD < KPC) {
+#pragma unroll
+                for (int wn = 0; wn < WN; ++wn) ring[kp + RD][wn] = RCA_ABL_BREAD(xb[b_off[kp + RD] + wn * 32]);
+            }
+            float bfr[WN];
+#pragma unroll
+            for (int wn = 0; wn < WN; ++wn) bfr[wn] = (EDGE && ((zmask[wn] >> kp) & 1u)) ? 0.0f : ring[kp][wn];
+#pragma unroll
+            for (int wm = 0; wm < WM; ++wm) {
+                const float4 q4 = a[wm][kp >> 2];
+                const float av = (kp & 3) == 0 ? q4.x : (kp & 3) == 1 ? q4.y : (kp & 3) == 2 ? q4.z : q4.w;
+#pragma unroll
+                for (int wn = 0; wn < WN; ++wn)
+                    acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bfr[wn], acc[wm][wn], 0, 0, 0);
+            }
+#ifndef RCA_ABL_NOAREFILL   // (timing experiment when defined: the weights of chunk 0 are reused)
+            if ((kp & 3) == 3) {
+#pragma unroll
+                for (int wm = 0; wm < WM; ++wm) a[wm][kp >> 2] = pn[wm][(kp >> 2) * 64];
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
     stage_load(0);
 #pragma unroll
     for (int wm = 0; wm < WM; ++wm) {
@@ -523,6 +601,9 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, 2) void conv1d_mfma_kernel(const
     }
     stage_write(0);
     __builtin_amdgcn_wave_barrier();
+#if RCA_CONV_PIPE
+    read_head(0);
+#endif
     RCA_TL_STAMP(tl1);
 #ifdef RCA_CONV_TIMELINE
     long tl_load = 0, tl_mfma = 0, tl_write = 0;   // even chunks only: issue of the next loads / MFMA block / activation + LDS write
@@ -544,12 +625,20 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, 2) void conv1d_mfma_kernel(const
         __builtin_amdgcn_sched_barrier(0);
         RCA_TL_STAMP(tb);
         __builtin_amdgcn_s_setprio(0);
+#if RCA_CONV_PIPE
+        compute_p(0, c1, edge_tag);
+#else
         compute_t(0, c1, edge_tag);
-        __builtin_amdgcn_s_setprio(2);  // staging phases run at raised priority (measured +2.4 %)
+#endif
+        __builtin_amdgcn_s_setprio(RCA_CONV_PRIO ? 3 : 2);  // staging phases run at raised priority (measured +2.4 %)
         __builtin_amdgcn_sched_barrier(0);
         RCA_TL_STAMP(tc);
         stage_write_t(1, act_tag);
         __builtin_amdgcn_wave_barrier();
+#if RCA_CONV_PIPE
+        read_head(1);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         RCA_TL_STAMP(td);
         RCA_TL_ADD(tl_load, ta, tb); RCA_TL_ADD(tl_mfma, tb, tc); RCA_TL_ADD(tl_write, tc, td);
         if (c + 1 >= nchunks) break;
@@ -557,11 +646,19 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, 2) void conv1d_mfma_kernel(const
         stage_load(c2);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(0);
+#if RCA_CONV_PIPE
+        compute_p(1, c2, edge_tag);
+#else
         compute_t(1, c2, edge_tag);
-        __builtin_amdgcn_s_setprio(2);
+#endif
+        __builtin_amdgcn_s_setprio(RCA_CONV_PRIO ? 3 : 2);
         __builtin_amdgcn_sched_barrier(0);
         stage_write_t(0, act_tag);
         __builtin_amdgcn_wave_barrier();
+#if RCA_CONV_PIPE
+        read_head(0);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     };
     if (pre & 1) {
