@@ -227,6 +227,49 @@ struct FuseIn {
 struct TrInfo {
     int s, padL, Lout, n_co;   // upsampling stride, left pad, output length per row, real channel tiles
 };
+// LDS word offset of the B operand of k pair kp for the lanes of one half (without the lane's column): the lanes of half 1 hold the
+// odd k of the pair.  The difference between the halves takes one or two values per layer shape, so a lane needs one or two base
+// registers (column + half * difference) and every read adds a compile-time constant -- not one address register per k pair.
+template <int KS, int S, int TR>
+struct ConvBOff {
+    static constexpr int padL = (KS - S + 1) / 2;
+    static constexpr int q_of(int kp, int half) {
+        const int kl = 2 * kp + half, kk = kl % KS;
+        const int d = TR ? -kk : kk - padL;
+        return (d >= 0) ? d / S : -((-d + S - 1) / S);
+    }
+    static constexpr int off(int kp, int half, int U) {
+        const int kl = 2 * kp + half, ci = kl / KS, kk = kl % KS;
+        const int d = TR ? -kk : kk - padL;
+        const int q = q_of(kp, half);
+        return (ci * S + (d - q * S)) * U + 1 + q;
+    }
+    static constexpr int delta(int kp, int U) { return off(kp, 1, U) - off(kp, 0, U); }
+    // k-th distinct value of delta over the k pairs of a chunk (the last one repeated when there are fewer)
+    static constexpr int distinct(int k, int KPC, int U) {
+        int found[4] = {0, 0, 0, 0};
+        int n = 0;
+        for (int kp = 0; kp < KPC; ++kp) {
+            const int d = delta(kp, U);
+            bool seen = false;
+            for (int i = 0; i < n; ++i) seen = seen || found[i] == d;
+            if (!seen && n < 4) found[n++] = d;
+        }
+        return found[k < n ? k : n - 1];
+    }
+    static constexpr int count(int KPC, int U) {
+        int found[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int n = 0;
+        for (int kp = 0; kp < KPC; ++kp) {
+            const int d = delta(kp, U);
+            bool seen = false;
+            for (int i = 0; i < n; ++i) seen = seen || found[i] == d;
+            if (!seen && n < 8) found[n++] = d;
+        }
+        return n;
+    }
+};
+
 // waves per workgroup of conv1d_mfma_kernel: the waves never synchronise with each other, so the workgroup is only a unit of
 // dispatch -- with one wave per workgroup a finished wave's slot is refilled at once instead of when its three siblings are done
 #ifndef RCA_CONV_WPB
@@ -367,16 +410,18 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, 2) void conv1d_mfma_kernel(const
         }
     }
     // ---- B-read role: per k-pair LDS offset and edge masks for this lane's half
-    int b_off[KPC];
+    typedef ConvBOff<KS, S, TR> BO;    // TR: tap 0 reads x[t0], tap 1 reads x[t0-1]
+    static_assert(BO::count(KPC, U) <= 3, "B-operand base registers");
+    constexpr int BD0 = BO::distinct(0, KPC, U), BD1 = BO::distinct(1, KPC, U), BD2 = BO::distinct(2, KPC, U);
+    const int b_base0 = (lane & 31) + half * BD0, b_base1 = (lane & 31) + half * BD1, b_base2 = (lane & 31) + half * BD2;
+    auto b_off = [&](int kp) __attribute__((always_inline)) {   // kp is a constant after unrolling: one of the bases + an immediate
+        const int dl = BO::delta(kp, U);
+        return (dl == BD0 ? b_base0 : dl == BD1 ? b_base1 : b_base2) + BO::off(kp, 0, U);
+    };
     unsigned m_first = 0, m_last = 0;  // bit kp: the read reaches into the previous / next column
 #pragma unroll
     for (int kp = 0; kp < KPC; ++kp) {
-        const int kl = 2 * kp + half;
-        const int ci = kl / KS, kk = kl - ci * KS;
-        const int d = TR ? -kk : kk - padL;    // TR: tap 0 reads x[t0], tap 1 reads x[t0-1]
-        const int q = (d >= 0) ? d / S : -((-d + S - 1) / S);
-        const int p = d - q * S;
-        b_off[kp] = (ci * S + p) * U + 1 + q + (lane & 31);
+        const int q = half ? BO::q_of(kp, 1) : BO::q_of(kp, 0);
         if (q < 0) m_first |= 1u << kp;
         if (q > 0) m_last |= 1u << kp;
     }
@@ -509,7 +554,7 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, 2) void conv1d_mfma_kernel(const
 #pragma unroll
             for (int i = 0; i < PB; ++i)
 #pragma unroll
-                for (int wn = 0; wn < WN; ++wn) bv[i][wn] = xb[b_off[nb * PB + i] + wn * 32];
+                for (int wn = 0; wn < WN; ++wn) bv[i][wn] = xb[b_off(nb * PB + i) + wn * 32];
 #pragma unroll
             for (int i = 0; i < PB; ++i) {
                 const int kp = nb * PB + i;
@@ -536,6 +581,10 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, 2) void conv1d_mfma_kernel(const
     // MFMAs that consume them -- the first RD of a block are requested as soon as its window is in LDS, a whole staging phase
     // earlier -- the weight quad is refilled right behind its last MFMA, and a scheduling barrier per k pair keeps that order
     // (left alone, the scheduler issues each batch of reads right in front of its first use and sinks the refills to the end of the block).
+    // measured per layer (same box, pipelined vs batched block): k16s8 950 vs 962 us, k8s4 1150 vs 1130, k10s5 1102 vs 1087, fused k4s2
+    // 799 vs 788, k3 225 vs 220 -> the pipeline is used for the k = 16 layer only (all within a few per cent: the block is not
+    // what bounds these layers)
+    constexpr bool PIPE = RCA_CONV_PIPE && !TR && KS == 16;
     constexpr int RD = KPC >= 8 ? 4 : 2;
     float bhead[RD][WN];
     auto read_head = [&](int buf) __attribute__((always_inline)) {
@@ -543,7 +592,7 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, 2) void conv1d_mfma_kernel(const
 #pragma unroll
         for (int i = 0; i < RD; ++i)
 #pragma unroll
-            for (int wn = 0; wn < WN; ++wn) bhead[i][wn] = RCA_ABL_BREAD(xb[b_off[i] + wn * 32]);
+            for (int wn = 0; wn < WN; ++wn) bhead[i][wn] = RCA_ABL_BREAD(xb[b_off(i) + wn * 32]);
     };
     auto compute_p = [&](int buf, int cn, auto edge_tag) __attribute__((always_inline)) {
         constexpr bool EDGE = decltype(edge_tag)::value;
@@ -569,7 +618,7 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, 2) void conv1d_mfma_kernel(const
 #endif
             if (kp + RD < KPC) {
 #pragma unroll
-                for (int wn = 0; wn < WN; ++wn) ring[kp + RD][wn] = RCA_ABL_BREAD(xb[b_off[kp + RD] + wn * 32]);
+                for (int wn = 0; wn < WN; ++wn) ring[kp + RD][wn] = RCA_ABL_BREAD(xb[b_off(kp + RD) + wn * 32]);
             }
             float bfr[WN];
 #pragma unroll
@@ -601,9 +650,7 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, 2) void conv1d_mfma_kernel(const
     }
     stage_write(0);
     __builtin_amdgcn_wave_barrier();
-#if RCA_CONV_PIPE
-    read_head(0);
-#endif
+    if constexpr (PIPE) read_head(0);
     RCA_TL_STAMP(tl1);
 #ifdef RCA_CONV_TIMELINE
     long tl_load = 0, tl_mfma = 0, tl_write = 0;   // even chunks only: issue of the next loads / MFMA block / activation + LDS write
@@ -625,20 +672,17 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, 2) void conv1d_mfma_kernel(const
         __builtin_amdgcn_sched_barrier(0);
         RCA_TL_STAMP(tb);
         __builtin_amdgcn_s_setprio(0);
-#if RCA_CONV_PIPE
-        compute_p(0, c1, edge_tag);
-#else
-        compute_t(0, c1, edge_tag);
-#endif
+        if constexpr (PIPE) compute_p(0, c1, edge_tag);
+        else compute_t(0, c1, edge_tag);
         __builtin_amdgcn_s_setprio(RCA_CONV_PRIO ? 3 : 2);  // staging phases run at raised priority (measured +2.4 %)
         __builtin_amdgcn_sched_barrier(0);
         RCA_TL_STAMP(tc);
         stage_write_t(1, act_tag);
         __builtin_amdgcn_wave_barrier();
-#if RCA_CONV_PIPE
-        read_head(1);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
+        if constexpr (PIPE) {
+            read_head(1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         RCA_TL_STAMP(td);
         RCA_TL_ADD(tl_load, ta, tb); RCA_TL_ADD(tl_mfma, tb, tc); RCA_TL_ADD(tl_write, tc, td);
         if (c + 1 >= nchunks) break;
@@ -646,19 +690,16 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, 2) void conv1d_mfma_kernel(const
         stage_load(c2);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(0);
-#if RCA_CONV_PIPE
-        compute_p(1, c2, edge_tag);
-#else
-        compute_t(1, c2, edge_tag);
-#endif
+        if constexpr (PIPE) compute_p(1, c2, edge_tag);
+        else compute_t(1, c2, edge_tag);
         __builtin_amdgcn_s_setprio(RCA_CONV_PRIO ? 3 : 2);
         __builtin_amdgcn_sched_barrier(0);
         stage_write_t(0, act_tag);
         __builtin_amdgcn_wave_barrier();
-#if RCA_CONV_PIPE
-        read_head(0);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
+        if constexpr (PIPE) {
+            read_head(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     };
     if (pre & 1) {
@@ -1807,7 +1848,11 @@ static int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B,
     // column tiles multiply the fetches: 32 x 64 in the middle range, 32 x 32 only for small launches.  64x64 stays ahead
     // at 3360 workgroups (k10s5: 1137 vs 1169 us).
     const long waves_big = (long)cdiv(Ncols, 64) * cdiv(L.cout, 64);
+#ifdef RCA_CONV_FORCE_MID   // timing experiment: 32 x 64 wave tiles (3 waves per SIMD) also for the largest launches
+    constexpr long BIG_MIN = 1L << 40, MID_MIN = 2048;
+#else
     constexpr long BIG_MIN = 8192, MID_MIN = 2048;
+#endif
     const FuseIn none{};
     const TrInfo notr{};
     if (fuse) {
