@@ -275,6 +275,9 @@ struct ConvBOff {
 #ifndef RCA_CONV_WPB
 #define RCA_CONV_WPB 1
 #endif
+#ifndef RCA_CONV_OCC
+#define RCA_CONV_OCC 2
+#endif
 #ifndef RCA_CONV_PIPE
 #define RCA_CONV_PIPE 1
 #endif
@@ -287,7 +290,7 @@ struct ConvBOff {
 #define RCA_ABL_BREAD(x) (x)
 #endif
 template <int KS, int S, int CIC, int WM, int WN, int FUSE, int TR>
-__global__ __launch_bounds__(64 * RCA_CONV_WPB, 2) void conv1d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+__global__ __launch_bounds__(64 * RCA_CONV_WPB, ((KS == 8 && CIC == 2) || (KS == 16 && CIC == 1)) ? 3 : RCA_CONV_OCC) void conv1d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           int Cin, int Lin, int Cout, int Lout, long Ncols, int nchunks,
                                                           int pre, float slope, FuseIn fin, TrInfo tr) {
@@ -653,7 +656,7 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, 2) void conv1d_mfma_kernel(const
     if constexpr (PIPE) read_head(0);
     RCA_TL_STAMP(tl1);
 #ifdef RCA_CONV_TIMELINE
-    long tl_load = 0, tl_mfma = 0, tl_write = 0;   // even chunks only: issue of the next loads / MFMA block / activation + LDS write
+    long tl_load = 1 << 30, tl_mfma = 0, tl_write = 0;   // even chunks only: SHORTEST MFMA block / sum of the MFMA blocks / activation + LDS write
 #endif
     const int lastc = nchunks - 1;
     // The whole chunk loop exists twice, with and without the edge selects, and the wave picks one ONCE: a branch per chunk joins
@@ -684,7 +687,7 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, 2) void conv1d_mfma_kernel(const
             __builtin_amdgcn_sched_barrier(0);
         }
         RCA_TL_STAMP(td);
-        RCA_TL_ADD(tl_load, ta, tb); RCA_TL_ADD(tl_mfma, tb, tc); RCA_TL_ADD(tl_write, tc, td);
+        tl_load = (tc - tb) < tl_load ? (tc - tb) : tl_load; RCA_TL_ADD(tl_mfma, tb, tc); RCA_TL_ADD(tl_write, tc, td);
         if (c + 1 >= nchunks) break;
         const int c2 = min(c + 2, lastc);
         stage_load(c2);
@@ -1492,11 +1495,18 @@ struct ConvLayer {
 };
 
 // input channels per K chunk of the MFMA conv, by (kernel size, stride)
+#ifdef RCA_CONV_SMALLCHUNK   // experiment: 16-k chunks (half the weight / staging registers) so that 64 x 64 tiles fit three waves per SIMD
+#define RCA_CIC_K8 2
+#define RCA_CIC_K16 1
+#else
+#define RCA_CIC_K8 4
+#define RCA_CIC_K16 2
+#endif
 static int conv_cic(int k, int s) {
     if (k == 4 && s == 2) return 4;
-    if (k == 8 && s == 4) return 4;
+    if (k == 8 && s == 4) return RCA_CIC_K8;
     if (k == 10 && s == 5) return 4;
-    if (k == 16 && s == 8) return 2;
+    if (k == 16 && s == 8) return RCA_CIC_K16;
     if (k == 3 && s == 1) return 8;
     return 0;
 }
@@ -2002,9 +2012,9 @@ static int run_conv(rca_codec* h, const ConvLayer& L, const float* x, float* y, 
         const int act = ((L.pre && !in_activated) ? 1 : 0) | (want_post ? 2 : 0);
         if (post_done) *post_done = want_post;
         if (L.k == 4 && L.s == 2) return launch_conv_mfma<4, 2, 4>(L, x, y, B, Lin, Lout, slope, st, nullptr, act);
-        if (L.k == 8 && L.s == 4) return launch_conv_mfma<8, 4, 4>(L, x, y, B, Lin, Lout, slope, st, nullptr, act);
+        if (L.k == 8 && L.s == 4) return launch_conv_mfma<8, 4, RCA_CIC_K8>(L, x, y, B, Lin, Lout, slope, st, nullptr, act);
         if (L.k == 10 && L.s == 5) return launch_conv_mfma<10, 5, 4>(L, x, y, B, Lin, Lout, slope, st, nullptr, act);
-        if (L.k == 16 && L.s == 8) return launch_conv_mfma<16, 8, 2>(L, x, y, B, Lin, Lout, slope, st, nullptr, act);
+        if (L.k == 16 && L.s == 8) return launch_conv_mfma<16, 8, RCA_CIC_K16>(L, x, y, B, Lin, Lout, slope, st, nullptr, act);
         if (L.k == 3 && L.s == 1) return launch_conv_mfma<3, 1, 8>(L, x, y, B, Lin, Lout, slope, st, nullptr, act);
     }
     if (in_activated) return fail(RCA_ERR_ARG, "internal: activated input handed to a kernel without that mode");
@@ -2063,8 +2073,8 @@ static int run_encoder(rca_codec* h, RowSrc src, int B, hipStream_t st, float** 
             const int act = (E1.pre ? 1 : 0) | (prev_post ? 2 : 0);
             if (h->variant == 2 && try_conv_ws(E1, nullptr, y, B, L, Lout, slope, st, &fin)) { rc = RCA_OK; RCA_LAUNCH_CHECK(); }
             else if (E1.k == 4) rc = launch_conv_mfma<4, 2, 4>(E1, nullptr, y, B, L, Lout, slope, st, &fin, act);
-            else if (E1.k == 8) rc = launch_conv_mfma<8, 4, 4>(E1, nullptr, y, B, L, Lout, slope, st, &fin, act);
-            else rc = launch_conv_mfma<16, 8, 2>(E1, nullptr, y, B, L, Lout, slope, st, &fin, act);
+            else if (E1.k == 8) rc = launch_conv_mfma<8, 4, RCA_CIC_K8>(E1, nullptr, y, B, L, Lout, slope, st, &fin, act);
+            else rc = launch_conv_mfma<16, 8, RCA_CIC_K16>(E1, nullptr, y, B, L, Lout, slope, st, &fin, act);
         }
         if (rc != RCA_OK) return rc;
         L = Lout;

@@ -55,8 +55,8 @@ def analyse(path):
         T0, T1, T2, T3, HW = sub[:, 0], sub[:, 1], sub[:, 2], sub[:, 3], sub[:, 4]
         nch = (sub[:, 7] >> 32)[0]
         half = (nch + 1) // 2   # stamped chunks (the even ones)
-        ld, mf, wr = (sub[:, 6] & 0xFFFFFFFF) * 0.01 / half, (sub[:, 6] >> 32) * 0.01 / half, (sub[:, 7] & 0xFFFFFFFF) * 0.01 / half
-        print(f"   per chunk ({nch} chunks): issue next loads {np.median(ld):5.2f} (p90 {np.percentile(ld, 90):5.2f})  fragment reads + MFMA block {np.median(mf):5.2f} (p90 {np.percentile(mf, 90):5.2f})"
+        ld, mf, wr = (sub[:, 6] & 0xFFFFFFFF) * 0.01, (sub[:, 6] >> 32) * 0.01 / half, (sub[:, 7] & 0xFFFFFFFF) * 0.01 / half
+        print(f"   per chunk ({nch} chunks): shortest MFMA block of the wave {np.median(ld):5.2f} (p10 {np.percentile(ld, 10):5.2f})  fragment reads + MFMA block {np.median(mf):5.2f} (p10 {np.percentile(mf, 10):5.2f}, p90 {np.percentile(mf, 90):5.2f})"
               f"  activation + LDS write {np.median(wr):5.2f} (p90 {np.percentile(wr, 90):5.2f}) us")
         span = (T3.max() - T0.min()) * 0.01
         pro, loop, epi = (T1 - T0) * 0.01, (T2 - T1) * 0.01, (T3 - T2) * 0.01

@@ -3,7 +3,7 @@ usage: kernel_resources.py <file.hip> [name-substring]"""
 import re, subprocess, sys
 src = sys.argv[1]
 pat = sys.argv[2] if len(sys.argv) > 2 else ""
-out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-c", src, "-o", "/dev/null",
+out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-c", src, "-o", "/dev/null"] + sys.argv[3:] + [
                       "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True).stderr
 name, d = None, {}
 for line in out.splitlines():
