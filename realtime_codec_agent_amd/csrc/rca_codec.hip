@@ -195,9 +195,11 @@ __device__ __forceinline__ rca_rsrc_t rca_make_rsrc(const void* base, int num_re
 __device__ long* rca_prof_buf = nullptr;
 #define RCA_TL_STAMP(v) const long v = tl_buf ? (long)wall_clock64() : 0   // tl_buf: the buffer pointer, read once per wave
 #define RCA_TL_ADD(acc, a, b) acc += (b) - (a)
+#define RCA_TL_MIN(acc, a, b) acc = ((b) - (a)) < acc ? ((b) - (a)) : acc
 #else
 #define RCA_TL_STAMP(v)
 #define RCA_TL_ADD(acc, a, b)
+#define RCA_TL_MIN(acc, a, b)
 #endif
 template <int S>
 struct ConvLds {
@@ -687,7 +689,7 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, ((KS == 8 && CIC == 2) || (KS ==
             __builtin_amdgcn_sched_barrier(0);
         }
         RCA_TL_STAMP(td);
-        tl_load = (tc - tb) < tl_load ? (tc - tb) : tl_load; RCA_TL_ADD(tl_mfma, tb, tc); RCA_TL_ADD(tl_write, tc, td);
+        RCA_TL_MIN(tl_load, tb, tc); RCA_TL_ADD(tl_mfma, tb, tc); RCA_TL_ADD(tl_write, tc, td);
         if (c + 1 >= nchunks) break;
         const int c2 = min(c + 2, lastc);
         stage_load(c2);
