@@ -286,6 +286,9 @@ struct ConvBOff {
 #ifndef RCA_CONV_PRIO
 #define RCA_CONV_PRIO 1
 #endif
+#ifndef RCA_CONV_EPRIO
+#define RCA_CONV_EPRIO 1   // priority of the MFMA blocks (the prologue / epilogue of a wave run at 0)
+#endif
 #ifdef RCA_ABL_NOBREAD   // timing experiment: B fragments from a register instead of LDS
 #define RCA_ABL_BREAD(x) (slope)
 #else
@@ -617,7 +620,7 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, ((KS == 8 && CIC == 2) || (KS ==
             // pipe, finishes, and does its staging while the other has the pipe to itself -- the pair settles into alternation instead of
             // entering and leaving their MFMA blocks together (round-robin issue keeps two waves that started together in lock step:
             // both then stage at the same time and the pipe idles)
-            if (kp == KPC / 4) __builtin_amdgcn_s_setprio(1);
+            if (kp == KPC / 4 && !RCA_CONV_EPRIO) __builtin_amdgcn_s_setprio(1);
             if (kp == KPC / 2) __builtin_amdgcn_s_setprio(2);
             if (kp == 3 * KPC / 4) __builtin_amdgcn_s_setprio(3);
 #endif
@@ -676,7 +679,7 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, ((KS == 8 && CIC == 2) || (KS ==
         stage_load(c1);
         __builtin_amdgcn_sched_barrier(0);
         RCA_TL_STAMP(tb);
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(RCA_CONV_EPRIO);
         if constexpr (PIPE) compute_p(0, c1, edge_tag);
         else compute_t(0, c1, edge_tag);
         __builtin_amdgcn_s_setprio(RCA_CONV_PRIO ? 3 : 2);  // staging phases run at raised priority (measured +2.4 %)
@@ -694,7 +697,7 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, ((KS == 8 && CIC == 2) || (KS ==
         const int c2 = min(c + 2, lastc);
         stage_load(c2);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(RCA_CONV_EPRIO);
         if constexpr (PIPE) compute_p(1, c2, edge_tag);
         else compute_t(1, c2, edge_tag);
         __builtin_amdgcn_s_setprio(RCA_CONV_PRIO ? 3 : 2);
@@ -715,6 +718,9 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, ((KS == 8 && CIC == 2) || (KS ==
         else chunk_loop(std::false_type{}, std::false_type{});
     }
 
+    // prologue and epilogue run below the MFMA blocks: the partner wave's matrix instructions are never queued behind their address
+    // arithmetic and stores
+    if (RCA_CONV_EPRIO) __builtin_amdgcn_s_setprio(0);
     RCA_TL_STAMP(tl2);
     // epilogue: C/D layout col = lane&31 (column), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel).  A store is
     // (wave-uniform row pointer) + (per-lane 32-bit element offset): scalar address arithmetic only.
