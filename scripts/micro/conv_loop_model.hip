@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256, 2) void k(const float* __restrict__ gx, const 
         const long xb = (((long)(tile >> 1) * 4 + wave) * 65536) & xmask;   // 64 KB of input per wave tile, streamed; channel-tile siblings share it
         const f32x4* wq = gw + (long)(tile & 3) * nchunks * 8 * 64 + lane;
         f32x2 sreg[CIC][RE];
+        f32x2 sreg2[CIC][RE];
         f32x4 a[2][4];
         auto load_chunk = [&](int c) {
 #pragma unroll
@@ -72,6 +73,16 @@ __global__ __launch_bounds__(256, 2) void k(const float* __restrict__ gx, const 
                 for (int q = 0; q < 4; ++q) a[wm][q] = wq[(wm * 4 + q) * 64];
             write_chunk(0);
             if (MODE == 1) load_chunk(1);
+            if (MODE == 5) {
+#pragma unroll
+                for (int cl = 0; cl < CIC; ++cl)
+#pragma unroll
+                    for (int r = 0; r < RE; ++r) {
+                        sreg[cl][r] = asm_ld2(gx + ((xb + ((long)(1 * CIC + cl) * 1024) + 2 * lane_el(r)) & xmask));
+                        sreg2[cl][r] = asm_ld2(gx + ((xb + ((long)(2 * CIC + cl) * 1024) + 2 * lane_el(r)) & xmask));
+                    }
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+            }
             if (MODE == 4) {
 #pragma unroll
                 for (int cl = 0; cl < CIC; ++cl)
@@ -159,6 +170,57 @@ __global__ __launch_bounds__(256, 2) void k(const float* __restrict__ gx, const 
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_wave_barrier();
+            } else if (MODE == 5) {
+                // mode 4 with the input loads TWO chunks ahead of their LDS write (two register sets; the loop is unrolled by two so that
+                // every asm load has ONE fixed destination): 20 loads are issued per chunk, so the load a write depends on has 39 younger ones
+                if (c & 1) continue;
+                auto body = [&](int cc, f32x2 (&sr)[CIC][RE]) __attribute__((always_inline)) {
+                    const int bufc = cc & 1;
+                    const float* xrc = xs + bufc * BUF + rd_base;
+                    const f32x4* wnc = wq + (long)((cc + 1) % nchunks) * 8 * 64;
+                    float bv[KPC][2];
+                    auto rd = [&](int kp) {
+                        const int off = (kp >> 2) * 4 * U + ((kp & 3) >> 1) * 2 * U + (kp & 1);
+                        bv[kp][0] = xrc[off];
+                        bv[kp][1] = xrc[off + 32];
+                    };
+#pragma unroll
+                    for (int kp = 0; kp < 4; ++kp) rd(kp);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kp = 0; kp < KPC; ++kp) {
+                        if (kp + 4 < KPC) rd(kp + 4);
+                        if ((kp & 3) == 0) {
+                            if (kp == 12) WAIT_VM(18, "+v"(a[0][3]), "+v"(a[1][3]));
+                            else if (kp == 0) WAIT_VM(14, "+v"(a[0][0]), "+v"(a[1][0]));
+                            else if (kp == 4) WAIT_VM(14, "+v"(a[0][1]), "+v"(a[1][1]));
+                            else WAIT_VM(14, "+v"(a[0][2]), "+v"(a[1][2]));
+                        }
+#pragma unroll
+                        for (int wm = 0; wm < 2; ++wm) {
+                            const f32x4 q4 = a[wm][kp >> 2];
+                            const float av = (kp & 3) == 0 ? q4.x : (kp & 3) == 1 ? q4.y : (kp & 3) == 2 ? q4.z : q4.w;
+#pragma unroll
+                            for (int wn_ = 0; wn_ < 2; ++wn_) acc[wm][wn_] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[kp][wn_], acc[wm][wn_], 0, 0, 0);
+                        }
+                        if (kp < CIC * RE) {
+                            const int cl = kp / RE, r = kp % RE;
+                            float* d = xs + (bufc ^ 1) * BUF + cl * 4 * U + wr_off[r];
+                            WAIT_VM(39, "+v"(sr[cl][r]));
+                            d[0] = sr[cl][r][0];
+                            d[U] = sr[cl][r][1];
+                            sr[cl][r] = asm_ld2(gx + ((xb + ((long)(((cc + 3) % nchunks) * CIC + cl) * 1024) + 2 * lane_el(r)) & xmask));
+                        }
+                        if ((kp & 3) == 3) {
+#pragma unroll
+                            for (int wm = 0; wm < 2; ++wm) a[wm][kp >> 2] = asm_ld4(wnc + (wm * 4 + (kp >> 2)) * 64);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                };
+                body(c, sreg);
+                body(c + 1, sreg2);
             } else if (MODE == 4) {
                 // interleaved, loads in asm with hand-counted waits: 20 loads are issued per chunk (12 x, 8 weight quads)
                 float bv[KPC][2];
@@ -213,12 +275,15 @@ __global__ __launch_bounds__(256, 2) void k(const float* __restrict__ gx, const 
                     }
             }
         }
-        if (MODE == 4) {
+        if (MODE == 4 || MODE == 5) {
             // loads issued by the last chunks are never consumed: their destination registers must stay reserved until they have
             // landed (the compiler does not know they are in flight and would hand the registers out again)
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(sreg[0][0]), "+v"(sreg[0][1]), "+v"(sreg[0][2]), "+v"(sreg[1][0]), "+v"(sreg[1][1]), "+v"(sreg[1][2]),
                          "+v"(sreg[2][0]), "+v"(sreg[2][1]), "+v"(sreg[2][2]), "+v"(sreg[3][0]), "+v"(sreg[3][1]), "+v"(sreg[3][2]) : : "memory");
             asm volatile("" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]));
+            if (MODE == 5)
+                asm volatile("" : "+v"(sreg2[0][0]), "+v"(sreg2[0][1]), "+v"(sreg2[0][2]), "+v"(sreg2[1][0]), "+v"(sreg2[1][1]), "+v"(sreg2[1][2]),
+                             "+v"(sreg2[2][0]), "+v"(sreg2[2][1]), "+v"(sreg2[2][2]), "+v"(sreg2[3][0]), "+v"(sreg2[3][1]), "+v"(sreg2[3][2]));
         }
         // epilogue stand-in: one store per lane per tile, depending on every accumulator
         float s = 0;
@@ -385,6 +450,10 @@ int main(int argc, char** argv) {
     hipMalloc(&out, (1 << 20) * 4 + 4096);
     const long xmask = xfloats - 1;
     if (only4) {
+        run<5>(1, 16, "il asm 2-ahead", gx, gw, out, xmask);
+        run<5>(2, 16, "il asm 2-ahead", gx, gw, out, xmask);
+        run<5>(1, 64, "il asm 2-ahead", gx, gw, out, xmask);
+        run<5>(2, 64, "il asm 2-ahead", gx, gw, out, xmask);
         run<4>(1, 16, "il asm-wait", gx, gw, out, xmask);
         run<4>(2, 16, "il asm-wait", gx, gw, out, xmask);
         run<4>(1, 64, "il asm-wait", gx, gw, out, xmask);
