@@ -179,6 +179,8 @@ typedef int rca_rsrc_t __attribute__((ext_vector_type(4)));
 typedef float rca_f32x2_t __attribute__((ext_vector_type(2)));
 __device__ float rca_buffer_load_f32(rca_rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 __device__ rca_f32x2_t rca_buffer_load_f32x2(rca_rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+typedef float rca_f32x4_t __attribute__((ext_vector_type(4)));
+__device__ rca_f32x4_t rca_buffer_load_f32x4(rca_rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 __device__ __forceinline__ rca_rsrc_t rca_make_rsrc(const void* base, int num_records) {   // base must be wave-uniform
     const unsigned long a = (unsigned long)base;
     rca_rsrc_t r;
@@ -285,6 +287,9 @@ struct ConvBOff {
 #endif
 #ifndef RCA_CONV_PRIO
 #define RCA_CONV_PRIO 1
+#endif
+#ifndef RCA_CONV_ABUF
+#define RCA_CONV_ABUF 1   // weight refills as buffer loads with scalar offsets
 #endif
 #ifndef RCA_CONV_EPRIO
 #define RCA_CONV_EPRIO 1   // priority of the MFMA blocks (the prologue / epilogue of a wave run at 0)
@@ -537,6 +542,15 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, ((KS == 8 && CIC == 2) || (KS ==
 
     const long kquads = (long)nchunks * QPC;
     // A fragments (weights), pre-packed in fragment order: quad q of chunk c for 32-row tile wm
+    // weight quads through a buffer descriptor over this wave's first 32-row tile: the lane part of the address is one constant
+    // VGPR (lane * 16), everything else -- 32-row tile, chunk, quad -- is scalar (SALU soffset + immediate), so a refill costs no
+    // vector address arithmetic.  (The pointer form below adds 64-bit offsets per load on the VALU.)
+    const rca_rsrc_t rs_w = rca_make_rsrc(reinterpret_cast<const float4*>(wp) + ((long)((TR ? phase * tr.n_co : 0) + co_tile * WM) * kquads) * 64, 0x7FFFFFFF);
+    const int w_lane = lane * 16;
+    auto w_load = [&](int wm, int c, int q) __attribute__((always_inline)) {
+        const rca_f32x4_t v = rca_buffer_load_f32x4(rs_w, w_lane, (int)(((long)wm * kquads + (long)c * QPC + q) * 1024), 0);
+        return make_float4(v[0], v[1], v[2], v[3]);
+    };
     auto w_ptr = [&](int wm, int c) {
         const int cot = (TR ? phase * tr.n_co : 0) + co_tile * WM + wm;   // TR: tr.n_co 32-row tiles per phase
         return reinterpret_cast<const float4*>(wp) + ((long)cot * kquads + (long)c * QPC) * 64 + lane;
@@ -579,7 +593,7 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, ((KS == 8 && CIC == 2) || (KS ==
                 }
                 if ((kp & 3) == 3) {
 #pragma unroll
-                    for (int wm = 0; wm < WM; ++wm) a[wm][kp >> 2] = pn[wm][(kp >> 2) * 64];
+                    for (int wm = 0; wm < WM; ++wm) a[wm][kp >> 2] = RCA_CONV_ABUF ? w_load(wm, cn, kp >> 2) : pn[wm][(kp >> 2) * 64];
                 }
             }
         }
@@ -642,7 +656,7 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, ((KS == 8 && CIC == 2) || (KS ==
 #ifndef RCA_ABL_NOAREFILL   // (timing experiment when defined: the weights of chunk 0 are reused)
             if ((kp & 3) == 3) {
 #pragma unroll
-                for (int wm = 0; wm < WM; ++wm) a[wm][kp >> 2] = pn[wm][(kp >> 2) * 64];
+                for (int wm = 0; wm < WM; ++wm) a[wm][kp >> 2] = RCA_CONV_ABUF ? w_load(wm, cn, kp >> 2) : pn[wm][(kp >> 2) * 64];
             }
 #endif
             __builtin_amdgcn_sched_barrier(0);
@@ -654,7 +668,7 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, ((KS == 8 && CIC == 2) || (KS ==
     for (int wm = 0; wm < WM; ++wm) {
         const float4* p0 = w_ptr(wm, 0);
 #pragma unroll
-        for (int q = 0; q < QPC; ++q) a[wm][q] = p0[q * 64];
+        for (int q = 0; q < QPC; ++q) a[wm][q] = RCA_CONV_ABUF ? w_load(wm, 0, q) : p0[q * 64];
     }
     stage_write(0);
     __builtin_amdgcn_wave_barrier();
