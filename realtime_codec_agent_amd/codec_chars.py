@@ -29,13 +29,15 @@ def codes_to_chars(codes, codebook_size: int, copy_before_conversion: bool = Tru
         raise ValueError("code out of range")
     offs = (np.arange(codes.shape[0], dtype=np.int64) * codebook_size + unicode_offset)[:, None]
     cps = (codes.astype(np.int64) + offs).T.reshape(-1)
-    return "".join(map(chr, cps.tolist()))
+    # one vectorised conversion instead of a chr() per code (this runs on every frame of the duplex loop); "surrogatepass" keeps
+    # the code points of the small offset that fall into U+D800..DFFF, which chr() also produces
+    return cps.astype("<u4").tobytes().decode("utf-32-le", "surrogatepass")
 
 
 def chars_to_codes(chars: str, num_codebooks: int, codebook_size: int, return_tensors: Union[str, None] = None,
                    unicode_offset: int = UNICODE_OFFSET_LARGE):
     """str -> codes [num_codebooks, T]; trailing chars that do not fill a frame are dropped."""
-    cps = np.fromiter((ord(c) for c in chars), dtype=np.int64, count=len(chars))
+    cps = np.frombuffer(chars.encode("utf-32-le", "surrogatepass"), dtype="<u4").astype(np.int64)
     T = len(cps) // num_codebooks
     cps = cps[: T * num_codebooks].reshape(T, num_codebooks).T
     offs = (np.arange(num_codebooks, dtype=np.int64) * codebook_size + unicode_offset)[:, None]
