@@ -422,48 +422,6 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, ((KS == 8 && CIC == 2) || (KS ==
             }
         }
     }
-    // ---- B-read role: per k-pair LDS offset and edge masks for this lane's half
-    typedef ConvBOff<KS, S, TR> BO;    // TR: tap 0 reads x[t0], tap 1 reads x[t0-1]
-    static_assert(BO::count(KPC, U) <= 3, "B-operand base registers");
-    constexpr int BD0 = BO::distinct(0, KPC, U), BD1 = BO::distinct(1, KPC, U), BD2 = BO::distinct(2, KPC, U);
-    const int b_base0 = (lane & 31) + half * BD0, b_base1 = (lane & 31) + half * BD1, b_base2 = (lane & 31) + half * BD2;
-    auto b_off = [&](int kp) __attribute__((always_inline)) {   // kp is a constant after unrolling: one of the bases + an immediate
-        const int dl = BO::delta(kp, U);
-        return (dl == BD0 ? b_base0 : dl == BD1 ? b_base1 : b_base2) + BO::off(kp, 0, U);
-    };
-    unsigned m_first = 0, m_last = 0;  // bit kp: the read reaches into the previous / next column
-#pragma unroll
-    for (int kp = 0; kp < KPC; ++kp) {
-        const int q = half ? BO::q_of(kp, 1) : BO::q_of(kp, 0);
-        if (q < 0) m_first |= 1u << kp;
-        if (q > 0) m_last |= 1u << kp;
-    }
-    unsigned zmask[WN];
-    unsigned zany = 0;
-#pragma unroll
-    for (int wn = 0; wn < WN; ++wn) {
-        int bz, t;
-        rel_bt(1 - lead + wn * 32 + (lane & 31), bz, t);
-        zmask[wn] = (t == 0 ? m_first : 0u) | (t == Lout - 1 ? m_last : 0u);
-        zany |= zmask[wn];
-    }
-    // most waves hold no row edge: they run the MFMA block without the per-fragment edge selects
-    const bool edges = __builtin_amdgcn_ballot_w64(zany != 0) != 0;
-
-    // accumulators start at the bias; `bias` is padded to whole channel tiles, rows past Cout are never stored
-    f32x16 acc[WM][WN];
-#pragma unroll
-    for (int wm = 0; wm < WM; ++wm) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 bq = *reinterpret_cast<const f32x4*>(bias + co0 + wm * 32 + 8 * q + 4 * half);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int wn = 0; wn < WN; ++wn) acc[wm][wn][4 * q + j] = bq[j];
-        }
-    }
-
     float sreg[CIC][RE][PW];
     auto stage_load = [&](int c) {
 #pragma unroll
@@ -509,6 +467,75 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, ((KS == 8 && CIC == 2) || (KS ==
             }
         }
     };
+    const long kquads = (long)nchunks * QPC;
+    // A fragments (weights), pre-packed in fragment order: quad q of chunk c for 32-row tile wm
+    // weight quads through a buffer descriptor over this wave's first 32-row tile: the lane part of the address is one constant
+    // VGPR (lane * 16), everything else -- 32-row tile, chunk, quad -- is scalar (SALU soffset + immediate), so a refill costs no
+    // vector address arithmetic.  (The pointer form below adds 64-bit offsets per load on the VALU.)
+    const rca_rsrc_t rs_w = rca_make_rsrc(reinterpret_cast<const float4*>(wp) + ((long)((TR ? phase * tr.n_co : 0) + co_tile * WM) * kquads) * 64, 0x7FFFFFFF);
+    const int w_lane = lane * 16;
+    auto w_load = [&](int wm, int c, int q) __attribute__((always_inline)) {
+        const rca_f32x4_t v = rca_buffer_load_f32x4(rs_w, w_lane, (int)(((long)wm * kquads + (long)c * QPC + q) * 1024), 0);
+        return make_float4(v[0], v[1], v[2], v[3]);
+    };
+    auto w_ptr = [&](int wm, int c) {
+        const int cot = (TR ? phase * tr.n_co : 0) + co_tile * WM + wm;   // TR: tr.n_co 32-row tiles per phase
+        return reinterpret_cast<const float4*>(wp) + ((long)cot * kquads + (long)c * QPC) * 64 + lane;
+    };
+    float4 a[WM][QPC];
+    // The first chunk's input loads and weight quads go out before the rest of the prologue (B-read offsets, edge masks, bias): that
+    // arithmetic then runs under their memory latency instead of in front of it.  (Fused first layer: its staged values are computed
+    // from the PCM window requested above, so only the weights can be requested here.)
+    if (!FUSE) stage_load(0);
+#pragma unroll
+    for (int wm = 0; wm < WM; ++wm) {
+        const float4* p0 = w_ptr(wm, 0);
+#pragma unroll
+        for (int q = 0; q < QPC; ++q) a[wm][q] = RCA_CONV_ABUF ? w_load(wm, 0, q) : p0[q * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- B-read role: per k-pair LDS offset and edge masks for this lane's half
+    typedef ConvBOff<KS, S, TR> BO;    // TR: tap 0 reads x[t0], tap 1 reads x[t0-1]
+    static_assert(BO::count(KPC, U) <= 3, "B-operand base registers");
+    constexpr int BD0 = BO::distinct(0, KPC, U), BD1 = BO::distinct(1, KPC, U), BD2 = BO::distinct(2, KPC, U);
+    const int b_base0 = (lane & 31) + half * BD0, b_base1 = (lane & 31) + half * BD1, b_base2 = (lane & 31) + half * BD2;
+    auto b_off = [&](int kp) __attribute__((always_inline)) {   // kp is a constant after unrolling: one of the bases + an immediate
+        const int dl = BO::delta(kp, U);
+        return (dl == BD0 ? b_base0 : dl == BD1 ? b_base1 : b_base2) + BO::off(kp, 0, U);
+    };
+    unsigned m_first = 0, m_last = 0;  // bit kp: the read reaches into the previous / next column
+#pragma unroll
+    for (int kp = 0; kp < KPC; ++kp) {
+        const int q = half ? BO::q_of(kp, 1) : BO::q_of(kp, 0);
+        if (q < 0) m_first |= 1u << kp;
+        if (q > 0) m_last |= 1u << kp;
+    }
+    unsigned zmask[WN];
+    unsigned zany = 0;
+#pragma unroll
+    for (int wn = 0; wn < WN; ++wn) {
+        int bz, t;
+        rel_bt(1 - lead + wn * 32 + (lane & 31), bz, t);
+        zmask[wn] = (t == 0 ? m_first : 0u) | (t == Lout - 1 ? m_last : 0u);
+        zany |= zmask[wn];
+    }
+    // most waves hold no row edge: they run the MFMA block without the per-fragment edge selects
+    const bool edges = __builtin_amdgcn_ballot_w64(zany != 0) != 0;
+
+    // accumulators start at the bias; `bias` is padded to whole channel tiles, rows past Cout are never stored
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int wm = 0; wm < WM; ++wm) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(bias + co0 + wm * 32 + 8 * q + 4 * half);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int wn = 0; wn < WN; ++wn) acc[wm][wn][4 * q + j] = bq[j];
+        }
+    }
+
     // pre-activation applied here (ACT) unless the layer that produced x already stored activated values
     auto stage_write_t = [&](int buf, auto act_tag) __attribute__((always_inline)) {
         constexpr bool ACT = decltype(act_tag)::value;
@@ -540,22 +567,6 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, ((KS == 8 && CIC == 2) || (KS ==
         else stage_write_t(buf, std::false_type{});
     };
 
-    const long kquads = (long)nchunks * QPC;
-    // A fragments (weights), pre-packed in fragment order: quad q of chunk c for 32-row tile wm
-    // weight quads through a buffer descriptor over this wave's first 32-row tile: the lane part of the address is one constant
-    // VGPR (lane * 16), everything else -- 32-row tile, chunk, quad -- is scalar (SALU soffset + immediate), so a refill costs no
-    // vector address arithmetic.  (The pointer form below adds 64-bit offsets per load on the VALU.)
-    const rca_rsrc_t rs_w = rca_make_rsrc(reinterpret_cast<const float4*>(wp) + ((long)((TR ? phase * tr.n_co : 0) + co_tile * WM) * kquads) * 64, 0x7FFFFFFF);
-    const int w_lane = lane * 16;
-    auto w_load = [&](int wm, int c, int q) __attribute__((always_inline)) {
-        const rca_f32x4_t v = rca_buffer_load_f32x4(rs_w, w_lane, (int)(((long)wm * kquads + (long)c * QPC + q) * 1024), 0);
-        return make_float4(v[0], v[1], v[2], v[3]);
-    };
-    auto w_ptr = [&](int wm, int c) {
-        const int cot = (TR ? phase * tr.n_co : 0) + co_tile * WM + wm;   // TR: tr.n_co 32-row tiles per phase
-        return reinterpret_cast<const float4*>(wp) + ((long)cot * kquads + (long)c * QPC) * 64 + lane;
-    };
-    float4 a[WM][QPC];
     // One chunk of MFMAs.  ONE set of weight fragments: as soon as the last k pair of quad q has been issued, the same
     // registers are refilled with quad q of chunk `cn` (a full chunk of MFMAs, ~2 us, ahead of their next use), so the
     // weights cost QPC x WM x 4 registers instead of twice that.
@@ -663,13 +674,7 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, ((KS == 8 && CIC == 2) || (KS ==
         }
     };
 
-    stage_load(0);
-#pragma unroll
-    for (int wm = 0; wm < WM; ++wm) {
-        const float4* p0 = w_ptr(wm, 0);
-#pragma unroll
-        for (int q = 0; q < QPC; ++q) a[wm][q] = RCA_CONV_ABUF ? w_load(wm, 0, q) : p0[q * 64];
-    }
+    if (FUSE) stage_load(0);
     stage_write(0);
     __builtin_amdgcn_wave_barrier();
     if constexpr (PIPE) read_head(0);
