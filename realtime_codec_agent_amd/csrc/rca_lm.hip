@@ -2078,7 +2078,11 @@ template <int EPI>
 __global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __restrict__ stt, const bf16_t* __restrict__ W,
                                                             const bf16_t* __restrict__ xh, const bf16_t* __restrict__ xl, int N, int K,
                                                             int kslice, float* __restrict__ y, int ldy, bf16_t* __restrict__ oh,
-                                                            bf16_t* __restrict__ ol, float* __restrict__ part, GemvRope rope) {
+                                                            bf16_t* __restrict__ ol, float* __restrict__ part, GemvRope rope, int nseq) {
+    // nseq > 1: this workgroup walks nseq consecutive k slices itself.  Each slice is summed into a fresh accumulator and that is
+    // added to a running total -- exactly the additions, in exactly the order, of "every slice its own workgroup, then
+    // lm_gemm128_epilogue_kernel adds the partial sums starting from 0" -- so the result does not depend on which of the two forms a
+    // pass used, and the partial sums never travel through HBM.  Used where the token blocks alone fill the chip.
     extern __shared__ __attribute__((aligned(16))) bf16_t g128_lds[];   // [2 buffers][W, xh, xl][128 rows][G128_PITCH]
     typedef bf16_t tile_t[3][128 * G128_PITCH];
     tile_t* sm = reinterpret_cast<tile_t*>(g128_lds);
@@ -2088,10 +2092,11 @@ __global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int n0 = blockIdx.x * 128;
-    const int ks = blockIdx.y * kslice;
+    const int ks = blockIdx.y * nseq * kslice;
     const int tb = blockIdx.z * 128;   // token block of this workgroup: a pass holds up to LM_MAXM / 128 of them, the weights are
                                        // fetched from HBM by the first and served from L2 / Infinity Cache to the others
-    const int nstage = kslice >> 5;
+    const int spf = kslice >> 5;          // stages per slice
+    const int nstage = nseq * spf;
     // staging role: two 16-byte chunks per tile and thread: rows c >> 2, k offset (c & 3) * 8
     const int srow0 = tid >> 2, skc = (tid & 3) * 8;
     const bf16_t* gW = W + (long)(n0 + srow0) * K + ks + skc;
@@ -2118,13 +2123,13 @@ __global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __
         *reinterpret_cast<uint4*>(&sm[buf][1][soff0]) = rh[xs][0]; *reinterpret_cast<uint4*>(&sm[buf][1][soff1]) = rh[xs][1];
         *reinterpret_cast<uint4*>(&sm[buf][2][soff0]) = rl[xs][0]; *reinterpret_cast<uint4*>(&sm[buf][2][soff1]) = rl[xs][1];
     };
-    f32x16 acc[2][2];
+    f32x16 acc[2][2], tot[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; tot[i][j][r] = 0.0f; }
     // fragment read offsets: row (lane & 31) of the 32-row tile, k offset 8 * half inside a 16-k substep
     const int fa = (wr * 64 + (lane & 31)) * G128_PITCH + 8 * half;
     const int fb = (wc * 64 + (lane & 31)) * G128_PITCH + 8 * half;
@@ -2161,9 +2166,26 @@ __global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
                     }
             }
+            if (nseq > 1 && (s + 1) % spf == 0) {   // end of a slice: fold it into the running total (0 + p0, then + p1, ...)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            tot[i][j][r] = tot[i][j][r] + acc[i][j][r];
+                            acc[i][j][r] = 0.0f;
+                        }
+            }
             if (s + 1 < nstage) swrite(buf ^ 1, (d + 1) % DW, (d + 1) % DX);
             __syncthreads();
         }
+    }
+    if (nseq > 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = tot[i][j];
     }
     // epilogue.  C layout: token = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * half inside a 32 x 32 tile
     const int Mv = stt->m;
@@ -2356,6 +2378,12 @@ static int lm_enqueue_prefill_tile128(rca_lm* h, int M, hipStream_t st, int nsp_
     const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     const int sq = g128_splits(QKV, H), so = g128_splits(H, AO), sg = g128_splits(2 * F, H), sd = g128_splits(H, F);
     const int tbz = cdiv(M, 128);   // token blocks of this pass
+    // A projection whose token blocks alone put `seq_min` workgroups on the chip is run with every workgroup walking the k slices itself
+    // (same sums in the same order, no partial sums through HBM, no epilogue launch); RCA_LM_SEQ_MIN_WGS overrides the threshold
+    // (0 = never) for A/B runs.
+    static const int seq_min = getenv("RCA_LM_SEQ_MIN_WGS") ? atoi(getenv("RCA_LM_SEQ_MIN_WGS")) : 512;
+    auto seq = [&](int N, int ns) { return ns > 1 && seq_min > 0 && (N / 128) * tbz >= seq_min; };
+    const bool q_seq = seq(QKV, sq), o_seq = seq(H, so), gu_seq = seq(2 * F, sg), d_seq = seq(H, sd);
     float* x = h->x;
     lm_embed_kernel<<<M, 256, 0, st>>>(h->stt, h->embed, x, H, c.vocab_size);
     for (int l = 0; l < c.n_layers; ++l) {
@@ -2364,20 +2392,24 @@ static int lm_enqueue_prefill_tile128(rca_lm* h, int M, hipStream_t st, int nsp_
         f16_t* vc = h->vc + (long)l * h->kv_layer_stride;
         rope.kc = kc; rope.vc = vc;
         lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.attn_norm, h->xn, H, c.rms_eps, h->xh, h->xl);
-        lm_gemm128_kernel<GEMM_EPI_ROPE><<<dim3(QKV / 128, sq, tbz), 256, G128_LDS, st>>>(h->stt, L.wqkv, h->xh, h->xl, QKV, H, H / sq, h->qkv, QKV, nullptr, nullptr, h->gpart, rope);
-        if (sq > 1) lm_gemm128_epilogue_kernel<GEMM_EPI_ROPE><<<dim3(QKV / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sq, QKV, h->qkv, nullptr, nullptr, rope);
+        lm_gemm128_kernel<GEMM_EPI_ROPE><<<dim3(QKV / 128, q_seq ? 1 : sq, tbz), 256, G128_LDS, st>>>(h->stt, L.wqkv, h->xh, h->xl, QKV, H, H / sq, h->qkv, QKV, nullptr, nullptr, h->gpart, rope, q_seq ? sq : 1);
+        if (sq > 1 && !q_seq) lm_gemm128_epilogue_kernel<GEMM_EPI_ROPE><<<dim3(QKV / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sq, QKV, h->qkv, nullptr, nullptr, rope);
         launch_attention_mfma(h, M, nsp_launch, kc, vc, st, h->xh, h->xl);
-        lm_gemm128_kernel<GEMM_EPI_RESID><<<dim3(H / 128, so, tbz), 256, G128_LDS, st>>>(h->stt, L.wo, h->xh, h->xl, H, AO, AO / so, x, H, nullptr, nullptr, h->gpart, norope);
-        if (so > 1) lm_gemm128_epilogue_kernel<GEMM_EPI_RESID><<<dim3(H / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, so, H, x, nullptr, nullptr, norope);
+        lm_gemm128_kernel<GEMM_EPI_RESID><<<dim3(H / 128, o_seq ? 1 : so, tbz), 256, G128_LDS, st>>>(h->stt, L.wo, h->xh, h->xl, H, AO, AO / so, x, H, nullptr, nullptr, h->gpart, norope, o_seq ? so : 1);
+        if (so > 1 && !o_seq) lm_gemm128_epilogue_kernel<GEMM_EPI_RESID><<<dim3(H / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, so, H, x, nullptr, nullptr, norope);
         lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.ffn_norm, h->xn, H, c.rms_eps, h->xh, h->xl);
         // SwiGLU epilogue writes the hi/lo split of h straight into the (ffn-wide) split buffers of the down projection:
         // it reads xh/xl [M][H] and writes [M][F] -- distinct regions are needed, so h goes to the second half of hbuf
         bf16_t* hh = reinterpret_cast<bf16_t*>(h->hbuf);
         bf16_t* hl = hh + (long)LM_MAXM * F;
-        lm_gemm128_kernel<GEMM_EPI_SWIGLU><<<dim3(2 * F / 128, sg, tbz), 256, G128_LDS, st>>>(h->stt, L.wgu, h->xh, h->xl, 2 * F, H, H / sg, nullptr, F, hh, hl, h->gpart, norope);
-        if (sg > 1) lm_gemm128_epilogue_kernel<GEMM_EPI_SWIGLU><<<dim3(2 * F / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sg, 2 * F, nullptr, hh, hl, norope);
-        lm_gemm128_kernel<GEMM_EPI_RESID><<<dim3(H / 128, sd, tbz), 256, G128_LDS, st>>>(h->stt, L.wdown, hh, hl, H, F, F / sd, x, H, nullptr, nullptr, h->gpart, norope);
-        if (sd > 1) lm_gemm128_epilogue_kernel<GEMM_EPI_RESID><<<dim3(H / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sd, H, x, nullptr, nullptr, norope);
+        if (gu_seq) {   // the token blocks alone fill the chip: every workgroup walks the slices itself (same sums, same order, no partials)
+            lm_gemm128_kernel<GEMM_EPI_SWIGLU><<<dim3(2 * F / 128, 1, tbz), 256, G128_LDS, st>>>(h->stt, L.wgu, h->xh, h->xl, 2 * F, H, H / sg, nullptr, F, hh, hl, h->gpart, norope, sg);
+        } else {
+            lm_gemm128_kernel<GEMM_EPI_SWIGLU><<<dim3(2 * F / 128, sg, tbz), 256, G128_LDS, st>>>(h->stt, L.wgu, h->xh, h->xl, 2 * F, H, H / sg, nullptr, F, hh, hl, h->gpart, norope, 1);
+            if (sg > 1) lm_gemm128_epilogue_kernel<GEMM_EPI_SWIGLU><<<dim3(2 * F / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sg, 2 * F, nullptr, hh, hl, norope);
+        }
+        lm_gemm128_kernel<GEMM_EPI_RESID><<<dim3(H / 128, d_seq ? 1 : sd, tbz), 256, G128_LDS, st>>>(h->stt, L.wdown, hh, hl, H, F, F / sd, x, H, nullptr, nullptr, h->gpart, norope, d_seq ? sd : 1);
+        if (sd > 1 && !d_seq) lm_gemm128_epilogue_kernel<GEMM_EPI_RESID><<<dim3(H / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sd, H, x, nullptr, nullptr, norope);
     }
     RCA_LAUNCH_CHECK();
     return RCA_OK;
