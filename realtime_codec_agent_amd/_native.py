@@ -123,7 +123,31 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc] + HIPCC_FLAGS + extra + sources() + ["-o", LIB_PATH + ".tmp"]
+    # one object per source, compiled side by side and kept under csrc/.obj (keyed by the flags): editing one kernel file
+    # recompiles that file only; `force` recompiles everything
+    import hashlib
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + extra
+    key = hashlib.sha1(" ".join([hipcc] + cflags).encode()).hexdigest()[:10]
+    obj_dir = os.path.join(CSRC_DIR, ".obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    headers = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(_PKG_DIR), "include", "rca.h"))
+    hdr_t = max([os.path.getmtime(p) for p in headers if os.path.exists(p)] + [0.0])
+    objs, jobs = [], []
+    for src in sources():
+        obj = os.path.join(obj_dir, f"{os.path.splitext(os.path.basename(src))[0]}.{key}.o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            cmd = [hipcc] + cflags + ["-c", src, "-o", obj + ".tmp"]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((subprocess.Popen(cmd), cmd, obj))
+    failed = [cmd for p, cmd, _ in jobs if p.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
+    for _, _, obj in jobs:
+        os.replace(obj + ".tmp", obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -134,19 +134,19 @@ class HipWindowEncoder:
         self.cfg = self.model.cfg
 
     def encode_many(self, audios: Sequence[np.ndarray], chunk: int, ctx: int, batch_windows: int):
-        """audios: float32 [C, N_f] per file (same C).  -> (pinned host int64 codes [total], [(a, b)] slice of every (file, channel) row,
-        wait()) -- wait() blocks until the codes have landed in the host buffer.  Everything up to the D2H copy is enqueued
-        asynchronously, so the caller can prepare the next super-batch while this one runs."""
+        """audios: float32 [C_f, N_f] per file (a --stereo corpus may mix mono and stereo files: every file brings its own
+        channel count).  -> (pinned host int64 codes [total], [(a, b)] slice of every (file, channel) row, wait()) -- wait()
+        blocks until the codes have landed in the host buffer.  Everything up to the D2H copy is enqueued asynchronously, so the
+        caller can prepare the next super-batch while this one runs."""
         torch, hip = self.torch, self.model.hip
-        C = audios[0].shape[0]
         W = max(chunk, ctx)
         fpc = hip.frames_per_chunk(chunk)
-        lengths = [a.shape[-1] for a in audios]
+        lengths = [a.shape[-1] for a in audios for _ in range(a.shape[0])]      # one entry per (file, channel) row
         # one pinned staging buffer, rows back to back (file-major, channel-minor), each start aligned to 4 samples
-        row_len = [((n + 3) // 4) * 4 for n in lengths for _ in range(C)]
+        row_len = [((n + 3) // 4) * 4 for n in lengths]
         src_base = np.concatenate([[0], np.cumsum(row_len)[:-1]]).astype(np.int64)
         total = int(sum(row_len))
-        n_codes = [(n // chunk) * fpc for n in lengths for _ in range(C)]
+        n_codes = [(n // chunk) * fpc for n in lengths]
         dst_base = np.concatenate([[0], np.cumsum(n_codes)[:-1]]).astype(np.int64)
         total_codes = int(sum(n_codes))
         slices = [(int(b), int(b + n)) for b, n in zip(dst_base, n_codes)]
@@ -154,10 +154,10 @@ class HipWindowEncoder:
         sv = stage.numpy()
         r = 0
         for a in audios:
-            for c in range(C):
+            for c in range(a.shape[0]):
                 sv[src_base[r]:src_base[r] + a.shape[-1]] = a[c]
                 r += 1
-        T, src, dst = window_table(lengths, C, chunk, W, fpc, src_base, dst_base)
+        T, src, dst = window_table(lengths, chunk, W, fpc, src_base, dst_base)
         host_codes = torch.empty(max(total_codes, 1), dtype=torch.int64).pin_memory()
         if len(T) == 0:
             return host_codes.numpy()[:0], slices, (lambda: None)
@@ -202,14 +202,14 @@ class HipWindowEncoder:
         return out.cpu().numpy()
 
 
-def window_table(lengths: Sequence[int], channels: int, chunk: int, W: int, fpc: int, src_base: Sequence[int], dst_base: Sequence[int]):
-    """Every window of every (file, channel) row of a super-batch.  Row r (file-major, channel-minor) holds lengths[r // channels]
+def window_table(lengths: Sequence[int], chunk: int, W: int, fpc: int, src_base: Sequence[int], dst_base: Sequence[int]):
+    """Every window of every (file, channel) row of a super-batch.  Row r (file-major, channel-minor) holds lengths[r]
     samples at element offset src_base[r]; its codes start at dst_base[r].  Chunk i of a row is encoded from the window of
     T_i = min((i + 1) * chunk, W) samples ending at (i + 1) * chunk (the rolling context of audio_tokenizer.py:72-74) and keeps its
     last fpc codes.  -> (T [n], src_off [n], dst_off [n]) int64, sorted by T descending (full windows first), stable."""
     Ts, srcs, dsts = [], [], []
     for r, (sb, db) in enumerate(zip(src_base, dst_base)):
-        n_chunks = lengths[r // channels] // chunk
+        n_chunks = lengths[r] // chunk
         if n_chunks == 0:
             continue
         end = (np.arange(n_chunks, dtype=np.int64) + 1) * chunk
@@ -324,6 +324,8 @@ def encode_files_pipelined(files: Sequence[str], encoder, args, rank: int = 0) -
             audios = [a for _, a in group]
             host_codes, slices, wait = encoder.encode_many(audios, chunk, ctx, args.batch_size)
             names = [(os.path.splitext(os.path.relpath(p, args.audio_path))[0], c) for p, a in group for c in range(a.shape[0])]
+            if len(names) != len(slices):
+                raise RuntimeError(f"encode_many returned {len(slices)} code rows for {len(names)} (file, channel) rows")
             done.put((names, wait, host_codes, slices))
             totals[0] += sum(a.shape[-1] for a in audios) / sr
             totals[1] += int(sum(b - a for a, b in slices))

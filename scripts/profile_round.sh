@@ -4,6 +4,7 @@
 TAG=${1:-r01}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
+rm -rf $OUT   # a fresh directory per run: nothing of an earlier run can be picked up
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. kernel trace + stats of the headline bench command (batch encode + duplex leg)

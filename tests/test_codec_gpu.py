@@ -366,6 +366,9 @@ def test_batch_cli_cross_file_pipeline_equals_per_file_loop(tmp_path):
         with wave.open(p, "wb") as w:
             w.setnchannels(2); w.setsampwidth(2); w.setframerate(16000)
             w.writeframes((np.clip(sig.T, -1, 1) * 32767).astype("<i2").tobytes())
+    with wave.open(os.path.join(raw, "f2b_mono.wav"), "wb") as w:      # a mono file in the middle of a --stereo corpus
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes((np.clip(rich_signal(16000 * 2 + 300, 77), -1, 1) * 32767).astype("<i2").tobytes())
 
     def tree(root):
         out = {}
@@ -381,7 +384,7 @@ def test_batch_cli_cross_file_pipeline_equals_per_file_loop(tmp_path):
             s1 = audio_to_codes.main(["--audio_path", raw, "--codes_path", a, "--one_file_at_a_time"] + extra + stereo)
             s2 = audio_to_codes.main(["--audio_path", raw, "--codes_path", b, "--super_batch_samples", "200000"] + extra + stereo)
             ta, tb = tree(a), tree(b)
-            assert ta.keys() == tb.keys() and len(ta) == 1 + (2 if stereo else 1) * 6
+            assert ta.keys() == tb.keys() and len(ta) == 1 + (2 if stereo else 1) * 6 + 1
             bad = [k for k in ta if ta[k] != tb[k]]
             assert not bad, bad
             assert s1["codes"] == s2["codes"] > 0

@@ -182,14 +182,13 @@ class _OracleRowsEncoder:
 
     def encode_many(self, audios, chunk, ctx, batch_windows):
         from realtime_codec_agent_amd.audio_to_codes import window_table
-        C = audios[0].shape[0]
         W, fpc = max(chunk, ctx), int((chunk / self.cfg.sample_rate) * self.cfg.framerate)
-        lengths = [a.shape[-1] for a in audios]
-        src_base = np.cumsum([0] + [n for n in lengths for _ in range(C)])[:-1]
-        n_codes = [(n // chunk) * fpc for n in lengths for _ in range(C)]
+        lengths = [a.shape[-1] for a in audios for _ in range(a.shape[0])]
+        src_base = np.cumsum([0] + lengths)[:-1]
+        n_codes = [(n // chunk) * fpc for n in lengths]
         dst_base = np.cumsum([0] + n_codes)[:-1]
-        flat = np.concatenate([a[c] for a in audios for c in range(C)])
-        T, src, dst = window_table(lengths, C, chunk, W, fpc, src_base, dst_base)
+        flat = np.concatenate([a[c] for a in audios for c in range(a.shape[0])])
+        T, src, dst = window_table(lengths, chunk, W, fpc, src_base, dst_base)
         out = np.full(int(sum(n_codes)), -1, np.int64)
         i = 0
         while i < len(T):
@@ -240,3 +239,17 @@ def test_cross_file_batching_writes_the_same_tree(tmp_path):
     d = audio_to_codes.main(["--audio_path", raw, "--codes_path", os.path.join(tmp, "m2")], encoder=enc, backend="gloo")
     tc, td = _tree(os.path.join(tmp, "m1")), _tree(os.path.join(tmp, "m2"))
     assert tc.keys() == td.keys() and all(tc[k] == td[k] for k in tc) and c["codes"] == d["codes"]
+    # a --stereo corpus that mixes mono and stereo files (either kind first in a super-batch): every file keeps its own channel
+    # count, and every code row lands under its own file's name
+    mixed = os.path.join(tmp, "mixed")
+    os.makedirs(mixed)
+    for name, ch, n in (("a_mono.wav", 1, 11200), ("b_stereo.wav", 2, 9600), ("c_mono.wav", 1, 14400), ("d_stereo.wav", 2, 8000)):
+        sig = np.stack([bench_signal(n, 70 + i) for i in range(ch)])
+        with wave.open(os.path.join(mixed, name), "wb") as w:
+            w.setnchannels(ch); w.setsampwidth(2); w.setframerate(16000)
+            w.writeframes((np.clip(sig.T, -1, 1) * 32767).astype("<i2").tobytes())
+    mbase = ["--audio_path", mixed, "--stereo", "--batch_size", "16", "--context_secs", "0.5"]
+    e = audio_to_codes.main(mbase + ["--codes_path", os.path.join(tmp, "x1"), "--one_file_at_a_time"], encoder=enc, backend="gloo")
+    f = audio_to_codes.main(mbase + ["--codes_path", os.path.join(tmp, "x2")], encoder=enc, backend="gloo")
+    te, tf = _tree(os.path.join(tmp, "x1")), _tree(os.path.join(tmp, "x2"))
+    assert te.keys() == tf.keys() and len(te) == 1 + 6 and all(te[k] == tf[k] for k in te) and e["codes"] == f["codes"]
