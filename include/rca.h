@@ -41,13 +41,14 @@ typedef struct rca_lm rca_lm_t;
 #define RCA_F32 0
 #define RCA_BF16 1
 #define RCA_Q8_0 2   /* GGUF block_q8_0 as stored in the file: per 32 values one fp16 scale then 32 int8 (34 bytes); numel = values */
+#define RCA_F16 3    /* IEEE half (the reference's default model file is an F16 GGUF, realtime_agent_resources.py:12) */
 
 /* A named host tensor handed to a create() call (weights). */
 typedef struct {
     const char* name;
     const void* data;  /* host pointer */
     int64_t numel;
-    int32_t dtype;     /* RCA_F32, RCA_BF16, or RCA_Q8_0 (LM projection matrices and lm_head only) */
+    int32_t dtype;     /* RCA_F32, RCA_BF16, RCA_F16 (LM matrices, embedding table) or RCA_Q8_0 (LM matrices, embedding table) */
 } rca_tensor_t;
 
 const char* rca_last_error(void);
@@ -221,9 +222,13 @@ typedef struct {
     float rope_high_freq_factor;  /* 4 */
     int32_t rope_orig_ctx;    /* 8192 */
     int32_t logits_all;       /* keep logits of every evaluated position (aux_llm) */
-    int32_t decode_weights;   /* 0 = as supplied (bf16; tensors given as RCA_Q8_0 stay packed for the decode step), 1 = quantise every
-                                 projection matrix and lm_head to q8_0 at load, the way llama-quantize writes the Q8_0 file the reference
-                                 deploys (prep_test_model.sh:29): the decode step then streams 8.5 bits per weight */
+    int32_t decode_weights;   /* Every projection matrix and lm_head is kept ONCE, in the format it is streamed in by the decode step and
+                                 de-quantised from by the prefill tiles.  0 = as supplied: RCA_BF16 / RCA_F16 / RCA_Q8_0 tensors keep their
+                                 format (RCA_F32 is rounded to bf16); 1 = quantise to q8_0 at load the way llama-quantize writes the Q8_0 file
+                                 the reference deploys (prep_test_model.sh:29; 8.5 bits per weight streamed); 2 = convert bf16 to fp16 (what
+                                 convert_hf_to_gguf.py --outtype f16 writes, prep_test_model.sh:28).  Tensors that arrive quantised stay as
+                                 they are.  The embedding table is gathered, not streamed, and keeps full precision: f32 rows for RCA_F32 /
+                                 RCA_F16 / RCA_Q8_0 sources, bf16 rows for RCA_BF16. */
 } rca_lm_config_t;
 
 typedef struct {
@@ -292,7 +297,9 @@ int rca_lm_step(rca_lm_t* h, const int32_t* ids, int32_t n, int32_t* token);
  * pair step 0 evaluates (the last two ids of the sequence).  out_tokens[i] = token sampled by step i.  *n_done = number of steps
  * whose result stands: n_steps, or j + 1 when step j sampled a token <= audio_id_floor (the loop leaves audio mode there,
  * realtime_agent_v2.py:361-371); the KV position and the sampler's draw counter are then exactly what j + 1 single steps would
- * have left, and the caller continues step by step.  The last logits are those of the last step that ran. */
+ * have left, and the caller continues step by step.  After a complete frame the logits are those of its last step; after a frame
+ * cut short (n_done < n_steps) NO logits are available (the buffer holds a rolled-back step's): get_logits / token_probs / sample
+ * fail with "no logits" until the next eval or step. */
 int rca_lm_frame(rca_lm_t* h, const int32_t* first_pair, const int32_t* user_ids, int32_t n_steps, int32_t audio_id_floor,
                  int32_t* out_tokens, int32_t* n_done);
 /* softmax(logits)[token] of the last position, reduced on the device
@@ -319,10 +326,9 @@ int rca_lm_set_graphs(rca_lm_t* h, int32_t enable);
  * :725-733) run as 128-token tiles on bf16 MFMA with hi/lo-split activations (default; logits within ~1e-3 of the
  * decode path); 0 routes them through the 8-token GEMV chunks, which are bit-identical to decode */
 int rca_lm_set_mfma_prefill(rca_lm_t* h, int32_t enable);
-/* decode from the packed q8_0 matrices (1, default whenever they exist) or from their bf16(d*q) copies (0); _has_q8 reports whether
- * the handle holds packed matrices */
-int rca_lm_set_q8_decode(rca_lm_t* h, int32_t enable);
-int rca_lm_has_q8(const rca_lm_t* h, int32_t* out);
+/* the format the projection matrices are kept and streamed in (0 bf16, 1 q8_0, 2 f16) and, optionally, the weight bytes one decode
+ * step reads (llama.cpp prints the same two facts at load: file type and model size) */
+int rca_lm_weight_format(const rca_lm_t* h, int32_t* fmt, int64_t* bytes_per_step);
 /* decode steps merge the attention splits inside the attention launch (1, default: the workgroup that publishes its partial last
  * merges them; bit-identical to the separate merge launch) or in a launch of its own (0); tests compare the two */
 int rca_lm_set_attn_fuse(rca_lm_t* h, int32_t enable);

@@ -21,7 +21,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"
                "-Wno-unused-result"]
 
 MAX_STAGES = 8
-RCA_F32, RCA_BF16, RCA_Q8_0 = 0, 1, 2
+RCA_F32, RCA_BF16, RCA_Q8_0, RCA_F16 = 0, 1, 2, 3
 
 
 class RcaError(RuntimeError):
@@ -172,7 +172,7 @@ ABI_SYMBOLS = [
     "rca_lm_logits_dev", "rca_lm_sampler_init", "rca_lm_sample", "rca_lm_step", "rca_lm_token_probs",
     "rca_lm_sync", "rca_lm_set_graphs", "rca_lm_mask_head_rows", "rca_lm_set_mfma_prefill", "rca_lm_set_logits_all",
     "rca_lm_persist_codec_embeddings", "rca_lm_create_shared", "rca_lm_eval_async", "rca_lm_copy_kv", "rca_lm_swap_kv",
-    "rca_lm_set_low_priority", "rca_lm_frame", "rca_lm_set_q8_decode", "rca_lm_has_q8", "rca_lm_set_attn_fuse",
+    "rca_lm_set_low_priority", "rca_lm_frame", "rca_lm_weight_format", "rca_lm_set_attn_fuse",
 ]
 
 
@@ -206,7 +206,7 @@ def check(rc: int, what: str = "") -> None:
 
 
 def make_tensors(weights: Dict[str, np.ndarray]) -> Tuple[C.Array, list]:
-    """dict name -> ndarray (float32, or uint16 holding bf16 bits) -> rca_tensor_t[]; returns keep-alive list."""
+    """dict name -> ndarray (float32, float16, uint16 holding bf16 bits, or Q8Blocks) -> rca_tensor_t[]; returns keep-alive list."""
     keep = []
     arr = (Tensor * len(weights))()
     for i, (name, a) in enumerate(weights.items()):
@@ -218,6 +218,8 @@ def make_tensors(weights: Dict[str, np.ndarray]) -> Tuple[C.Array, list]:
             continue
         if a.dtype == np.uint16:
             dt = RCA_BF16
+        elif a.dtype == np.float16:
+            dt = RCA_F16
         else:
             a = np.ascontiguousarray(a, dtype=np.float32)
             dt = RCA_F32

@@ -104,14 +104,21 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ------------------------------------------------------------------------------------- embed
-__global__ __launch_bounds__(256) void lm_embed_kernel(const LmDevState* __restrict__ stt, const bf16_t* __restrict__ table,
+// The table is gathered, never streamed, so it keeps the precision it arrived in: bf16 rows for a bf16 checkpoint, f32 rows for
+// an F32 / F16 tensor or a de-quantised Q8_0 / Q4_K one (llama.cpp de-quantises embedding rows exactly, get_rows) -- `f32tab`.
+__global__ __launch_bounds__(256) void lm_embed_kernel(const LmDevState* __restrict__ stt, const void* __restrict__ table, int f32tab,
                                                        float* __restrict__ x, int H, int V) {
     const int m = blockIdx.x;
     if (m >= stt->m) return;
     int id = stt->ids[m];
     id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-    const bf16_t* row = table + (long)id * H;
-    for (int h = threadIdx.x; h < H; h += 256) x[(long)m * H + h] = __uint_as_float((unsigned)row[h] << 16);
+    if (f32tab) {
+        const float* row = reinterpret_cast<const float*>(table) + (long)id * H;
+        for (int h = threadIdx.x; h < H; h += 256) x[(long)m * H + h] = row[h];
+    } else {
+        const bf16_t* row = reinterpret_cast<const bf16_t*>(table) + (long)id * H;
+        for (int h = threadIdx.x; h < H; h += 256) x[(long)m * H + h] = __uint_as_float((unsigned)row[h] << 16);
+    }
 }
 
 // --------------------------------------------------- residual add + RMSNorm shared arithmetic
@@ -307,9 +314,14 @@ struct GemvQ8 {
     const u32x4* qs;      // [N / 2][K / 8] 16-byte units
     const unsigned* sc;   // [K / 32][N / 2]
 };
+// The format a projection matrix is kept in (ONE copy per matrix; the decode GEMV streams it, the prefill tiles de-quantise it while
+// staging): the GEMV's template parameter Q.
+#define WF_BF16 0   // bf16 [N][K]
+#define WF_Q8 1     // GGUF q8_0, pair-interleaved (GemvQ8)
+#define WF_F16 2    // fp16 [N][K] (the reference's default GGUF is F16, realtime_agent_resources.py:12)
 // minimum waves per SIMD asked of the register allocator.  The q8_0 bodies otherwise spread over 200+ registers (one wave per
 // SIMD) although their live set is ~130: a streaming kernel wants the occupancy.
-constexpr int gemv_min_waves(int Q, int R, int NIT) { return !Q ? 1 : (R * NIT >= 16 ? 2 : 4); }
+constexpr int gemv_min_waves(int Q, int R, int NIT) { return Q != WF_Q8 ? 1 : (R * NIT >= 16 ? 2 : 4); }
 template <int M, int NIT, int R, int PRO, int EPI, int Q = 0>
 __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel(const LmDevState* __restrict__ stt, const bf16_t* __restrict__ W,
                                                       const float* __restrict__ x, float* __restrict__ y, int N, int K,
@@ -336,16 +348,17 @@ __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel
         }
         return b * R + r;
     };
-    constexpr int NL = Q ? R / 2 : R;        // 16-byte weight loads per chunk: one per row, or one per slot pair (q8_0)
+    constexpr bool Q8 = Q == WF_Q8;
+    constexpr int NL = Q8 ? R / 2 : R;        // 16-byte weight loads per chunk: one per row, or one per slot pair (q8_0)
     u32x4 wq[NL][NIT];
-    unsigned wsc[Q ? NIT : 1][Q ? R / 2 : 1];   // q8_0: (fp16, fp16) scales of the batch's pairs for this lane's 32-element block
+    unsigned wsc[Q8 ? NIT : 1][Q8 ? R / 2 : 1];   // q8_0: (fp16, fp16) scales of the batch's pairs for this lane's 32-element block
     const int npairs = N >> 1;
     // Every lane loads from a VALID address, whatever its chunk: a lane past the wave's range (narrow test models) re-reads chunk 0
     // and multiplies it by x = 0.  A select or an exec mask on the loaded value would be a vector instruction on the load's
     // result, i.e. a wait for it right behind its issue -- and with it for every load issued before.
     const int cbase = cn > 0 ? c0 : 0;
     auto load_batch = [&](int b) {
-        if (Q) {
+        if (Q8) {
             const long p0 = (long)b * (R / 2);
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -458,7 +471,7 @@ __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel
         float val[V];   // value index v = m * R + r
 #pragma unroll
         for (int v = 0; v < V; ++v) val[v] = 0.0f;
-        if (Q) {
+        if (Q8) {
 #pragma unroll
             for (int s2 = 0; s2 < R / 2; ++s2) {
 #pragma unroll
@@ -496,7 +509,19 @@ __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const u32x4 a = wq[r][it];
-                const float f[8] = {bf16_lo(a.x), bf16_hi(a.x), bf16_lo(a.y), bf16_hi(a.y), bf16_lo(a.z), bf16_hi(a.z), bf16_lo(a.w), bf16_hi(a.w)};
+                float f[8];
+                if (Q == WF_F16) {   // fp16 weights: the widening is a v_cvt_f32_f16 (low half) / its SDWA form (high half) instead of a shift
+                    const unsigned au[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f16x2 h2 = __builtin_bit_cast(f16x2, au[j]);
+                        f[2 * j] = (float)h2[0];
+                        f[2 * j + 1] = (float)h2[1];
+                    }
+                } else {
+                    f[0] = bf16_lo(a.x); f[1] = bf16_hi(a.x); f[2] = bf16_lo(a.y); f[3] = bf16_hi(a.y);
+                    f[4] = bf16_lo(a.z); f[5] = bf16_hi(a.z); f[6] = bf16_lo(a.w); f[7] = bf16_hi(a.w);
+                }
 #pragma unroll
                 for (int m = 0; m < M; ++m)
 #pragma unroll
@@ -1057,9 +1082,10 @@ __global__ __launch_bounds__(256) void lm_f32_to_bf16_kernel(const float* __rest
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = f32_to_bf16_rne(in[i]);
 }
 
-// ------------------------------------------------------------------------- q8_0 weights
+// ------------------------------------------------------------------------- weight formats at load
 // GGUF block_q8_0 = { fp16 d; int8 qs[32] } (34 bytes), value = d * q.  "Plain" form on the device: q [N][K] int8 and
-// d [N][K / 32] fp16; from there the pair-interleaved layout the GEMV streams (GemvQ8) and a bf16(d * q) copy for the prefill tiles.
+// d [N][K / 32] fp16; from there the pair-interleaved layout the GEMV streams (GemvQ8).  There is no second copy: the prefill tiles
+// de-quantise the packed blocks while staging (lm_gemm128_kernel).
 __global__ __launch_bounds__(256) void lm_q8_unblock_kernel(const unsigned char* __restrict__ blocks, long nblocks, signed char* __restrict__ q,
                                                             f16_t* __restrict__ d) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nblocks * 32; i += (long)gridDim.x * blockDim.x) {
@@ -1073,15 +1099,18 @@ __global__ __launch_bounds__(256) void lm_q8_unblock_kernel(const unsigned char*
         }
     }
 }
+__device__ __forceinline__ float w16_to_f32(bf16_t bits, int is_f16) {
+    return is_f16 ? (float)__builtin_bit_cast(f16_t, bits) : __uint_as_float((unsigned)bits << 16);
+}
 // llama.cpp's quantize_row_q8_0: d = amax / 127, q = round(x / d) (ties away from zero), d stored as fp16
-__global__ __launch_bounds__(256) void lm_q8_quantize_kernel(const bf16_t* __restrict__ w, long nblocks, signed char* __restrict__ q,
+__global__ __launch_bounds__(256) void lm_q8_quantize_kernel(const bf16_t* __restrict__ w, int is_f16, long nblocks, signed char* __restrict__ q,
                                                              f16_t* __restrict__ d) {
     for (long blk = (long)blockIdx.x * blockDim.x + threadIdx.x; blk < nblocks; blk += (long)gridDim.x * blockDim.x) {
         float v[32];
         float amax = 0.0f;
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
-            v[j] = __uint_as_float((unsigned)w[blk * 32 + j] << 16);
+            v[j] = w16_to_f32(w[blk * 32 + j], is_f16);
             amax = fmaxf(amax, fabsf(v[j]));
         }
         const float dd = amax / 127.0f;
@@ -1091,11 +1120,18 @@ __global__ __launch_bounds__(256) void lm_q8_quantize_kernel(const bf16_t* __res
         d[blk] = (f16_t)dd;
     }
 }
-__global__ __launch_bounds__(256) void lm_q8_dequant_bf16_kernel(const signed char* __restrict__ q, const f16_t* __restrict__ d, bf16_t* __restrict__ out, long n) {
+__global__ __launch_bounds__(256) void lm_q8_dequant_f32_kernel(const signed char* __restrict__ q, const f16_t* __restrict__ d, float* __restrict__ out, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        out[i] = f32_to_bf16_rne((float)d[i >> 5] * (float)q[i]);
+        out[i] = (float)d[i >> 5] * (float)q[i];
 }
-// rows of two byte matrices interleaved: dst row 2i = a row i, 2i+1 = b row i (gate/up, in q and in d)
+__global__ __launch_bounds__(256) void lm_bf16_to_f16_kernel(const bf16_t* __restrict__ in, f16_t* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = (f16_t)__uint_as_float((unsigned)in[i] << 16);   // round to nearest even (values below the fp16 range go subnormal / to zero)
+}
+__global__ __launch_bounds__(256) void lm_f16_to_f32_kernel(const f16_t* __restrict__ in, float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (float)in[i];
+}
+// rows of two byte matrices interleaved: dst row 2i = a row i, 2i+1 = b row i (gate/up: 16-bit values, q8_0 q and d)
 __global__ __launch_bounds__(256) void lm_interleave_rows_bytes_kernel(const unsigned char* __restrict__ a, const unsigned char* __restrict__ b,
                                                                        unsigned char* __restrict__ dst, long rows, long row_bytes) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * rows * row_bytes; i += (long)gridDim.x * blockDim.x) {
@@ -1124,13 +1160,26 @@ __global__ __launch_bounds__(256) void lm_q8_pack_kernel(const signed char* __re
 }
 
 // =============================================================================================
-struct Q8Mat {
-    u32x4* qs = nullptr;
+// One projection matrix [N][K] as it is kept in HBM: ONE copy, in the format it arrived in (or was asked for through
+// rca_lm_config_t::decode_weights).
+struct WMat {
+    int fmt = WF_BF16;
+    int N = 0, K = 0;
+    bf16_t* w = nullptr;        // WF_BF16 / WF_F16: row-major 16-bit values
+    u32x4* qs = nullptr;        // WF_Q8 (GemvQ8)
     unsigned* sc = nullptr;
+    void release() {
+        for (void* p : {(void*)w, (void*)qs, (void*)sc})
+            if (p) (void)hipFree(p);
+        w = nullptr; qs = nullptr; sc = nullptr;
+    }
+    long stream_bytes() const {   // bytes one decode pass reads of it
+        const long n = (long)N * K;
+        return fmt == WF_Q8 ? n + n / 16 : 2 * n;
+    }
 };
 struct LmLayer {
-    bf16_t *wqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wdown = nullptr;
-    Q8Mat qqkv, qo, qgu, qdown;   // set when the decode GEMVs stream q8_0 (rca_lm_config_t::decode_weights / RCA_Q8_0 tensors)
+    WMat qkv, o, gu, down;
     float *attn_norm = nullptr, *ffn_norm = nullptr;
 };
 
@@ -1138,8 +1187,9 @@ struct rca_lm {
     rca_lm_config_t cfg;
     int device = 0;
     hipStream_t stream = nullptr;
-    bf16_t *embed = nullptr, *head = nullptr;
-    Q8Mat qhead;
+    void* embed = nullptr;      // [V][H] bf16 or f32 rows (embed_f32): the table keeps the precision it arrived in
+    int embed_f32 = 0;
+    WMat head;
     float* final_norm = nullptr;
     std::vector<LmLayer> layers;
     float *cos_t = nullptr, *sin_t = nullptr;
@@ -1174,7 +1224,6 @@ struct rca_lm {
     bool graphs_enabled = true;
     bool mfma_prefill = true;   // evals longer than LM_PREFILL_MIN tokens use the bf16 MFMA tiles
     bool fuse_attn = true;      // decode steps merge the attention splits inside the attention launch (rca_lm_set_attn_fuse)
-    bool use_q8 = true;         // stream the packed q8_0 form of a matrix when it has one (rca_lm_set_q8_decode: tests compare with the bf16(d*q) copy)
     // weight sharing (rca_lm_create_shared): a borrower points at the handle that owns the weights and the RoPE tables; an owner
     // destroyed while borrowers are alive keeps those allocations (and its struct) until the last borrower is gone
     rca_lm* weights_of = nullptr;
@@ -1189,15 +1238,16 @@ static int lm_alloc(void** p, size_t bytes) {
 }
 
 static void lm_free_weights(rca_lm* h) {
-    for (auto& L : h->layers)
-        for (void* p : {(void*)L.wqkv, (void*)L.wo, (void*)L.wgu, (void*)L.wdown, (void*)L.attn_norm, (void*)L.ffn_norm, (void*)L.qqkv.qs, (void*)L.qqkv.sc,
-                        (void*)L.qo.qs, (void*)L.qo.sc, (void*)L.qgu.qs, (void*)L.qgu.sc, (void*)L.qdown.qs, (void*)L.qdown.sc})
+    for (auto& L : h->layers) {
+        for (WMat* m : {&L.qkv, &L.o, &L.gu, &L.down}) m->release();
+        for (void* p : {(void*)L.attn_norm, (void*)L.ffn_norm})
             if (p) (void)hipFree(p);
-    for (void* p : {(void*)h->embed, (void*)h->head, (void*)h->final_norm, (void*)h->cos_t, (void*)h->sin_t, (void*)h->qhead.qs, (void*)h->qhead.sc})
+    }
+    h->head.release();
+    for (void* p : {(void*)h->embed, (void*)h->final_norm, (void*)h->cos_t, (void*)h->sin_t})
         if (p) (void)hipFree(p);
-    h->qhead = Q8Mat{};
     h->layers.clear();
-    h->embed = h->head = nullptr;
+    h->embed = nullptr;
     h->final_norm = h->cos_t = h->sin_t = nullptr;
 }
 
@@ -1270,55 +1320,122 @@ static int lm_check_cfg(const rca_lm_config_t* c) {
     if (c->ffn > LM_KSLICE * LM_MAXSPLIT) return fail(RCA_ERR_ARG, "ffn > %d unsupported", LM_KSLICE * LM_MAXSPLIT);
     if (c->ffn > LM_KSLICE && c->ffn % LM_KSLICE) return fail(RCA_ERR_ARG, "ffn above %d must be a multiple of it", LM_KSLICE);
     if (c->vocab_size < 2 || c->n_layers < 1 || c->n_ctx < 2) return fail(RCA_ERR_ARG, "bad sizes");
+    if (c->decode_weights < 0 || c->decode_weights > 2) return fail(RCA_ERR_ARG, "decode_weights %d (0 as supplied, 1 q8_0, 2 f16)", c->decode_weights);
     return RCA_OK;
 }
 
-struct Q8Plain {   // a matrix that arrived as q8_0 blocks, unblocked on the device: q [numel] int8, d [numel / 32] fp16
-    signed char* q = nullptr;
-    f16_t* d = nullptr;
-    void release() { if (q) (void)hipFree(q); if (d) (void)hipFree(d); q = nullptr; d = nullptr; }
+// A source tensor on the device in its "plain" form (row-major, one array per component), before fusion (q;k;v rows, gate/up rows
+// interleaved) and before the GEMV layout is built.
+struct RawMat {
+    int fmt = WF_BF16;
+    long rows = 0, cols = 0;
+    bf16_t* w16 = nullptr;      // WF_BF16 / WF_F16
+    signed char* q = nullptr;   // WF_Q8: int8 [rows][cols]
+    f16_t* d = nullptr;         //        fp16 [rows][cols / 32]
+    void release() {
+        for (void* p : {(void*)w16, (void*)q, (void*)d})
+            if (p) (void)hipFree(p);
+        w16 = nullptr; q = nullptr; d = nullptr;
+    }
+    // (array, bytes per row) of every component
+    int parts(void** ptr, long* row_bytes) const {
+        if (fmt == WF_Q8) { ptr[0] = q; row_bytes[0] = cols; ptr[1] = d; row_bytes[1] = cols / 32 * 2; return 2; }
+        ptr[0] = w16; row_bytes[0] = cols * 2;
+        return 1;
+    }
+    int alloc(int f, long r, long c) {
+        fmt = f; rows = r; cols = c;
+        int rc;
+        if (f == WF_Q8) {
+            if (c % 32) return fail(RCA_ERR_ARG, "q8_0 needs rows of a multiple of 32 values (got %ld)", c);
+            if ((rc = lm_alloc((void**)&q, (size_t)r * c)) != RCA_OK || (rc = lm_alloc((void**)&d, (size_t)r * (c / 32) * 2)) != RCA_OK) { release(); return rc; }
+            return RCA_OK;
+        }
+        return lm_alloc((void**)&w16, (size_t)r * c * 2);
+    }
 };
-// uploads a tensor as bf16 (converting from f32 on the device when needed).  A tensor supplied as RCA_Q8_0 (the 34-byte GGUF
-// blocks as they sit in the file) is unblocked on the device; its bf16 form is bf16(d * q) and, when `plain` is given, the
-// unblocked q / d stay for the packed decode layout.
-static int lm_upload_bf16(rca_lm* h, const rca_tensor_t* ts, int nt, const std::string& name, long numel, bf16_t** out, Q8Plain* plain = nullptr) {
+
+// Uploads a matrix.  RCA_BF16 / RCA_F16 stay what they are; RCA_F32 is rounded to bf16 (nearest even: this build's storage format
+// for 32-bit checkpoints); RCA_Q8_0 (the 34-byte GGUF blocks as they sit in the file) is unblocked.
+static int lm_upload_raw(rca_lm* h, const rca_tensor_t* ts, int nt, const std::string& name, long rows, long cols, RawMat* out) {
     const rca_tensor_t* t = find_tensor(ts, nt, name);
+    const long numel = rows * cols;
     if (!t) return fail(RCA_ERR_MISSING, "tensor '%s' missing", name.c_str());
     if (t->numel != numel) return fail(RCA_ERR_ARG, "tensor '%s': numel %ld, expected %ld", name.c_str(), (long)t->numel, numel);
     int rc;
-    if ((rc = lm_alloc((void**)out, (size_t)numel * 2)) != RCA_OK) return rc;
     if (t->dtype == RCA_Q8_0) {
-        if (numel % 32) return fail(RCA_ERR_ARG, "tensor '%s': q8_0 needs a multiple of 32 elements", name.c_str());
+        if ((rc = out->alloc(WF_Q8, rows, cols)) != RCA_OK) return rc;
         const long nblk = numel / 32;
         unsigned char* raw = nullptr;
-        Q8Plain pl;
-        if ((rc = lm_alloc((void**)&raw, (size_t)nblk * 34)) != RCA_OK) return rc;
-        if ((rc = lm_alloc((void**)&pl.q, (size_t)numel)) != RCA_OK || (rc = lm_alloc((void**)&pl.d, (size_t)nblk * 2)) != RCA_OK) { (void)hipFree(raw); pl.release(); return rc; }
+        if ((rc = lm_alloc((void**)&raw, (size_t)nblk * 34)) != RCA_OK) { out->release(); return rc; }
         hipError_t e = hipMemcpy(raw, t->data, (size_t)nblk * 34, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
-            lm_q8_unblock_kernel<<<4096, 256, 0, h->stream>>>(raw, nblk, pl.q, pl.d);
-            lm_q8_dequant_bf16_kernel<<<4096, 256, 0, h->stream>>>(pl.q, pl.d, *out, numel);
+            lm_q8_unblock_kernel<<<4096, 256, 0, h->stream>>>(raw, nblk, out->q, out->d);
             e = hipStreamSynchronize(h->stream);
         }
         (void)hipFree(raw);
-        if (e != hipSuccess) { pl.release(); return fail(RCA_ERR_HIP, "upload '%s': %s", name.c_str(), hipGetErrorString(e)); }
-        if (plain) *plain = pl; else pl.release();
+        if (e != hipSuccess) { out->release(); return fail(RCA_ERR_HIP, "upload '%s': %s", name.c_str(), hipGetErrorString(e)); }
         return RCA_OK;
     }
+    if (t->dtype == RCA_BF16 || t->dtype == RCA_F16) {
+        if ((rc = out->alloc(t->dtype == RCA_F16 ? WF_F16 : WF_BF16, rows, cols)) != RCA_OK) return rc;
+        RCA_HIP(hipMemcpy(out->w16, t->data, (size_t)numel * 2, hipMemcpyHostToDevice));
+        return RCA_OK;
+    }
+    if (t->dtype != RCA_F32) return fail(RCA_ERR_ARG, "tensor '%s': dtype %d is not supported for a projection matrix", name.c_str(), t->dtype);
+    if ((rc = out->alloc(WF_BF16, rows, cols)) != RCA_OK) return rc;
+    float* tmp = nullptr;
+    if ((rc = lm_alloc((void**)&tmp, (size_t)numel * 4)) != RCA_OK) return rc;
+    hipError_t e = hipMemcpy(tmp, t->data, (size_t)numel * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        lm_f32_to_bf16_kernel<<<2048, 256, 0, h->stream>>>(tmp, out->w16, numel);
+        e = hipStreamSynchronize(h->stream);
+    }
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(RCA_ERR_HIP, "upload '%s': %s", name.c_str(), hipGetErrorString(e));
+    return RCA_OK;
+}
+// The embedding table: never streamed, so it is kept exact -- f32 rows for RCA_F32 / RCA_F16 / RCA_Q8_0 sources, bf16 rows for RCA_BF16.
+static int lm_upload_embed(rca_lm* h, const rca_tensor_t* ts, int nt, const std::string& name, long rows, long cols) {
+    const rca_tensor_t* t = find_tensor(ts, nt, name);
+    const long numel = rows * cols;
+    if (!t) return fail(RCA_ERR_MISSING, "tensor '%s' missing", name.c_str());
+    if (t->numel != numel) return fail(RCA_ERR_ARG, "tensor '%s': numel %ld, expected %ld", name.c_str(), (long)t->numel, numel);
+    int rc;
     if (t->dtype == RCA_BF16) {
-        RCA_HIP(hipMemcpy(*out, t->data, (size_t)numel * 2, hipMemcpyHostToDevice));
-    } else {
-        float* tmp = nullptr;
-        if ((rc = lm_alloc((void**)&tmp, (size_t)numel * 4)) != RCA_OK) return rc;
-        hipError_t e = hipMemcpy(tmp, t->data, (size_t)numel * 4, hipMemcpyHostToDevice);
+        h->embed_f32 = 0;
+        if ((rc = lm_alloc(&h->embed, (size_t)numel * 2)) != RCA_OK) return rc;
+        RCA_HIP(hipMemcpy(h->embed, t->data, (size_t)numel * 2, hipMemcpyHostToDevice));
+        return RCA_OK;
+    }
+    h->embed_f32 = 1;
+    if ((rc = lm_alloc(&h->embed, (size_t)numel * 4)) != RCA_OK) return rc;
+    if (t->dtype == RCA_F32) {
+        RCA_HIP(hipMemcpy(h->embed, t->data, (size_t)numel * 4, hipMemcpyHostToDevice));
+        return RCA_OK;
+    }
+    if (t->dtype == RCA_F16) {
+        f16_t* tmp = nullptr;
+        if ((rc = lm_alloc((void**)&tmp, (size_t)numel * 2)) != RCA_OK) return rc;
+        hipError_t e = hipMemcpy(tmp, t->data, (size_t)numel * 2, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
-            lm_f32_to_bf16_kernel<<<2048, 256, 0, h->stream>>>(tmp, *out, numel);
+            lm_f16_to_f32_kernel<<<4096, 256, 0, h->stream>>>(tmp, (float*)h->embed, numel);
             e = hipStreamSynchronize(h->stream);
         }
         (void)hipFree(tmp);
         if (e != hipSuccess) return fail(RCA_ERR_HIP, "upload '%s': %s", name.c_str(), hipGetErrorString(e));
+        return RCA_OK;
     }
-    return RCA_OK;
+    if (t->dtype == RCA_Q8_0) {
+        RawMat raw;
+        if ((rc = lm_upload_raw(h, ts, nt, name, rows, cols, &raw)) != RCA_OK) return rc;
+        lm_q8_dequant_f32_kernel<<<4096, 256, 0, h->stream>>>(raw.q, raw.d, (float*)h->embed, numel);
+        hipError_t e = hipStreamSynchronize(h->stream);
+        raw.release();
+        if (e != hipSuccess) return fail(RCA_ERR_HIP, "upload '%s': %s", name.c_str(), hipGetErrorString(e));
+        return RCA_OK;
+    }
+    return fail(RCA_ERR_ARG, "tensor '%s': dtype %d is not supported for the embedding table", name.c_str(), t->dtype);
 }
 static int lm_upload_f32(const rca_tensor_t* ts, int nt, const std::string& name, long numel, float** out) {
     const rca_tensor_t* t = find_tensor(ts, nt, name);
@@ -1334,9 +1451,96 @@ static int lm_upload_f32(const rca_tensor_t* ts, int nt, const std::string& name
             memcpy(&tmp[i], &u, 4);
         }
         RCA_HIP(hipMemcpy(*out, tmp.data(), (size_t)numel * 4, hipMemcpyHostToDevice));
-    } else {
+    } else if (t->dtype == RCA_F32) {
         RCA_HIP(hipMemcpy(*out, t->data, (size_t)numel * 4, hipMemcpyHostToDevice));
+    } else {
+        return fail(RCA_ERR_ARG, "tensor '%s': norm weights must be f32 or bf16", name.c_str());
     }
+    return RCA_OK;
+}
+
+// rca_lm_config_t::decode_weights applied to one plain matrix: 1 = quantise to q8_0 the way llama-quantize does, 2 = fp16.
+// A matrix that ARRIVED quantised stays what it is.
+static int lm_raw_convert(rca_lm* h, RawMat* m, int want) {
+    if (want == 0 || m->fmt == WF_Q8) return RCA_OK;
+    int rc;
+    if (want == 1) {
+        RawMat qd;
+        if ((rc = qd.alloc(WF_Q8, m->rows, m->cols)) != RCA_OK) return rc;
+        lm_q8_quantize_kernel<<<4096, 256, 0, h->stream>>>(m->w16, m->fmt == WF_F16, m->rows * m->cols / 32, qd.q, qd.d);
+        hipError_t e = hipStreamSynchronize(h->stream);
+        m->release();
+        if (e != hipSuccess) { qd.release(); return fail(RCA_ERR_HIP, "q8_0 quantise: %s", hipGetErrorString(e)); }
+        *m = qd;
+        return RCA_OK;
+    }
+    if (want == 2 && m->fmt == WF_BF16) {
+        f16_t* out = nullptr;
+        if ((rc = lm_alloc((void**)&out, (size_t)m->rows * m->cols * 2)) != RCA_OK) return rc;
+        lm_bf16_to_f16_kernel<<<4096, 256, 0, h->stream>>>(m->w16, out, m->rows * m->cols);
+        hipError_t e = hipStreamSynchronize(h->stream);
+        (void)hipFree(m->w16);
+        m->w16 = reinterpret_cast<bf16_t*>(out);
+        m->fmt = WF_F16;
+        if (e != hipSuccess) return fail(RCA_ERR_HIP, "fp16 conversion: %s", hipGetErrorString(e));
+    }
+    return RCA_OK;
+}
+// rows of `parts` stacked (q; k; v).  Parts of different formats cannot be fused.
+static int lm_raw_concat(rca_lm* h, std::vector<RawMat*> parts, RawMat* out, const char* what) {
+    long rows = 0;
+    for (RawMat* p : parts) {
+        if (p->fmt != parts[0]->fmt || p->cols != parts[0]->cols) return fail(RCA_ERR_ARG, "%s: its parts arrived in different formats", what);
+        rows += p->rows;
+    }
+    int rc;
+    if ((rc = out->alloc(parts[0]->fmt, rows, parts[0]->cols)) != RCA_OK) return rc;
+    void* dp[2]; long drb[2];
+    const int np = out->parts(dp, drb);
+    long r0 = 0;
+    for (RawMat* p : parts) {
+        void* sp[2]; long srb[2];
+        p->parts(sp, srb);
+        for (int i = 0; i < np; ++i)
+            RCA_HIP(hipMemcpyAsync((char*)dp[i] + r0 * drb[i], sp[i], (size_t)p->rows * srb[i], hipMemcpyDeviceToDevice, h->stream));
+        r0 += p->rows;
+    }
+    RCA_HIP(hipStreamSynchronize(h->stream));
+    return RCA_OK;
+}
+// dst row 2i = a row i, 2i+1 = b row i (gate/up: SwiGLU becomes an epilogue)
+static int lm_raw_interleave(rca_lm* h, RawMat* a, RawMat* b, RawMat* out, const char* what) {
+    if (a->fmt != b->fmt || a->cols != b->cols || a->rows != b->rows) return fail(RCA_ERR_ARG, "%s: its parts arrived in different formats", what);
+    int rc;
+    if ((rc = out->alloc(a->fmt, 2 * a->rows, a->cols)) != RCA_OK) return rc;
+    void *dp[2], *ap[2], *bp[2]; long rb[2];
+    const int np = out->parts(dp, rb);
+    a->parts(ap, rb);
+    b->parts(bp, rb);
+    for (int i = 0; i < np; ++i)
+        lm_interleave_rows_bytes_kernel<<<4096, 256, 0, h->stream>>>((const unsigned char*)ap[i], (const unsigned char*)bp[i], (unsigned char*)dp[i], a->rows, rb[i]);
+    RCA_HIP(hipStreamSynchronize(h->stream));
+    return RCA_OK;
+}
+// plain -> the layout the decode GEMV streams.  Takes ownership of `raw` (released or moved into `out`).
+static int lm_finish_mat(rca_lm* h, RawMat* raw, int qkv_pairs, WMat* out, const char* what) {
+    out->fmt = raw->fmt; out->N = (int)raw->rows; out->K = (int)raw->cols;
+    if (raw->fmt != WF_Q8) {
+        out->w = raw->w16;
+        raw->w16 = nullptr;
+        return RCA_OK;
+    }
+    const int N = out->N, K = out->K;
+    if ((K % 32) || (N % 2) || (qkv_pairs && (N % 64))) { raw->release(); return fail(RCA_ERR_ARG, "q8_0 weights: %s is %d x %d (K must be a multiple of 32, N even)", what, N, K); }
+    int rc;
+    const long npairs = N / 2, nchunk = K / 8;
+    if ((rc = lm_alloc((void**)&out->qs, (size_t)npairs * nchunk * 16)) != RCA_OK ||
+        (rc = lm_alloc((void**)&out->sc, (size_t)(K / 32) * npairs * 4 + 256)) != RCA_OK) { raw->release(); return rc; }   // + slack: the last batch's vector scale load
+    (void)hipMemsetAsync(out->sc, 0, (size_t)(K / 32) * npairs * 4 + 256, h->stream);
+    lm_q8_pack_kernel<<<4096, 256, 0, h->stream>>>(raw->q, raw->d, N, K, qkv_pairs, out->qs, out->sc);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    raw->release();
+    if (e != hipSuccess) return fail(RCA_ERR_HIP, "q8_0 pack of %s: %s", what, hipGetErrorString(e));
     return RCA_OK;
 }
 
@@ -1450,34 +1654,23 @@ static int lm_new(const rca_lm_config_t* cfg, int device, rca_lm** out) {
     return RCA_OK;
 }
 
-// The packed decode form of one projection matrix [N][K] (rows in the order the GEMV's slots use them).  `plain` = its q8_0 values
-// if it arrived as blocks; otherwise, when the handle was asked to stream q8_0 (cfg.decode_weights), the bf16 matrix is quantised
-// here the way llama-quantize does and REPLACED by bf16(d * q), so that the prefill tiles and the decode GEMVs see one model.
-static int lm_finish_q8(rca_lm* h, bf16_t* w, Q8Plain plain, int N, int K, int qkv_pairs, Q8Mat* out, const char* what) {
-    const bool want = plain.q != nullptr || h->cfg.decode_weights == 1;
-    if (!want) return RCA_OK;
-    const bool fits = (K % 32) == 0 && (N % 2) == 0 && (!qkv_pairs || (N % 64) == 0);
-    if (!fits) {
-        plain.release();
-        if (h->cfg.decode_weights == 1) return fail(RCA_ERR_ARG, "q8_0 decode weights: %s is %d x %d (K must be a multiple of 32, N even)", what, N, K);
-        return RCA_OK;   // stays on the bf16(d * q) copy
-    }
-    int rc;
-    const long numel = (long)N * K;
-    if (!plain.q) {
-        if ((rc = lm_alloc((void**)&plain.q, (size_t)numel)) != RCA_OK || (rc = lm_alloc((void**)&plain.d, (size_t)(numel / 32) * 2)) != RCA_OK) { plain.release(); return rc; }
-        lm_q8_quantize_kernel<<<4096, 256, 0, h->stream>>>(w, numel / 32, plain.q, plain.d);
-        lm_q8_dequant_bf16_kernel<<<4096, 256, 0, h->stream>>>(plain.q, plain.d, w, numel);
-    }
-    const long npairs = N / 2, nchunk = K / 8;
-    if ((rc = lm_alloc((void**)&out->qs, (size_t)npairs * nchunk * 16)) != RCA_OK ||
-        (rc = lm_alloc((void**)&out->sc, (size_t)(K / 32) * npairs * 4 + 256)) != RCA_OK) { plain.release(); return rc; }   // + slack: the last batch's vector scale load
-    (void)hipMemsetAsync(out->sc, 0, (size_t)(K / 32) * npairs * 4 + 256, h->stream);
-    lm_q8_pack_kernel<<<4096, 256, 0, h->stream>>>(plain.q, plain.d, N, K, qkv_pairs, out->qs, out->sc);
-    hipError_t e = hipStreamSynchronize(h->stream);
-    plain.release();
-    if (e != hipSuccess) return fail(RCA_ERR_HIP, "q8_0 pack of %s: %s", what, hipGetErrorString(e));
-    return RCA_OK;
+// Fusions + GEMV layouts of one layer from its seven plain matrices (which are consumed).
+static int lm_build_layer(rca_lm* h, LmLayer& L, RawMat& q, RawMat& k, RawMat& v, RawMat& o, RawMat& g, RawMat& u, RawMat& dn) {
+    const int want = h->cfg.decode_weights;
+    int rc = RCA_OK;
+    RawMat qkv, gu;
+    auto done = [&](int code) { for (RawMat* m : {&q, &k, &v, &o, &g, &u, &dn, &qkv, &gu}) m->release(); return code; };
+    for (RawMat* m : {&q, &k, &v, &o, &g, &u, &dn})
+        if ((rc = lm_raw_convert(h, m, want)) != RCA_OK) return done(rc);
+    if ((rc = lm_raw_concat(h, {&q, &k, &v}, &qkv, "the fused QKV projection")) != RCA_OK) return done(rc);
+    q.release(); k.release(); v.release();
+    if ((rc = lm_raw_interleave(h, &g, &u, &gu, "the fused gate/up projection")) != RCA_OK) return done(rc);
+    g.release(); u.release();
+    if ((rc = lm_finish_mat(h, &qkv, 1, &L.qkv, "the fused QKV projection")) != RCA_OK) return done(rc);
+    if ((rc = lm_finish_mat(h, &o, 0, &L.o, "o_proj")) != RCA_OK) return done(rc);
+    if ((rc = lm_finish_mat(h, &gu, 0, &L.gu, "the fused gate/up projection")) != RCA_OK) return done(rc);
+    if ((rc = lm_finish_mat(h, &dn, 0, &L.down, "down_proj")) != RCA_OK) return done(rc);
+    return done(RCA_OK);
 }
 
 extern "C" int rca_lm_create(const rca_lm_config_t* cfg, const rca_tensor_t* ts, int32_t nt, int32_t device, rca_lm_t** out) {
@@ -1488,60 +1681,29 @@ extern "C" int rca_lm_create(const rca_lm_config_t* cfg, const rca_tensor_t* ts,
     auto bail = [&](int code) { rca_lm_destroy(h); return code; };
     const rca_lm_config_t& c = h->cfg;
     const long H = c.hidden, V = c.vocab_size, F = c.ffn, Q = (long)c.n_heads * c.head_dim, KVD = (long)c.n_kv_heads * c.head_dim;
-    if ((rc = lm_upload_bf16(h, ts, nt, "model.embed_tokens.weight", V * H, &h->embed)) != RCA_OK) return bail(rc);
+    if ((rc = lm_upload_embed(h, ts, nt, "model.embed_tokens.weight", V, H)) != RCA_OK) return bail(rc);
     {
-        Q8Plain ph;
-        if ((rc = lm_upload_bf16(h, ts, nt, "lm_head.weight", V * H, &h->head, &ph)) != RCA_OK) return bail(rc);
-        if ((rc = lm_finish_q8(h, h->head, ph, (int)V, (int)H, 0, &h->qhead, "lm_head")) != RCA_OK) return bail(rc);
+        RawMat ph;
+        if ((rc = lm_upload_raw(h, ts, nt, "lm_head.weight", V, H, &ph)) != RCA_OK) return bail(rc);
+        if ((rc = lm_raw_convert(h, &ph, c.decode_weights)) != RCA_OK) { ph.release(); return bail(rc); }
+        if ((rc = lm_finish_mat(h, &ph, 0, &h->head, "lm_head")) != RCA_OK) return bail(rc);
     }
     if ((rc = lm_upload_f32(ts, nt, "model.norm.weight", H, &h->final_norm)) != RCA_OK) return bail(rc);
     for (int l = 0; l < c.n_layers; ++l) {
         const std::string p = "model.layers." + std::to_string(l) + ".";
         LmLayer& L = h->layers[l];
-        bf16_t *q = nullptr, *k = nullptr, *v = nullptr, *g = nullptr, *u = nullptr;
-        Q8Plain pq, pk, pv, pg, pu;
-        auto free5 = [&]() { for (bf16_t* t : {q, k, v, g, u}) if (t) (void)hipFree(t); for (Q8Plain* t : {&pq, &pk, &pv, &pg, &pu}) t->release(); };
-        if ((rc = lm_upload_bf16(h, ts, nt, p + "self_attn.q_proj.weight", Q * H, &q, &pq)) != RCA_OK ||
-            (rc = lm_upload_bf16(h, ts, nt, p + "self_attn.k_proj.weight", KVD * H, &k, &pk)) != RCA_OK ||
-            (rc = lm_upload_bf16(h, ts, nt, p + "self_attn.v_proj.weight", KVD * H, &v, &pv)) != RCA_OK ||
-            (rc = lm_upload_bf16(h, ts, nt, p + "mlp.gate_proj.weight", F * H, &g, &pg)) != RCA_OK ||
-            (rc = lm_upload_bf16(h, ts, nt, p + "mlp.up_proj.weight", F * H, &u, &pu)) != RCA_OK) { free5(); return bail(rc); }
-        // fused layouts: [q; k; v] rows, and gate/up rows interleaved for the SwiGLU epilogue
-        if ((rc = lm_alloc((void**)&L.wqkv, (size_t)(Q + 2 * KVD) * H * 2)) != RCA_OK || (rc = lm_alloc((void**)&L.wgu, (size_t)2 * F * H * 2)) != RCA_OK) { free5(); return bail(rc); }
-        (void)hipMemcpyAsync(L.wqkv, q, Q * H * 2, hipMemcpyDeviceToDevice, h->stream);
-        (void)hipMemcpyAsync(L.wqkv + Q * H, k, KVD * H * 2, hipMemcpyDeviceToDevice, h->stream);
-        (void)hipMemcpyAsync(L.wqkv + (Q + KVD) * H, v, KVD * H * 2, hipMemcpyDeviceToDevice, h->stream);
-        lm_interleave_rows_kernel<<<cdiv(2 * F * H, 256), 256, 0, h->stream>>>(g, u, L.wgu, (int)F, (int)H);
-        // the same fusions on the q8_0 values when every part arrived as blocks
-        Q8Plain pqkv, pgu;
-        if (pq.q && pk.q && pv.q && (H % 32) == 0) {
-            const long Hb = H / 32;
-            if ((rc = lm_alloc((void**)&pqkv.q, (size_t)(Q + 2 * KVD) * H)) != RCA_OK || (rc = lm_alloc((void**)&pqkv.d, (size_t)(Q + 2 * KVD) * Hb * 2)) != RCA_OK) { pqkv.release(); free5(); return bail(rc); }
-            (void)hipMemcpyAsync(pqkv.q, pq.q, Q * H, hipMemcpyDeviceToDevice, h->stream);
-            (void)hipMemcpyAsync(pqkv.q + Q * H, pk.q, KVD * H, hipMemcpyDeviceToDevice, h->stream);
-            (void)hipMemcpyAsync(pqkv.q + (Q + KVD) * H, pv.q, KVD * H, hipMemcpyDeviceToDevice, h->stream);
-            (void)hipMemcpyAsync(pqkv.d, pq.d, Q * Hb * 2, hipMemcpyDeviceToDevice, h->stream);
-            (void)hipMemcpyAsync(pqkv.d + Q * Hb, pk.d, KVD * Hb * 2, hipMemcpyDeviceToDevice, h->stream);
-            (void)hipMemcpyAsync(pqkv.d + (Q + KVD) * Hb, pv.d, KVD * Hb * 2, hipMemcpyDeviceToDevice, h->stream);
+        RawMat q, k, v, o, g, u, dn;
+        if ((rc = lm_upload_raw(h, ts, nt, p + "self_attn.q_proj.weight", Q, H, &q)) != RCA_OK ||
+            (rc = lm_upload_raw(h, ts, nt, p + "self_attn.k_proj.weight", KVD, H, &k)) != RCA_OK ||
+            (rc = lm_upload_raw(h, ts, nt, p + "self_attn.v_proj.weight", KVD, H, &v)) != RCA_OK ||
+            (rc = lm_upload_raw(h, ts, nt, p + "self_attn.o_proj.weight", H, Q, &o)) != RCA_OK ||
+            (rc = lm_upload_raw(h, ts, nt, p + "mlp.gate_proj.weight", F, H, &g)) != RCA_OK ||
+            (rc = lm_upload_raw(h, ts, nt, p + "mlp.up_proj.weight", F, H, &u)) != RCA_OK ||
+            (rc = lm_upload_raw(h, ts, nt, p + "mlp.down_proj.weight", H, F, &dn)) != RCA_OK) {
+            for (RawMat* m : {&q, &k, &v, &o, &g, &u, &dn}) m->release();
+            return bail(rc);
         }
-        if (pg.q && pu.q && (H % 32) == 0) {
-            const long Hb = H / 32;
-            if ((rc = lm_alloc((void**)&pgu.q, (size_t)2 * F * H)) != RCA_OK || (rc = lm_alloc((void**)&pgu.d, (size_t)2 * F * Hb * 2)) != RCA_OK) { pqkv.release(); pgu.release(); free5(); return bail(rc); }
-            lm_interleave_rows_bytes_kernel<<<4096, 256, 0, h->stream>>>((const unsigned char*)pg.q, (const unsigned char*)pu.q, (unsigned char*)pgu.q, F, H);
-            lm_interleave_rows_bytes_kernel<<<1024, 256, 0, h->stream>>>((const unsigned char*)pg.d, (const unsigned char*)pu.d, (unsigned char*)pgu.d, F, Hb * 2);
-        }
-        hipError_t e = hipStreamSynchronize(h->stream);
-        free5();
-        if (e != hipSuccess) { pqkv.release(); pgu.release(); return bail(fail(RCA_ERR_HIP, "layer %d pack: %s", l, hipGetErrorString(e))); }
-        if ((rc = lm_finish_q8(h, L.wqkv, pqkv, (int)(Q + 2 * KVD), (int)H, 1, &L.qqkv, "the fused QKV projection")) != RCA_OK) { pgu.release(); return bail(rc); }
-        if ((rc = lm_finish_q8(h, L.wgu, pgu, (int)(2 * F), (int)H, 0, &L.qgu, "the fused gate/up projection")) != RCA_OK) return bail(rc);
-        {
-            Q8Plain po, pd;
-            if ((rc = lm_upload_bf16(h, ts, nt, p + "self_attn.o_proj.weight", H * Q, &L.wo, &po)) != RCA_OK) return bail(rc);
-            if ((rc = lm_finish_q8(h, L.wo, po, (int)H, (int)Q, 0, &L.qo, "o_proj")) != RCA_OK) return bail(rc);
-            if ((rc = lm_upload_bf16(h, ts, nt, p + "mlp.down_proj.weight", H * F, &L.wdown, &pd)) != RCA_OK) return bail(rc);
-            if ((rc = lm_finish_q8(h, L.wdown, pd, (int)H, (int)F, 0, &L.qdown, "down_proj")) != RCA_OK) return bail(rc);
-        }
+        if ((rc = lm_build_layer(h, L, q, k, v, o, g, u, dn)) != RCA_OK) return bail(rc);
         if ((rc = lm_upload_f32(ts, nt, p + "input_layernorm.weight", H, &L.attn_norm)) != RCA_OK) return bail(rc);
         if ((rc = lm_upload_f32(ts, nt, p + "post_attention_layernorm.weight", H, &L.ffn_norm)) != RCA_OK) return bail(rc);
     }
@@ -1560,11 +1722,15 @@ extern "C" int rca_lm_create_random(const rca_lm_config_t* cfg, uint64_t seed, f
     const long H = c.hidden, V = c.vocab_size, F = c.ffn, Q = (long)c.n_heads * c.head_dim, KVD = (long)c.n_kv_heads * c.head_dim;
     const float scale = init_std * 1.7320508f / 65535.0f;
     unsigned long long tid = 1;
-    auto rnd = [&](bf16_t** p, long n) -> int {
-        int r = lm_alloc((void**)p, (size_t)n * 2);
+    // every matrix is generated as bf16 values (hash of (seed, tensor id, element)), then brought into the requested decode format
+    // the way a converter would from a bf16 checkpoint
+    auto rnd = [&](long rows, long cols, int qkv_pairs, WMat* dst, const char* what) -> int {
+        RawMat m;
+        int r = m.alloc(WF_BF16, rows, cols);
         if (r != RCA_OK) return r;
-        lm_random_bf16_kernel<<<4096, 256, 0, h->stream>>>(*p, n, seed, tid++, scale);
-        return RCA_OK;
+        lm_random_bf16_kernel<<<4096, 256, 0, h->stream>>>(m.w16, rows * cols, seed, tid++, scale);
+        if ((r = lm_raw_convert(h, &m, c.decode_weights)) != RCA_OK) { m.release(); return r; }
+        return lm_finish_mat(h, &m, qkv_pairs, dst, what);
     };
     auto ones = [&](float** p, long n) -> int {
         int r = lm_alloc((void**)p, (size_t)n * 4);
@@ -1573,26 +1739,19 @@ extern "C" int rca_lm_create_random(const rca_lm_config_t* cfg, uint64_t seed, f
         return RCA_OK;
     };
     // tensor ids: 1 embed, 2 head, then per layer 10*l + {3 qkv, 4 o, 5 gate/up(interleaved), 6 down}
-    if ((rc = rnd(&h->embed, V * H)) != RCA_OK || (rc = rnd(&h->head, V * H)) != RCA_OK || (rc = ones(&h->final_norm, H)) != RCA_OK) return bail(rc);
+    h->embed_f32 = 0;
+    if ((rc = lm_alloc(&h->embed, (size_t)V * H * 2)) != RCA_OK) return bail(rc);
+    lm_random_bf16_kernel<<<4096, 256, 0, h->stream>>>((bf16_t*)h->embed, V * H, seed, tid++, scale);
+    if ((rc = rnd(V, H, 0, &h->head, "lm_head")) != RCA_OK || (rc = ones(&h->final_norm, H)) != RCA_OK) return bail(rc);
     for (int l = 0; l < c.n_layers; ++l) {
         LmLayer& L = h->layers[l];
         tid = 10ull * (l + 1) + 3;
-        if ((rc = rnd(&L.wqkv, (Q + 2 * KVD) * H)) != RCA_OK || (rc = rnd(&L.wo, H * Q)) != RCA_OK || (rc = rnd(&L.wgu, 2 * F * H)) != RCA_OK ||
-            (rc = rnd(&L.wdown, H * F)) != RCA_OK || (rc = ones(&L.attn_norm, H)) != RCA_OK || (rc = ones(&L.ffn_norm, H)) != RCA_OK)
+        if ((rc = rnd(Q + 2 * KVD, H, 1, &L.qkv, "the fused QKV projection")) != RCA_OK || (rc = rnd(H, Q, 0, &L.o, "o_proj")) != RCA_OK ||
+            (rc = rnd(2 * F, H, 0, &L.gu, "the fused gate/up projection")) != RCA_OK || (rc = rnd(H, F, 0, &L.down, "down_proj")) != RCA_OK ||
+            (rc = ones(&L.attn_norm, H)) != RCA_OK || (rc = ones(&L.ffn_norm, H)) != RCA_OK)
             return bail(rc);
     }
     RCA_HIP(hipStreamSynchronize(h->stream));
-    if (c.decode_weights == 1) {   // the same hash-generated model, its projections quantised like llama-quantize q8_0 would
-        const Q8Plain none;
-        if ((rc = lm_finish_q8(h, h->head, none, (int)V, (int)H, 0, &h->qhead, "lm_head")) != RCA_OK) return bail(rc);
-        for (int l = 0; l < c.n_layers; ++l) {
-            LmLayer& L = h->layers[l];
-            if ((rc = lm_finish_q8(h, L.wqkv, none, (int)(Q + 2 * KVD), (int)H, 1, &L.qqkv, "the fused QKV projection")) != RCA_OK ||
-                (rc = lm_finish_q8(h, L.wo, none, (int)H, (int)Q, 0, &L.qo, "o_proj")) != RCA_OK ||
-                (rc = lm_finish_q8(h, L.wgu, none, (int)(2 * F), (int)H, 0, &L.qgu, "the fused gate/up projection")) != RCA_OK ||
-                (rc = lm_finish_q8(h, L.wdown, none, (int)H, (int)F, 0, &L.qdown, "down_proj")) != RCA_OK) return bail(rc);
-        }
-    }
     if ((rc = lm_common_init(h, nullptr, 0)) != RCA_OK) return bail(rc);
     *out = h;
     return RCA_OK;
@@ -1615,11 +1774,14 @@ extern "C" int rca_lm_create_shared(rca_lm_t* parent, int32_t n_ctx, int32_t log
     int rc;
     if ((rc = lm_new(&cfg, parent->device, &h)) != RCA_OK) return rc;
     h->embed = owner->embed;
+    h->embed_f32 = owner->embed_f32;
     h->head = owner->head;
-    h->qhead = owner->qhead;
     h->final_norm = owner->final_norm;
     h->layers = owner->layers;
     h->weights_of = owner;
+    // the twin evaluates with the kernels its parent would use (the shadow cache must hold the bits recompute_kv_cache would leave)
+    h->fuse_attn = parent->fuse_attn;
+    h->mfma_prefill = parent->mfma_prefill;
     owner->borrowers++;
     if ((rc = lm_common_init(h, nullptr, 0, owner)) != RCA_OK) { rca_lm_destroy(h); return rc; }
     *out = h;
@@ -1656,45 +1818,45 @@ static GemvGeom gemv_geom(int kind, int N, bool q8) {
     return g;
 }
 template <int M, int NIT, int PRO, int EPI, int Q>
-static void launch_gemv_r(const GemvGeom& g, rca_lm* h, const bf16_t* W, const Q8Mat& q8, const float* x, float* y, int N, int K, int ldy, const GemvPro& pro,
+static void launch_gemv_r(const GemvGeom& g, rca_lm* h, const WMat& w, const float* x, float* y, int N, int K, int ldy, const GemvPro& pro,
                           const GemvRope& rope, hipStream_t st) {
     const int grid = cdiv(cdiv(N, g.R), g.bpw);
-    const GemvQ8 qa{q8.qs, q8.sc};
+    const GemvQ8 qa{w.qs, w.sc};
     switch (g.R) {
-        case 4: lm_gemv_kernel<M, NIT, 4, PRO, EPI, Q><<<grid, 256, 0, st>>>(h->stt, W, x, y, N, K, g.bpw, ldy, pro, rope, qa); break;
-        case 8: lm_gemv_kernel<M, NIT, 8, PRO, EPI, Q><<<grid, 256, 0, st>>>(h->stt, W, x, y, N, K, g.bpw, ldy, pro, rope, qa); break;
-        default: lm_gemv_kernel<M, NIT, 16, PRO, EPI, Q><<<grid, 256, 0, st>>>(h->stt, W, x, y, N, K, g.bpw, ldy, pro, rope, qa); break;
+        case 4: lm_gemv_kernel<M, NIT, 4, PRO, EPI, Q><<<grid, 256, 0, st>>>(h->stt, w.w, x, y, N, K, g.bpw, ldy, pro, rope, qa); break;
+        case 8: lm_gemv_kernel<M, NIT, 8, PRO, EPI, Q><<<grid, 256, 0, st>>>(h->stt, w.w, x, y, N, K, g.bpw, ldy, pro, rope, qa); break;
+        default: lm_gemv_kernel<M, NIT, 16, PRO, EPI, Q><<<grid, 256, 0, st>>>(h->stt, w.w, x, y, N, K, g.bpw, ldy, pro, rope, qa); break;
     }
 }
 template <int PRO, int EPI, int Q>
-static void launch_gemv_q(GemvGeom g, rca_lm* h, int M, const bf16_t* W, const Q8Mat& q8, const float* x, float* y, int N, int K, int ldy, const GemvPro& pro,
+static void launch_gemv_q(GemvGeom g, rca_lm* h, int M, const WMat& w, const float* x, float* y, int N, int K, int ldy, const GemvPro& pro,
                           const GemvRope& rope, hipStream_t st) {
     const int nit = cdiv(cdiv(K >> 3, 4), 64);
     // 16-byte weight loads in flight per lane: at most 16 (registers); q8_0 needs one load per row PAIR
-    const int lpr = Q ? 2 : 1;
+    const int lpr = Q == WF_Q8 ? 2 : 1;
     while (g.R > 4 && (g.R / lpr) * (nit == 3 ? 4 : nit) > 16) g.R >>= 1;
     if (PRO == 0 && EPI == 3 && nit > 1) {
         if (nit == 2) {
-            if (M == 1) launch_gemv_r<1, 2, 0, 3, Q>(g, h, W, q8, x, y, N, K, ldy, pro, rope, st);
-            else launch_gemv_r<2, 2, 0, 3, Q>(g, h, W, q8, x, y, N, K, ldy, pro, rope, st);
+            if (M == 1) launch_gemv_r<1, 2, 0, 3, Q>(g, h, w, x, y, N, K, ldy, pro, rope, st);
+            else launch_gemv_r<2, 2, 0, 3, Q>(g, h, w, x, y, N, K, ldy, pro, rope, st);
         } else {
-            if (M == 1) launch_gemv_r<1, 4, 0, 3, Q>(g, h, W, q8, x, y, N, K, ldy, pro, rope, st);
-            else launch_gemv_r<2, 4, 0, 3, Q>(g, h, W, q8, x, y, N, K, ldy, pro, rope, st);
+            if (M == 1) launch_gemv_r<1, 4, 0, 3, Q>(g, h, w, x, y, N, K, ldy, pro, rope, st);
+            else launch_gemv_r<2, 4, 0, 3, Q>(g, h, w, x, y, N, K, ldy, pro, rope, st);
         }
         return;
     }
-    if (M == 1) launch_gemv_r<1, 1, PRO, EPI, Q>(g, h, W, q8, x, y, N, K, ldy, pro, rope, st);
-    else launch_gemv_r<2, 1, PRO, EPI, Q>(g, h, W, q8, x, y, N, K, ldy, pro, rope, st);
+    if (M == 1) launch_gemv_r<1, 1, PRO, EPI, Q>(g, h, w, x, y, N, K, ldy, pro, rope, st);
+    else launch_gemv_r<2, 1, PRO, EPI, Q>(g, h, w, x, y, N, K, ldy, pro, rope, st);
 }
-// M = 1 or 2 tokens.  Only the down projection (K = ffn) needs more than one chunk per lane and wave.  A matrix that has a packed
-// q8_0 form streams that (half the bytes); the bf16 matrix is then only read by the prefill tiles.
+// M = 1 or 2 tokens.  Only the down projection (K = ffn) needs more than one chunk per lane and wave.  The matrix is streamed in the
+// format it is kept in.
 template <int PRO, int EPI>
-static void launch_gemv(int kind, rca_lm* h, int M, const bf16_t* W, const Q8Mat& q8, const float* x, float* y, int N, int K, int ldy, const GemvPro& pro,
+static void launch_gemv(int kind, rca_lm* h, int M, const WMat& w, const float* x, float* y, int N, int K, int ldy, const GemvPro& pro,
                         const GemvRope& rope, hipStream_t st) {
-    const bool use_q8 = q8.qs != nullptr && h->use_q8;
-    const GemvGeom g = gemv_geom(kind, N, use_q8);
-    if (use_q8) launch_gemv_q<PRO, EPI, 1>(g, h, M, W, q8, x, y, N, K, ldy, pro, rope, st);
-    else launch_gemv_q<PRO, EPI, 0>(g, h, M, W, q8, x, y, N, K, ldy, pro, rope, st);
+    const GemvGeom g = gemv_geom(kind, N, w.fmt == WF_Q8);
+    if (w.fmt == WF_Q8) launch_gemv_q<PRO, EPI, WF_Q8>(g, h, M, w, x, y, N, K, ldy, pro, rope, st);
+    else if (w.fmt == WF_F16) launch_gemv_q<PRO, EPI, WF_F16>(g, h, M, w, x, y, N, K, ldy, pro, rope, st);
+    else launch_gemv_q<PRO, EPI, WF_BF16>(g, h, M, w, x, y, N, K, ldy, pro, rope, st);
 }
 
 // Merge of the splits of one (token, head) row by ONE wave, lane <-> dim, in split order.  Latency code: every load it will ever
@@ -2040,21 +2202,21 @@ static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st, in
     GemvRope rope{h->cos_t, h->sin_t, nullptr, nullptr, c.n_heads, c.n_kv_heads, c.n_ctx};
     const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     float* x = h->x;
-    lm_embed_kernel<<<M, 256, 0, st>>>(h->stt, h->embed, x, H, c.vocab_size);
+    lm_embed_kernel<<<M, 256, 0, st>>>(h->stt, h->embed, h->embed_f32, x, H, c.vocab_size);
     for (int l = 0; l < c.n_layers; ++l) {
         const LmLayer& L = h->layers[l];
         f16_t* kc = h->kc + (long)l * h->kv_layer_stride;
         f16_t* vc = h->vc + (long)l * h->kv_layer_stride;
         rope.kc = kc; rope.vc = vc;
-        launch_gemv<1, 2>(GEMV_QKV, h, M, L.wqkv, L.qqkv, nullptr, h->qkv, QKV, H, QKV, GemvPro{x, L.attn_norm, c.rms_eps, 0}, rope, st);
+        launch_gemv<1, 2>(GEMV_QKV, h, M, L.qkv, nullptr, h->qkv, QKV, H, QKV, GemvPro{x, L.attn_norm, c.rms_eps, 0}, rope, st);
         launch_attention_mfma(h, M, nsp_launch, kc, vc, st);
-        launch_gemv<0, 3>(GEMV_O, h, M, L.wo, L.qo, h->attn, x, H, AO, H, nopro, norope, st);
-        launch_gemv<1, 1>(GEMV_GU, h, M, L.wgu, L.qgu, nullptr, h->hbuf, 2 * F, H, F, GemvPro{x, L.ffn_norm, c.rms_eps, 0}, norope, st);
-        launch_gemv<0, 3>(GEMV_DOWN, h, M, L.wdown, L.qdown, h->hbuf, x, H, F, H, nopro, norope, st);
+        launch_gemv<0, 3>(GEMV_O, h, M, L.o, h->attn, x, H, AO, H, nopro, norope, st);
+        launch_gemv<1, 1>(GEMV_GU, h, M, L.gu, nullptr, h->hbuf, 2 * F, H, F, GemvPro{x, L.ffn_norm, c.rms_eps, 0}, norope, st);
+        launch_gemv<0, 3>(GEMV_DOWN, h, M, L.down, h->hbuf, x, H, F, H, nopro, norope, st);
     }
     if (want_logits) {
         const int only_last = want_logits == 1 ? 1 : 0;
-        launch_gemv<1, 0>(GEMV_HEAD, h, only_last ? 1 : M, h->head, h->qhead, nullptr, h->logits, c.vocab_size, H, c.vocab_size,
+        launch_gemv<1, 0>(GEMV_HEAD, h, only_last ? 1 : M, h->head, nullptr, h->logits, c.vocab_size, H, c.vocab_size,
                           GemvPro{x, h->final_norm, c.rms_eps, only_last}, norope, st);
     }
     RCA_LAUNCH_CHECK();
@@ -2073,9 +2235,30 @@ static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st, in
 // add); with several (the narrow N = hidden projections, to put more than 16 workgroups on the chip) each split
 // stores its partial sums and lm_gemm128_epilogue_kernel adds them in split order and runs the epilogue -- deterministic.
 #define G128_PITCH 40
-#define G128_LDS (2 * 3 * 128 * G128_PITCH * 2)
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __restrict__ stt, const bf16_t* __restrict__ W,
+#define G128_LDS_T(NT) (2 * (NT) * 128 * G128_PITCH * 2)
+#define G128_LDS G128_LDS_T(3)
+// Weight formats other than bf16 (WF): the matrix is kept ONCE, in the format the decode GEMV streams, and de-quantised while it is
+// staged -- a thread turns its 16 weights of the stage into f32 (fp16: widened; q8_0: d * q, exact in f32) and splits each into
+// bf16 hi + bf16 lo (hi = RNE(w), lo = RNE(w - hi): exact for fp16 values, within 2^-17 for d * q), written to a fourth LDS tile.
+// Three MFMAs per k step instead of two: w_hi x_hi + w_hi x_lo + w_lo x_hi (the dropped w_lo x_lo term is below the 16 bits the
+// activation split keeps anyway).  So prefill and decode see the same weights to 2^-17, whatever the format.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {   // v_cvt_pk_bf16_f32: round to nearest even
+    const bf16x2_t v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void split_w8(const float (&w)[8], uint4& hi, uint4& lo) {
+    unsigned ph[4], pl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ph[j] = pack_bf16x2(w[2 * j], w[2 * j + 1]);
+        pl[j] = pack_bf16x2(w[2 * j] - bf16_lo(ph[j]), w[2 * j + 1] - bf16_hi(ph[j]));
+    }
+    hi = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+    lo = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+}
+template <int EPI, int WF>
+__global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __restrict__ stt, const bf16_t* __restrict__ W, GemvQ8 q8,
                                                             const bf16_t* __restrict__ xh, const bf16_t* __restrict__ xl, int N, int K,
                                                             int kslice, float* __restrict__ y, int ldy, bf16_t* __restrict__ oh,
                                                             bf16_t* __restrict__ ol, float* __restrict__ part, GemvRope rope, int nseq) {
@@ -2083,8 +2266,9 @@ __global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __
     // added to a running total -- exactly the additions, in exactly the order, of "every slice its own workgroup, then
     // lm_gemm128_epilogue_kernel adds the partial sums starting from 0" -- so the result does not depend on which of the two forms a
     // pass used, and the partial sums never travel through HBM.  Used where the token blocks alone fill the chip.
-    extern __shared__ __attribute__((aligned(16))) bf16_t g128_lds[];   // [2 buffers][W, xh, xl][128 rows][G128_PITCH]
-    typedef bf16_t tile_t[3][128 * G128_PITCH];
+    constexpr int NT = WF == WF_BF16 ? 3 : 4;   // LDS tiles per buffer: W (hi), xh, xl [, W lo]
+    extern __shared__ __attribute__((aligned(16))) bf16_t g128_lds[];   // [2 buffers][NT][128 rows][G128_PITCH]
+    typedef bf16_t tile_t[NT][128 * G128_PITCH];
     tile_t* sm = reinterpret_cast<tile_t*>(g128_lds);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -2104,14 +2288,30 @@ __global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __
     const bf16_t* gL = xl + (long)(tb + srow0) * K + ks + skc;
     const long rstep = 64L * K;     // second chunk: row + 64
     const int soff0 = srow0 * G128_PITCH + skc, soff1 = soff0 + 64 * G128_PITCH;
+    // q8_0: a thread's stage is ONE 16-byte unit of the packed layout = 8 k of the two rows of pair (n0 / 2 + tid / 4); the pair's
+    // rows are (2p, 2p + 1), or (d, d + 32) of one head in the fused QKV matrix (the only matrix that runs the RoPE epilogue)
+    const int qp = tid >> 2;
+    const long q_npairs = N >> 1;
+    const u32x4* gQ = WF == WF_Q8 ? q8.qs + ((long)(n0 >> 1) + qp) * (K >> 3) + (ks >> 3) + (tid & 3) : nullptr;
+    const unsigned* gS = WF == WF_Q8 ? q8.sc + (long)(ks >> 5) * q_npairs + (n0 >> 1) + qp : nullptr;
+    const int qra = EPI == GEMM_EPI_ROPE ? (qp >> 5) * 64 + (qp & 31) : 2 * qp;
+    const int qsoff0 = qra * G128_PITCH + skc, qsoff1 = qsoff0 + (EPI == GEMM_EPI_ROPE ? 32 : 1) * G128_PITCH;
     // Software pipeline.  A workgroup's stage needs 8 KB of weights straight from HBM (~2 us away) and 16 KB of
     // activations from L2 (~0.7 us): weight chunks are requested DW stages ahead, activation chunks DX stages ahead,
     // both held in registers until their LDS buffer is free.
     constexpr int DW = 1, DX = 1;   // measured: deeper register prefetch (4 / 2) is slower at 2 workgroups per CU
     uint4 rw[DW][2], rh[DX][2], rl[DX][2];
+    unsigned rs[DW];
     auto gload_w = [&](int slot, int s) {
-        const int k = min(s, nstage - 1) << 5;
-        rw[slot][0] = *reinterpret_cast<const uint4*>(gW + k); rw[slot][1] = *reinterpret_cast<const uint4*>(gW + rstep + k);
+        const int st = min(s, nstage - 1);
+        if (WF == WF_Q8) {
+            const u32x4 t = gQ[st * 4];
+            rw[slot][0] = make_uint4(t.x, t.y, t.z, t.w);
+            rs[slot] = gS[(long)st * q_npairs];
+        } else {
+            const int k = st << 5;
+            rw[slot][0] = *reinterpret_cast<const uint4*>(gW + k); rw[slot][1] = *reinterpret_cast<const uint4*>(gW + rstep + k);
+        }
     };
     auto gload_x = [&](int slot, int s) {
         const int k = min(s, nstage - 1) << 5;
@@ -2119,7 +2319,39 @@ __global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __
         rl[slot][0] = *reinterpret_cast<const uint4*>(gL + k); rl[slot][1] = *reinterpret_cast<const uint4*>(gL + rstep + k);
     };
     auto swrite = [&](int buf, int ws, int xs) {
-        *reinterpret_cast<uint4*>(&sm[buf][0][soff0]) = rw[ws][0]; *reinterpret_cast<uint4*>(&sm[buf][0][soff1]) = rw[ws][1];
+        if (WF == WF_BF16) {
+            *reinterpret_cast<uint4*>(&sm[buf][0][soff0]) = rw[ws][0]; *reinterpret_cast<uint4*>(&sm[buf][0][soff1]) = rw[ws][1];
+        } else if (WF == WF_F16) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const unsigned u[4] = {rw[ws][c].x, rw[ws][c].y, rw[ws][c].z, rw[ws][c].w};
+                float wv[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f16x2 h2 = __builtin_bit_cast(f16x2, u[j]);
+                    wv[2 * j] = (float)h2[0];
+                    wv[2 * j + 1] = (float)h2[1];
+                }
+                uint4 hi, lo;
+                split_w8(wv, hi, lo);
+                *reinterpret_cast<uint4*>(&sm[buf][0][c ? soff1 : soff0]) = hi;
+                *reinterpret_cast<uint4*>(&sm[buf][3][c ? soff1 : soff0]) = lo;
+            }
+        } else {   // q8_0: .x .y = 8 int8 of the pair's first row, .z .w = of its second row; rs = (fp16 d_a, fp16 d_b)
+            const f16x2 d2 = __builtin_bit_cast(f16x2, rs[ws]);
+            const unsigned u[4] = {rw[ws][0].x, rw[ws][0].y, rw[ws][0].z, rw[ws][0].w};
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float dd = (float)d2[c];
+                float wv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wv[j] = dd * (float)(signed char)((u[2 * c + (j >> 2)] >> (8 * (j & 3))) & 0xffu);
+                uint4 hi, lo;
+                split_w8(wv, hi, lo);
+                *reinterpret_cast<uint4*>(&sm[buf][0][c ? qsoff1 : qsoff0]) = hi;
+                *reinterpret_cast<uint4*>(&sm[buf][3][c ? qsoff1 : qsoff0]) = lo;
+            }
+        }
         *reinterpret_cast<uint4*>(&sm[buf][1][soff0]) = rh[xs][0]; *reinterpret_cast<uint4*>(&sm[buf][1][soff1]) = rh[xs][1];
         *reinterpret_cast<uint4*>(&sm[buf][2][soff0]) = rl[xs][0]; *reinterpret_cast<uint4*>(&sm[buf][2][soff1]) = rl[xs][1];
     };
@@ -2151,10 +2383,11 @@ __global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __
             gload_x(d % DX, s + DX);
 #pragma unroll
             for (int ksub = 0; ksub < 2; ++ksub) {
-                bf16x8 a[2], bh[2], bl[2];
+                bf16x8 a[2], al[2], bh[2], bl[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     a[i] = *reinterpret_cast<const bf16x8*>(&sm[buf][0][fa + i * 32 * G128_PITCH + ksub * 16]);
+                    if (WF != WF_BF16) al[i] = *reinterpret_cast<const bf16x8*>(&sm[buf][NT - 1][fa + i * 32 * G128_PITCH + ksub * 16]);
                     bh[i] = *reinterpret_cast<const bf16x8*>(&sm[buf][1][fb + i * 32 * G128_PITCH + ksub * 16]);
                     bl[i] = *reinterpret_cast<const bf16x8*>(&sm[buf][2][fb + i * 32 * G128_PITCH + ksub * 16]);
                 }
@@ -2164,6 +2397,7 @@ __global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __
                     for (int j = 0; j < 2; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bh[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
+                        if (WF != WF_BF16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
                     }
             }
             if (nseq > 1 && (s + 1) % spf == 0) {   // end of a slice: fold it into the running total (0 + p0, then + p1, ...)
@@ -2322,10 +2556,19 @@ __global__ __launch_bounds__(256) void lm_gemm128_epilogue_kernel(const LmDevSta
     }
 }
 
+static bool lm_all_bf16(const rca_lm* h) {
+    for (const LmLayer& L : h->layers)
+        for (const WMat* m : {&L.qkv, &L.o, &L.gu, &L.down})
+            if (m->fmt != WF_BF16) return false;
+    return true;
+}
+static bool lm_can_gemm128(const rca_lm* h);
+// the 32-token tiles read bf16 fragments straight from HBM: bf16 models only; the 128-token tiles de-quantise any format while staging
 static bool lm_can_mfma_prefill(const rca_lm* h) {
     const rca_lm_config_t& c = h->cfg;
     const int AO = c.n_heads * c.head_dim;
-    return c.hidden % 64 == 0 && AO % 64 == 0 && c.ffn % 64 == 0 && (2 * c.ffn) % 32 == 0;
+    if (lm_can_gemm128(h)) return true;
+    return lm_all_bf16(h) && c.hidden % 64 == 0 && AO % 64 == 0 && c.ffn % 64 == 0 && (2 * c.ffn) % 32 == 0;
 }
 static int lm_enqueue_prefill_tile(rca_lm* h, int M, hipStream_t st, int nsp_launch) {
     const rca_lm_config_t& c = h->cfg;
@@ -2333,7 +2576,7 @@ static int lm_enqueue_prefill_tile(rca_lm* h, int M, hipStream_t st, int nsp_lau
     GemvRope rope{h->cos_t, h->sin_t, nullptr, nullptr, c.n_heads, c.n_kv_heads, c.n_ctx};
     const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     float* x = h->x;
-    lm_embed_kernel<<<M, 256, 0, st>>>(h->stt, h->embed, x, H, c.vocab_size);
+    lm_embed_kernel<<<M, 256, 0, st>>>(h->stt, h->embed, h->embed_f32, x, H, c.vocab_size);
     for (int l = 0; l < c.n_layers; ++l) {
         const LmLayer& L = h->layers[l];
         f16_t* kc = h->kc + (long)l * h->kv_layer_stride;
@@ -2341,18 +2584,18 @@ static int lm_enqueue_prefill_tile(rca_lm* h, int M, hipStream_t st, int nsp_lau
         rope.kc = kc; rope.vc = vc;
         lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.attn_norm, h->xn, H, c.rms_eps);
         lm_split_bf16_kernel<<<dim3(cdiv(H, 256), M), 256, 0, st>>>(h->stt, h->xn, h->xh, h->xl, H);
-        lm_gemm_mfma_kernel<GEMM_EPI_ROPE><<<QKV / 32, 256, 0, st>>>(h->stt, L.wqkv, h->xh, h->xl, QKV, H, h->qkv, QKV, nullptr, nullptr, rope);
+        lm_gemm_mfma_kernel<GEMM_EPI_ROPE><<<QKV / 32, 256, 0, st>>>(h->stt, L.qkv.w, h->xh, h->xl, QKV, H, h->qkv, QKV, nullptr, nullptr, rope);
         launch_attention_mfma(h, M, nsp_launch, kc, vc, st);
         lm_split_bf16_kernel<<<dim3(cdiv(AO, 256), M), 256, 0, st>>>(h->stt, h->attn, h->xh, h->xl, AO);
-        lm_gemm_mfma_kernel<GEMM_EPI_RESID><<<H / 32, 256, 0, st>>>(h->stt, L.wo, h->xh, h->xl, H, AO, x, H, nullptr, nullptr, norope);
+        lm_gemm_mfma_kernel<GEMM_EPI_RESID><<<H / 32, 256, 0, st>>>(h->stt, L.o.w, h->xh, h->xl, H, AO, x, H, nullptr, nullptr, norope);
         lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.ffn_norm, h->xn, H, c.rms_eps);
         lm_split_bf16_kernel<<<dim3(cdiv(H, 256), M), 256, 0, st>>>(h->stt, h->xn, h->xh, h->xl, H);
         // SwiGLU epilogue writes the hi/lo split of h straight into the (ffn-wide) split buffers of the down projection:
         // it reads xh/xl [M][H] and writes [M][F] -- distinct regions are needed, so h goes to the second half of hbuf
         bf16_t* hh = reinterpret_cast<bf16_t*>(h->hbuf);
         bf16_t* hl = hh + (long)LM_MAXM * F;
-        lm_gemm_mfma_kernel<GEMM_EPI_SWIGLU><<<2 * F / 32, 256, 0, st>>>(h->stt, L.wgu, h->xh, h->xl, 2 * F, H, nullptr, F, hh, hl, norope);
-        lm_gemm_mfma_kernel<GEMM_EPI_RESID><<<H / 32, 256, 0, st>>>(h->stt, L.wdown, hh, hl, H, F, x, H, nullptr, nullptr, norope);
+        lm_gemm_mfma_kernel<GEMM_EPI_SWIGLU><<<2 * F / 32, 256, 0, st>>>(h->stt, L.gu.w, h->xh, h->xl, 2 * F, H, nullptr, F, hh, hl, norope);
+        lm_gemm_mfma_kernel<GEMM_EPI_RESID><<<H / 32, 256, 0, st>>>(h->stt, L.down.w, hh, hl, H, F, x, H, nullptr, nullptr, norope);
     }
     RCA_LAUNCH_CHECK();
     return RCA_OK;
@@ -2371,6 +2614,24 @@ static bool lm_can_gemm128(const rca_lm* h) {
     const int G = c.n_heads / c.n_kv_heads;
     return c.head_dim == 64 && (G == 1 || G == 2 || G == 4) && H % 128 == 0 && QKV % 128 == 0 && (2 * F) % 128 == 0 && AO % 32 == 0 && F % 32 == 0;
 }
+// one 128-row GEMM launch in the format the matrix is kept in
+template <int EPI>
+static void launch_gemm128(rca_lm* h, const WMat& w, dim3 grid, hipStream_t st, const bf16_t* xh, const bf16_t* xl, int N, int K, int kslice,
+                           float* y, int ldy, bf16_t* oh, bf16_t* ol, GemvRope rope, int nseq) {
+    static bool attr_done = false;
+    if (!attr_done) {   // the four-tile variants need 80 KB of LDS
+        (void)hipFuncSetAttribute((const void*)lm_gemm128_kernel<EPI, WF_Q8>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS_T(4));
+        (void)hipFuncSetAttribute((const void*)lm_gemm128_kernel<EPI, WF_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS_T(4));
+        attr_done = true;
+    }
+    const GemvQ8 qa{w.qs, w.sc};
+    if (w.fmt == WF_Q8)
+        lm_gemm128_kernel<EPI, WF_Q8><<<grid, 256, G128_LDS_T(4), st>>>(h->stt, w.w, qa, xh, xl, N, K, kslice, y, ldy, oh, ol, h->gpart, rope, nseq);
+    else if (w.fmt == WF_F16)
+        lm_gemm128_kernel<EPI, WF_F16><<<grid, 256, G128_LDS_T(4), st>>>(h->stt, w.w, qa, xh, xl, N, K, kslice, y, ldy, oh, ol, h->gpart, rope, nseq);
+    else
+        lm_gemm128_kernel<EPI, WF_BF16><<<grid, 256, G128_LDS_T(3), st>>>(h->stt, w.w, qa, xh, xl, N, K, kslice, y, ldy, oh, ol, h->gpart, rope, nseq);
+}
 static int lm_enqueue_prefill_tile128(rca_lm* h, int M, hipStream_t st, int nsp_launch) {
     const rca_lm_config_t& c = h->cfg;
     const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim, F = c.ffn;
@@ -2385,17 +2646,17 @@ static int lm_enqueue_prefill_tile128(rca_lm* h, int M, hipStream_t st, int nsp_
     auto seq = [&](int N, int ns) { return ns > 1 && seq_min > 0 && (N / 128) * tbz >= seq_min; };
     const bool q_seq = seq(QKV, sq), o_seq = seq(H, so), gu_seq = seq(2 * F, sg), d_seq = seq(H, sd);
     float* x = h->x;
-    lm_embed_kernel<<<M, 256, 0, st>>>(h->stt, h->embed, x, H, c.vocab_size);
+    lm_embed_kernel<<<M, 256, 0, st>>>(h->stt, h->embed, h->embed_f32, x, H, c.vocab_size);
     for (int l = 0; l < c.n_layers; ++l) {
         const LmLayer& L = h->layers[l];
         f16_t* kc = h->kc + (long)l * h->kv_layer_stride;
         f16_t* vc = h->vc + (long)l * h->kv_layer_stride;
         rope.kc = kc; rope.vc = vc;
         lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.attn_norm, h->xn, H, c.rms_eps, h->xh, h->xl);
-        lm_gemm128_kernel<GEMM_EPI_ROPE><<<dim3(QKV / 128, q_seq ? 1 : sq, tbz), 256, G128_LDS, st>>>(h->stt, L.wqkv, h->xh, h->xl, QKV, H, H / sq, h->qkv, QKV, nullptr, nullptr, h->gpart, rope, q_seq ? sq : 1);
+        launch_gemm128<GEMM_EPI_ROPE>(h, L.qkv, dim3(QKV / 128, q_seq ? 1 : sq, tbz), st, h->xh, h->xl, QKV, H, H / sq, h->qkv, QKV, nullptr, nullptr, rope, q_seq ? sq : 1);
         if (sq > 1 && !q_seq) lm_gemm128_epilogue_kernel<GEMM_EPI_ROPE><<<dim3(QKV / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sq, QKV, h->qkv, nullptr, nullptr, rope);
         launch_attention_mfma(h, M, nsp_launch, kc, vc, st, h->xh, h->xl);
-        lm_gemm128_kernel<GEMM_EPI_RESID><<<dim3(H / 128, o_seq ? 1 : so, tbz), 256, G128_LDS, st>>>(h->stt, L.wo, h->xh, h->xl, H, AO, AO / so, x, H, nullptr, nullptr, h->gpart, norope, o_seq ? so : 1);
+        launch_gemm128<GEMM_EPI_RESID>(h, L.o, dim3(H / 128, o_seq ? 1 : so, tbz), st, h->xh, h->xl, H, AO, AO / so, x, H, nullptr, nullptr, norope, o_seq ? so : 1);
         if (so > 1 && !o_seq) lm_gemm128_epilogue_kernel<GEMM_EPI_RESID><<<dim3(H / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, so, H, x, nullptr, nullptr, norope);
         lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.ffn_norm, h->xn, H, c.rms_eps, h->xh, h->xl);
         // SwiGLU epilogue writes the hi/lo split of h straight into the (ffn-wide) split buffers of the down projection:
@@ -2403,12 +2664,12 @@ static int lm_enqueue_prefill_tile128(rca_lm* h, int M, hipStream_t st, int nsp_
         bf16_t* hh = reinterpret_cast<bf16_t*>(h->hbuf);
         bf16_t* hl = hh + (long)LM_MAXM * F;
         if (gu_seq) {   // the token blocks alone fill the chip: every workgroup walks the slices itself (same sums, same order, no partials)
-            lm_gemm128_kernel<GEMM_EPI_SWIGLU><<<dim3(2 * F / 128, 1, tbz), 256, G128_LDS, st>>>(h->stt, L.wgu, h->xh, h->xl, 2 * F, H, H / sg, nullptr, F, hh, hl, h->gpart, norope, sg);
+            launch_gemm128<GEMM_EPI_SWIGLU>(h, L.gu, dim3(2 * F / 128, 1, tbz), st, h->xh, h->xl, 2 * F, H, H / sg, nullptr, F, hh, hl, norope, sg);
         } else {
-            lm_gemm128_kernel<GEMM_EPI_SWIGLU><<<dim3(2 * F / 128, sg, tbz), 256, G128_LDS, st>>>(h->stt, L.wgu, h->xh, h->xl, 2 * F, H, H / sg, nullptr, F, hh, hl, h->gpart, norope, 1);
+            launch_gemm128<GEMM_EPI_SWIGLU>(h, L.gu, dim3(2 * F / 128, sg, tbz), st, h->xh, h->xl, 2 * F, H, H / sg, nullptr, F, hh, hl, norope, 1);
             if (sg > 1) lm_gemm128_epilogue_kernel<GEMM_EPI_SWIGLU><<<dim3(2 * F / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sg, 2 * F, nullptr, hh, hl, norope);
         }
-        lm_gemm128_kernel<GEMM_EPI_RESID><<<dim3(H / 128, d_seq ? 1 : sd, tbz), 256, G128_LDS, st>>>(h->stt, L.wdown, hh, hl, H, F, F / sd, x, H, nullptr, nullptr, h->gpart, norope, d_seq ? sd : 1);
+        launch_gemm128<GEMM_EPI_RESID>(h, L.down, dim3(H / 128, d_seq ? 1 : sd, tbz), st, hh, hl, H, F, F / sd, x, H, nullptr, nullptr, norope, d_seq ? sd : 1);
         if (sd > 1 && !d_seq) lm_gemm128_epilogue_kernel<GEMM_EPI_RESID><<<dim3(H / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sd, H, x, nullptr, nullptr, norope);
     }
     RCA_LAUNCH_CHECK();
@@ -2494,7 +2755,7 @@ static int lm_eval_impl(rca_lm_t* h, const int32_t* ids, int32_t n, bool wait_la
             if (last) {   // logits of the final token: final norm + head on the register GEMV path
                 const rca_lm_config_t& c = h->cfg;
                 const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
-                launch_gemv<1, 0>(GEMV_HEAD, h, 1, h->head, h->qhead, nullptr, h->logits, c.vocab_size, c.hidden, c.vocab_size,
+                launch_gemv<1, 0>(GEMV_HEAD, h, 1, h->head, nullptr, h->logits, c.vocab_size, c.hidden, c.vocab_size,
                                   GemvPro{h->x, h->final_norm, c.rms_eps, 1}, norope, st);
                 RCA_LAUNCH_CHECK();
             }
@@ -2768,7 +3029,9 @@ extern "C" int rca_lm_frame(rca_lm_t* h, const int32_t* first_pair, const int32_
     }
     *n_done = done;
     h->n_tokens += 2 * done;
-    h->logits_rows = 1;
+    // a frame cut short leaves the logits of a LATER step (evaluated on a wrong-guess pair, rolled back above) in the buffer: nothing
+    // may read them -- get_logits / token_probs / sample fail with "no logits" until the next eval
+    h->logits_rows = done < n_steps ? 0 : 1;
     h->rng_host += (unsigned long long)done;
     if (done < n_steps) {   // the device drew n_steps times: put its counter where the step-by-step loop would be
         RCA_HIP(hipMemcpy(&h->stt->rng_counter, &h->rng_host, 8, hipMemcpyHostToDevice));
@@ -2828,9 +3091,9 @@ extern "C" int rca_lm_mask_head_rows(rca_lm_t* h, int32_t row_begin, int32_t row
     if (!h || row_begin < 0 || row_end > h->cfg.vocab_size || row_begin > row_end) return fail(RCA_ERR_ARG, "mask_head_rows: bad range");
     RCA_HIP(hipSetDevice(h->device));
     const long n = (long)(row_end - row_begin) * h->cfg.hidden;
-    if (n > 0) lm_zero_rows_kernel<<<2048, 256, 0, h->stream>>>(h->head + (long)row_begin * h->cfg.hidden, n);
-    if (n > 0 && h->qhead.sc)   // the packed q8_0 head: a row is zero when its block scales are
-        lm_q8_zero_row_scales_kernel<<<256, 256, 0, h->stream>>>(h->qhead.sc, h->cfg.vocab_size / 2, h->cfg.hidden / 32, row_begin, row_end);
+    if (n > 0 && h->head.fmt != WF_Q8) lm_zero_rows_kernel<<<2048, 256, 0, h->stream>>>(h->head.w + (long)row_begin * h->cfg.hidden, n);   // bf16 / fp16: zero bits
+    if (n > 0 && h->head.fmt == WF_Q8)   // the packed q8_0 head: a row is zero when its block scales are
+        lm_q8_zero_row_scales_kernel<<<256, 256, 0, h->stream>>>(h->head.sc, h->cfg.vocab_size / 2, h->cfg.hidden / 32, row_begin, row_end);
     RCA_LAUNCH_CHECK();
     RCA_HIP(hipStreamSynchronize(h->stream));
     return RCA_OK;
@@ -2855,7 +3118,7 @@ __global__ __launch_bounds__(256) void lm_codec_proj1_kernel(const float* __rest
 }
 
 __global__ __launch_bounds__(256) void lm_codec_proj2_kernel(const float* __restrict__ h1, const float* __restrict__ w2, const float* __restrict__ b2,
-                                                             bf16_t* __restrict__ table_rows, float* __restrict__ out_f32, int rows, int H) {
+                                                             void* __restrict__ table_rows, int f32tab, float* __restrict__ out_f32, int rows, int H) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r32 = lane & 31, hs = lane >> 5;
     const int n0 = blockIdx.y * 32, f0 = (blockIdx.x * 4 + wave) * 32;
@@ -2881,7 +3144,8 @@ __global__ __launch_bounds__(256) void lm_codec_proj2_kernel(const float* __rest
         const int n = n0 + 8 * (i / 4) + 4 * hs + (i & 3);
         if (n < rows) {
             const float v = acc[i] + bias;
-            table_rows[(long)n * H + f] = f32_to_bf16_rne(v);
+            if (f32tab) reinterpret_cast<float*>(table_rows)[(long)n * H + f] = v;   // an f32 table keeps the projector output as it is
+            else reinterpret_cast<bf16_t*>(table_rows)[(long)n * H + f] = f32_to_bf16_rne(v);
             if (out_f32) out_f32[(long)n * H + f] = v;
         }
     }
@@ -2913,7 +3177,7 @@ extern "C" int rca_lm_persist_codec_embeddings(rca_lm_t* h, const float* codec_e
         const int rows = std::min(chunk, n_codes - r0);
         lm_codec_proj1_kernel<<<(unsigned)(((long)rows * H + 255) / 256), 256, 0, h->stream>>>(de + (long)r0 * dim, dw1, db1, dh1, rows, dim, H);
         lm_codec_proj2_kernel<<<dim3((H + 127) / 128, (rows + 31) / 32), 256, 0, h->stream>>>(
-            dh1, dw2, db2, h->embed + ((long)codec_vocab_start + r0) * H, dout, rows, H);
+            dh1, dw2, db2, (char*)h->embed + ((long)codec_vocab_start + r0) * H * (h->embed_f32 ? 4 : 2), h->embed_f32, dout, rows, H);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess && out_f32) e = hipMemcpyAsync(out_f32 + (long)r0 * H, dout, (size_t)rows * H * 4, hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -2923,16 +3187,6 @@ extern "C" int rca_lm_persist_codec_embeddings(rca_lm_t* h, const float* codec_e
     return RCA_OK;
 }
 
-// test / bench knob: decode from the packed q8_0 matrices (1, default when they exist) or from their bf16(d * q) copies (0)
-extern "C" int rca_lm_set_q8_decode(rca_lm_t* h, int32_t enable) {
-    if (!h) return fail(RCA_ERR_ARG, "null");
-    { const int src = lm_settle(h); if (src != RCA_OK) return src; }
-    RCA_HIP(hipSetDevice(h->device));
-    RCA_HIP(hipStreamSynchronize(h->stream));
-    if (h->use_q8 != (enable != 0)) lm_drop_graphs(h);   // the captured steps hold the other set of kernels
-    h->use_q8 = enable != 0;
-    return RCA_OK;
-}
 // test / bench knob: merge the attention splits inside the attention launch (1, default) or in a launch of its own (0)
 extern "C" int rca_lm_set_attn_fuse(rca_lm_t* h, int32_t enable) {
     if (!h) return fail(RCA_ERR_ARG, "null");
@@ -2943,9 +3197,15 @@ extern "C" int rca_lm_set_attn_fuse(rca_lm_t* h, int32_t enable) {
     h->fuse_attn = enable != 0;
     return RCA_OK;
 }
-extern "C" int rca_lm_has_q8(const rca_lm_t* h, int32_t* out) {
-    if (!h || !out) return fail(RCA_ERR_ARG, "null");
-    *out = h->qhead.qs != nullptr || (!h->layers.empty() && h->layers[0].qgu.qs != nullptr);
+// the format the projection matrices are kept (and streamed) in: 0 bf16, 1 q8_0, 2 f16; bytes = weight bytes one decode step reads
+extern "C" int rca_lm_weight_format(const rca_lm_t* h, int32_t* fmt, int64_t* bytes_per_step) {
+    if (!h || !fmt) return fail(RCA_ERR_ARG, "null");
+    *fmt = h->layers.empty() ? h->head.fmt : h->layers[0].gu.fmt;
+    if (bytes_per_step) {
+        long b = h->head.stream_bytes();
+        for (const LmLayer& L : h->layers) b += L.qkv.stream_bytes() + L.o.stream_bytes() + L.gu.stream_bytes() + L.down.stream_bytes();
+        *bytes_per_step = b;
+    }
     return RCA_OK;
 }
 

@@ -6,10 +6,11 @@ This module reads such a file -- format v2/v3, little endian, architecture "llam
 `llm.load_weights` returns for a safetensors directory: an LMConfig and tensors under their Hugging Face
 names, so a GGUF path can be handed to LlamaForAlternatingCodeChannels / RealtimeAgentResources unchanged.
 
-Supported tensor types: F32, F16, BF16 (the device keeps bf16 weights -- exact for F16 files converted from bf16 checkpoints,
-rounded to nearest-even otherwise) and Q8_0: the projection matrices and output.weight of a Q8_0 file are handed to the library
-as their raw 34-byte blocks (RCA_Q8_0) and stay packed in HBM for the decode step; the embedding table and anything else is
-de-quantised on the host.  K-quants (Q4_K_M ...) are rejected with a clear error.
+Supported tensor types: F32 (stored as bf16 on the device), BF16, F16 (2-D tensors stay fp16, RCA_F16: the reference's default file
+is the F16 one, realtime_agent_resources.py:12) and Q8_0: the projection matrices and output.weight of a Q8_0 file are handed to
+the library as their raw 34-byte blocks (RCA_Q8_0) and stay packed in HBM, one copy, for decode and prefill; the embedding table is
+de-quantised exactly (f32 rows on the device: llama.cpp's get_rows does the same per looked-up row).  K-quants (Q4_K_M ...) are
+rejected with a clear error.
 
 Two things convert_hf_to_gguf.py does to a Llama checkpoint are undone here:
   * q_proj / k_proj rows are permuted from the rotate-half layout to interleaved pairs (LlamaModel.permute);
@@ -75,11 +76,11 @@ def _read_value(f: BinaryIO, t: int):
 
 
 def _dequant(raw: np.ndarray, ttype: int, numel: int) -> np.ndarray:
-    """-> float32 [numel] (or uint16 bf16 bits for BF16, which the loader uploads as they are)."""
+    """-> float32 [numel] (or uint16 bf16 bits for BF16 / float16 for F16, which the loader uploads as they are)."""
     if ttype == GGML_F32:
         return raw.view(np.float32)[:numel]
     if ttype == GGML_F16:
-        return raw.view(np.float16)[:numel].astype(np.float32)
+        return raw.view(np.float16)[:numel]
     if ttype == GGML_BF16:
         return raw.view(np.uint16)[:numel]
     if ttype == GGML_Q8_0:  # blocks of 32: f16 scale + 32 x int8
@@ -159,11 +160,9 @@ def load_llama_gguf(path: str, keep_q8_0: bool = True):
     else (embedding table, norms) is de-quantised here."""
     from .llm import LMConfig, rope_inv_freq
     meta, t = read_gguf(path, keep_q8_0=keep_q8_0)
-    for k in ("token_embd.weight",):
-        if hasattr(t.get(k), "dequantize"):
-            t[k] = t[k].dequantize()
-    if "output.weight" not in t and hasattr(t.get("token_embd.weight"), "dequantize"):
-        pass
+    tied_head = t.get("token_embd.weight")          # a file without output.weight ties lm_head to the table: the head keeps the blocks
+    if hasattr(tied_head, "dequantize"):
+        t["token_embd.weight"] = tied_head.dequantize()   # exact f32 rows (the device keeps the table in f32)
     arch = meta.get("general.architecture", "llama")
     if arch != "llama":
         raise GGUFError(f"{path}: architecture '{arch}' is not supported (llama is)")
@@ -182,7 +181,7 @@ def load_llama_gguf(path: str, keep_q8_0: bool = True):
                    ffn=int(m("feed_forward_length")), rms_eps=float(m("attention.layer_norm_rms_epsilon", 1e-5)),
                    rope_theta=float(m("rope.freq_base", 10000.0)), rope_scaling=None)
     w: Dict[str, np.ndarray] = {"model.embed_tokens.weight": embd, "model.norm.weight": t["output_norm.weight"],
-                                "lm_head.weight": t.get("output.weight", embd)}
+                                "lm_head.weight": t.get("output.weight", tied_head)}
     names = {"attn_q": "self_attn.q_proj", "attn_k": "self_attn.k_proj", "attn_v": "self_attn.v_proj", "attn_output": "self_attn.o_proj",
              "ffn_gate": "mlp.gate_proj", "ffn_up": "mlp.up_proj", "ffn_down": "mlp.down_proj", "attn_norm": "input_layernorm",
              "ffn_norm": "post_attention_layernorm"}
@@ -197,6 +196,9 @@ def load_llama_gguf(path: str, keep_q8_0: bool = True):
             elif g == "attn_k":
                 a = _unpermute(a, n_kv)
             w[f"model.layers.{l}.{hf}.weight"] = a
+    for k, v in list(w.items()):       # 1-D tensors (norm weights) go up as f32
+        if isinstance(v, np.ndarray) and v.dtype == np.float16 and v.ndim < 2:
+            w[k] = v.astype(np.float32)
     inv = rope_inv_freq(cfg)
     if "rope_freqs.weight" in t:  # llama3 scaling: per-frequency divisors computed by the converter
         inv = (inv / np.asarray(t["rope_freqs.weight"], dtype=np.float32).reshape(-1)).astype(np.float32)

@@ -141,6 +141,8 @@ def load_weights(model_path: str):
                     t = sf.get_tensor(k)
                     if t.dtype == torch.bfloat16:
                         weights[k] = t.view(torch.int16).numpy().view(np.uint16)
+                    elif t.dtype == torch.float16 and t.dim() == 2:   # fp16 matrices stay fp16 on the device (RCA_F16)
+                        weights[k] = t.numpy()
                     else:
                         weights[k] = t.float().numpy()
     if "lm_head.weight" not in weights:  # tied checkpoints
@@ -192,11 +194,12 @@ class LlamaForAlternatingCodeChannels:
         weight_format: Optional[str] = None,
         **_ignored,
     ):
-        """weight_format="q8_0": every projection matrix and lm_head is quantised to GGUF Q8_0 at load (as llama-quantize writes the
-        Q8_0 file the reference deploys, prep_test_model.sh:29) and the decode step streams the packed form.  A .gguf whose tensors
-        are Q8_0 already keeps them packed without this flag."""
-        if weight_format not in (None, "bf16", "q8_0"):
-            raise ValueError(f"weight_format {weight_format!r}: 'bf16' (default) or 'q8_0'")
+        """weight_format: the format every projection matrix and lm_head is KEPT in (one copy: the decode step streams it, the prefill
+        tiles de-quantise it while staging).  None = as the checkpoint supplies it (bf16 / fp16 / Q8_0 tensors keep their format, f32 is
+        rounded to bf16); "q8_0" = quantised at load like the Q8_0 file the reference deploys (prep_test_model.sh:29); "f16" = bf16
+        values converted to fp16 (the F16 file of prep_test_model.sh:28, the reference's default model)."""
+        if weight_format not in (None, "bf16", "q8_0", "f16"):
+            raise ValueError(f"weight_format {weight_format!r}: None / 'bf16' (as supplied), 'q8_0' or 'f16'")
         self._lib = N.lib()
         self.model_path = model_path
         self.verbose = verbose
@@ -234,7 +237,7 @@ class LlamaForAlternatingCodeChannels:
             n_kv_heads=config.n_kv_heads, head_dim=config.head_dim, ffn=config.ffn, n_ctx=self._n_ctx, rms_eps=config.rms_eps,
             rope_theta=config.rope_theta, rope_scaling=1 if config.rope_scaling == "llama3" else 0, rope_factor=config.rope_factor,
             rope_low_freq_factor=config.rope_low_freq_factor, rope_high_freq_factor=config.rope_high_freq_factor,
-            rope_orig_ctx=config.rope_orig_ctx, logits_all=1 if logits_all else 0, decode_weights=1 if weight_format == "q8_0" else 0,
+            rope_orig_ctx=config.rope_orig_ctx, logits_all=1 if logits_all else 0, decode_weights={"q8_0": 1, "f16": 2}.get(weight_format, 0),
         )
         self._h = C.c_void_p()
         if random_init:
@@ -250,9 +253,12 @@ class LlamaForAlternatingCodeChannels:
                 self.persist_codec_embeddings({k[len(CODEC_PREFIX):]: v for k, v in weights.items() if k.startswith(CODEC_PREFIX)},
                                               int(weights["codec.vocab_start"]), int(weights.get("codec.codebook_size", 0)) or None)
         self._finish_init(seed)
-        has = C.c_int32()
-        N.check(self._lib.rca_lm_has_q8(self._h, C.byref(has)), "rca_lm_has_q8")
-        self.weight_format = "q8_0" if has.value else "bf16"
+        self.weight_format = self._query_format()[0]
+
+    def _query_format(self):
+        fmt, nbytes = C.c_int32(), C.c_int64()
+        N.check(self._lib.rca_lm_weight_format(self._h, C.byref(fmt), C.byref(nbytes)), "rca_lm_weight_format")
+        return {0: "bf16", 1: "q8_0", 2: "f16"}[fmt.value], int(nbytes.value)
 
     def _finish_init(self, seed: int) -> None:
         self._ctx = _Ctx(self)
@@ -552,14 +558,9 @@ class LlamaForAlternatingCodeChannels:
         """Merge the attention splits inside the attention launch (default) or in a launch of its own."""
         N.check(self._lib.rca_lm_set_attn_fuse(self._h, 1 if enable else 0), "rca_lm_set_attn_fuse")
 
-    def set_q8_decode(self, enable: bool) -> None:
-        """Decode from the packed q8_0 matrices (default when the handle has them) or from their bf16(d*q) copies."""
-        N.check(self._lib.rca_lm_set_q8_decode(self._h, 1 if enable else 0), "rca_lm_set_q8_decode")
-
     def weight_bytes_per_step(self) -> int:
-        """bytes of weights one decode step streams in the format this handle decodes from"""
-        b = self.config.weight_bytes_per_step()
-        return b * 34 // 64 if self.weight_format == "q8_0" else b
+        """bytes of weights one decode step streams, in the format this handle keeps them"""
+        return self._query_format()[1]
 
     def set_graphs(self, enable: bool) -> None:
         N.check(self._lib.rca_lm_set_graphs(self._h, 1 if enable else 0), "rca_lm_set_graphs")

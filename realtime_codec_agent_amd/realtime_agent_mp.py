@@ -81,8 +81,14 @@ def _worker_main(commands, results, epoch, config, self_play_mode, gpu_id, resou
         results.put((_FAILED, traceback.format_exc()))
         return
     results.put((_READY, os.getpid()))
+    parent = os.getppid()
     while True:
-        msg = commands.get()                      # blocks while the session is idle
+        try:
+            msg = commands.get(timeout=2.0)       # blocks while the session is idle ...
+        except _queue.Empty:
+            if os.getppid() != parent:            # ... but an orphan (parent killed outright) must not keep its GPU
+                os._exit(3)
+            continue
         tag = msg[0]
         if tag == _STOP:
             return
@@ -141,6 +147,8 @@ class RealtimeAgentMultiprocessing:
         deadline = None if timeout is None else time.monotonic() + timeout
         while True:
             try:
+                if timeout is not None and timeout <= 0.0:
+                    return self._results.get_nowait()          # a poll (is_running): never block
                 return self._results.get(timeout=0.2)
             except _queue.Empty:
                 if not self._process.is_alive():

@@ -30,14 +30,21 @@ def summarize(logits: np.ndarray) -> dict:
                 mean=np.float64(logits.astype(np.float64).mean()), std=np.float64(logits.astype(np.float64).std()))
 
 
-def oracle_points():
-    """LMRef (fp16 KV, like the HIP cache) over the case: [logits after the context, after step 1, after step 2]."""
+def oracle_points(weight_format=None):
+    """LMRef (fp16 KV, like the HIP cache) over the case: [logits after the context, after step 1, after step 2].
+    weight_format="q8_0": over the model whose projections and lm_head went through llama.cpp's q8_0 rule (oracle/q8_ref.py)."""
     import torch
     from oracle import lm_ref
     cfg = config()
     ctx, steps = token_ids()
     used = np.concatenate([ctx] + steps)
-    ref = lm_ref.LMRef(cfg, lm_ref.random_weights(cfg, SEED, INIT_STD, embed_rows=used), kv_dtype=torch.float16)
+    w = lm_ref.random_weights(cfg, SEED, INIT_STD, embed_rows=used)
+    if weight_format == "q8_0":
+        from oracle import q8_ref
+        for k in list(w):
+            if k.endswith("_proj.weight") or k == "lm_head.weight":
+                w[k] = q8_ref.fake_quant(w[k])       # one matrix at a time: the 1B lm_head alone is 2 GB in f32
+    ref = lm_ref.LMRef(cfg, w, kv_dtype=torch.float16)
     pts = [ref.eval(ctx)[-1].numpy()]
     for s in steps:
         pts.append(ref.eval(s)[-1].numpy())
