@@ -16,6 +16,7 @@
 //   the steady-state step (eval 1-2 tokens + sample) is captured once per context bucket into a hipGraph; the KV
 //   position, input ids and RNG counter live in device memory so the graph replays unchanged.
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 
 #include "rca_common.h"
@@ -312,10 +313,16 @@ __device__ __forceinline__ unsigned q8_opaque(unsigned w) {
 __device__ __forceinline__ float q8_byte_to_f32(unsigned w, int b) { return (float)(signed char)((w >> (8 * b)) & 0xffu); }
 struct GemvQ8 {
     const u32x4* qs;      // [N / 2][K / 8] 16-byte units
-    const unsigned* sc;   // [K / 32][N / 2]
+    const unsigned* sc;   // [ceil(N / 16)][K / 32][8]: (fp16, fp16) per pair and 32-element block, pairs in groups of 8 -- the scales a
+                          // wave needs for a batch (<= 8 pairs x its 16 blocks) are ONE contiguous run (was [K / 32][N / 2]: 16
+                          // separate lines per wave and load)
 };
+__host__ __device__ __forceinline__ long q8_sc_index(long pair, long kblock, long nkb) { return ((pair >> 3) * nkb + kblock) * 8 + (pair & 7); }
 // The format a projection matrix is kept in (ONE copy per matrix; the decode GEMV streams it, the prefill tiles de-quantise it while
 // staging): the GEMV's template parameter Q.
+#ifndef RCA_GEMV_VARIANT
+#define RCA_GEMV_VARIANT 0
+#endif
 #define WF_BF16 0   // bf16 [N][K]
 #define WF_Q8 1     // GGUF q8_0, pair-interleaved (GemvQ8)
 #define WF_F16 2    // fp16 [N][K] (the reference's default GGUF is F16, realtime_agent_resources.py:12)
@@ -340,6 +347,7 @@ __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel
     const int n_batches = (N + R - 1) / R;
     const int b_beg = blockIdx.x * batches_per_wg;
     const int b_end = min(n_batches, b_beg + batches_per_wg);
+    if (b_beg >= n_batches) return;   // never true for the grids launch_gemv_r builds; the peeled last batch below relies on it
     // slot r of batch b -> weight row
     auto row_of = [&](int b, int r) {
         if (EPI == 2) {   // slots (2s, 2s+1) = rows (d, d+32) of one head
@@ -357,34 +365,16 @@ __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel
     // and multiplies it by x = 0.  A select or an exec mask on the loaded value would be a vector instruction on the load's
     // result, i.e. a wait for it right behind its issue -- and with it for every load issued before.
     const int cbase = cn > 0 ? c0 : 0;
-    auto load_batch = [&](int b) {
+    // weight loads of ONE row (bf16 / fp16) or row pair (q8_0) of batch b into its registers; the q8_0 scales of a batch separately
+    auto issue_row = [&](int b, int r) {
         if (Q8) {
-            const long p0 = (long)b * (R / 2);
+            const long pp = min((long)b * (R / 2) + r, (long)npairs - 1);
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int c = lane + 64 * it;
-                const int cc = cbase + (c < cn ? c : 0);
-                const unsigned* sp = q8.sc + (long)(cc >> 2) * npairs + p0;
-#pragma unroll
-                for (int s2 = 0; s2 < R / 2; ++s2) {
-                    const long pp = min(p0 + s2, (long)npairs - 1);
-                    wq[s2][it] = __builtin_nontemporal_load(q8.qs + pp * nchunk + cc);
-                }
-                if ((npairs & 3) == 0 && R / 2 >= 4) {   // aligned: the batch's scales in 16-byte loads
-#pragma unroll
-                    for (int s4 = 0; s4 < R / 8; ++s4) {
-                        const u32x4 t = *reinterpret_cast<const u32x4*>(sp + 4 * s4);
-                        wsc[it][4 * s4 + 0] = t.x; wsc[it][4 * s4 + 1] = t.y; wsc[it][4 * s4 + 2] = t.z; wsc[it][4 * s4 + 3] = t.w;
-                    }
-                } else {
-#pragma unroll
-                    for (int s2 = 0; s2 < R / 2; ++s2) wsc[it][s2] = sp[min((long)s2, (long)npairs - 1 - p0)];
-                }
+                wq[r][it] = __builtin_nontemporal_load(q8.qs + pp * nchunk + cbase + (c < cn ? c : 0));
             }
-            return;
-        }
-#pragma unroll
-        for (int r = 0; r < NL; ++r) {
+        } else {
             const int row = min(row_of(b, r), N - 1);
             const u32x4* wr = reinterpret_cast<const u32x4*>(W + (long)row * K) + cbase;
 #pragma unroll
@@ -394,6 +384,36 @@ __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel
             }
         }
     };
+    // q8_0 scales of the pairs [s_beg, s_end) of batch b (a (fp16, fp16) dword per pair and 32-element block)
+    auto issue_scales = [&](int b, int s_beg, int s_end) {
+        if (!Q8) return;
+        const long p0 = (long)b * (R / 2);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = lane + 64 * it;
+            const int cc = cbase + (c < cn ? c : 0);
+            const unsigned* sp = q8.sc + q8_sc_index(p0, cc >> 2, K >> 5);   // a batch never crosses a group of 8 pairs (R <= 16)
+            if (R / 2 >= 4) {   // four pairs per 16-byte load (groups are padded to 8 pairs: always in bounds and aligned)
+#pragma unroll
+                for (int s4 = 0; s4 < R / 8; ++s4) {
+                    if (4 * s4 < s_beg || 4 * s4 >= s_end) continue;
+                    const u32x4 t = *reinterpret_cast<const u32x4*>(sp + 4 * s4);
+                    wsc[it][4 * s4 + 0] = t.x; wsc[it][4 * s4 + 1] = t.y; wsc[it][4 * s4 + 2] = t.z; wsc[it][4 * s4 + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int s2 = 0; s2 < R / 2; ++s2)
+                    if (s2 >= s_beg && s2 < s_end) wsc[it][s2] = sp[s2];
+            }
+        }
+    };
+    // half h (0 / 1) of batch b: its scales first (they are consumed with its first pair), then its rows
+    auto load_half = [&](int b, int h) {
+        issue_scales(b, h * (NL / 2), (h + 1) * (NL / 2));
+#pragma unroll
+        for (int r = 0; r < NL / 2; ++r) issue_row(b, h * (NL / 2) + r);
+    };
+    auto load_batch = [&](int b) { load_half(b, 0); load_half(b, 1); };
     // ---- this lane's x values.  Vector-memory results return in issue order, so the (short, L2-served) loads of x and of the
     // norm weights go out FIRST and the first batch of weight loads right behind them: the prologue below then waits for its own
     // operands only while the weights stay in flight under it.  (Issued the other way round, the first use of x would wait for
@@ -467,50 +487,48 @@ __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel
     int pos0 = 0;
     if (EPI == 2) pos0 = stt->n_tokens;
 
-    for (int b = b_beg; b < b_end; ++b) {
-        float val[V];   // value index v = m * R + r
-#pragma unroll
-        for (int v = 0; v < V; ++v) val[v] = 0.0f;
+    // The weight registers of a batch are two halves that refill separately: while the second half of batch b is being consumed the
+    // first half of batch b + 1 is already in flight, and the other way round -- at least R / 2 loads per lane are outstanding from
+    // the first instruction to the last half.  (Batch-synchronous -- wait for all R rows, compute them, then ask for the next R --
+    // left the CU's memory pipe idle for the length of a batch's arithmetic between batches.)  Rows are consumed in issue order, so
+    // the waits count down row by row.  Finer refills (row by row) make this compiler keep the next batch in a second register set
+    // and copy it over behind a vmcnt(0) at the loop end, or spill (two-arm form): measured in profiles/r03/experiments.
+    auto consume_row = [&](float (&val)[V], int r) {
         if (Q8) {
 #pragma unroll
-            for (int s2 = 0; s2 < R / 2; ++s2) {
+            for (int it = 0; it < NIT; ++it) {
+                const u32x4 a = wq[r][it];
+                const unsigned wa[2] = {q8_opaque(a.x), q8_opaque(a.y)}, wb[2] = {q8_opaque(a.z), q8_opaque(a.w)};
+                float pa[M], pb[M];
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const u32x4 a = wq[s2][it];
-                    const unsigned wa[2] = {q8_opaque(a.x), q8_opaque(a.y)}, wb[2] = {q8_opaque(a.z), q8_opaque(a.w)};
-                    float pa[M], pb[M];
+                for (int m = 0; m < M; ++m) pa[m] = pb[m] = 0.0f;
 #pragma unroll
-                    for (int m = 0; m < M; ++m) pa[m] = pb[m] = 0.0f;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float fa = q8_byte_to_f32(wa[j >> 2], j & 3);
-                        const float fb = q8_byte_to_f32(wb[j >> 2], j & 3);
-#pragma unroll
-                        for (int m = 0; m < M; ++m) {
-                            pa[m] = __builtin_fmaf(fa, xr[m][it][j], pa[m]);
-                            pb[m] = __builtin_fmaf(fb, xr[m][it][j], pb[m]);
-                        }
-                    }
-                    const f16x2 d2 = __builtin_bit_cast(f16x2, wsc[it][s2]);
-                    const float da = (float)d2[0], db = (float)d2[1];
+                for (int j = 0; j < 8; ++j) {
+                    const float fa = q8_byte_to_f32(wa[j >> 2], j & 3);
+                    const float fb = q8_byte_to_f32(wb[j >> 2], j & 3);
 #pragma unroll
                     for (int m = 0; m < M; ++m) {
-                        val[m * R + 2 * s2] = __builtin_fmaf(da, pa[m], val[m * R + 2 * s2]);
-                        val[m * R + 2 * s2 + 1] = __builtin_fmaf(db, pb[m], val[m * R + 2 * s2 + 1]);
+                        pa[m] = __builtin_fmaf(fa, xr[m][it][j], pa[m]);
+                        pb[m] = __builtin_fmaf(fb, xr[m][it][j], pb[m]);
                     }
-                    // one pair at a time: without the fence the scheduler converts the bytes of EVERY load in flight up front
-                    // (16 floats each) and the kernel drops to one wave per SIMD
-                    __builtin_amdgcn_sched_barrier(0);
                 }
+                const f16x2 d2 = __builtin_bit_cast(f16x2, wsc[it][r]);
+                const float da = (float)d2[0], db = (float)d2[1];
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    val[m * R + 2 * r] = __builtin_fmaf(da, pa[m], val[m * R + 2 * r]);
+                    val[m * R + 2 * r + 1] = __builtin_fmaf(db, pb[m], val[m * R + 2 * r + 1]);
+                }
+                // one pair at a time: without the fence the scheduler converts the bytes of EVERY load in flight up front
+                // (16 floats each) and the kernel drops to one wave per SIMD
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
-#pragma unroll
-        for (int r = 0; r < NL; ++r) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const u32x4 a = wq[r][it];
                 float f[8];
-                if (Q == WF_F16) {   // fp16 weights: the widening is a v_cvt_f32_f16 (low half) / its SDWA form (high half) instead of a shift
+                if (Q == WF_F16) {   // fp16 weights: the widening is folded into v_fma_mix_f32 instead of a shift
                     const unsigned au[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -528,9 +546,17 @@ __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel
                     for (int j = 0; j < 8; ++j) val[m * R + r] = __builtin_fmaf(f[j], xr[m][it][j], val[m * R + r]);
             }
         }
-        }
-        // epilogue operands that do not depend on the sums (fetched under the reduction; issued BEFORE the next batch's weights so
-        // that waiting for them does not mean waiting for those)
+    };
+    // One batch: `more` (compile-time) = another batch of this workgroup follows, and the registers of each half refill as soon as
+    // the half has been consumed.  The loop below runs the batches that have a successor; the last one is peeled, so the refill
+    // is unconditional inside the loop (no merge of "old" and "new" register contents for the compiler to copy around).
+    auto run_batch = [&](int b, auto more_tag) {
+        constexpr bool more = decltype(more_tag)::value;
+        float val[V];   // value index v = m * R + r
+#pragma unroll
+        for (int v = 0; v < V; ++v) val[v] = 0.0f;
+        // epilogue operands that do not depend on the sums: requested here, ahead of the next batch's weights in the (in-order) return
+        // queue, so that waiting for them later does not mean waiting for those
         float yv = 0.0f, cs = 0.0f, sn = 0.0f;
         if (EPI == 3 && tid < V) {
             const int m = tid / R, row = row_of(b, tid % R);
@@ -543,8 +569,27 @@ __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel
             cs = rope.cos_t[pos * 32 + d];
             sn = rope.sin_t[pos * 32 + d];
         }
-        // the weight registers are free: request the next batch before the (latency-bound) reduction and epilogue
-        if (b + 1 < b_end) load_batch(b + 1);
+#if RCA_GEMV_VARIANT == 2
+        {   // batch-synchronous (the round-2 structure), for A/B runs
+#pragma unroll
+            for (int r = 0; r < NL; ++r) consume_row(val, r);
+            if (more) load_batch(b + 1);
+        }
+#else
+#pragma unroll
+        for (int r = 0; r < NL / 2; ++r) consume_row(val, r);
+        if (more) {
+            load_half(b + 1, 0);
+            // the second half's arithmetic does not depend on the refill above and would be scheduled in front of it (the refill
+            // would then be requested only after the WHOLE batch has landed): one register of every row passes through a volatile
+            // statement that sits behind the refill
+#pragma unroll
+            for (int r = NL / 2; r < NL; ++r) asm volatile("" : "+v"(wq[r][0].x));
+        }
+#pragma unroll
+        for (int r = NL / 2; r < NL; ++r) consume_row(val, r);
+        if (more) load_half(b + 1, 1);
+#endif
         wave_reduce_transposed<V>(val);
         const int buf = (b - b_beg) & 1;
         if ((lane & 15) == 0) {
@@ -595,7 +640,9 @@ __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel
                 }
             }
         }
-    }
+    };
+    for (int b = b_beg; b + 1 < b_end; ++b) run_batch(b, std::true_type{});
+    run_batch(b_end - 1, std::false_type{});
 }
 
 
@@ -1154,7 +1201,7 @@ __global__ __launch_bounds__(256) void lm_q8_pack_kernel(const signed char* __re
         if ((c & 3) == 0) {
             const unsigned short da = __builtin_bit_cast(unsigned short, d[ra * (K >> 5) + (c >> 2)]);
             const unsigned short db = __builtin_bit_cast(unsigned short, d[rb * (K >> 5) + (c >> 2)]);
-            sc[(long)(c >> 2) * npairs + pp] = (unsigned)da | ((unsigned)db << 16);
+            sc[q8_sc_index(pp, c >> 2, K >> 5)] = (unsigned)da | ((unsigned)db << 16);
         }
     }
 }
@@ -1535,8 +1582,8 @@ static int lm_finish_mat(rca_lm* h, RawMat* raw, int qkv_pairs, WMat* out, const
     int rc;
     const long npairs = N / 2, nchunk = K / 8;
     if ((rc = lm_alloc((void**)&out->qs, (size_t)npairs * nchunk * 16)) != RCA_OK ||
-        (rc = lm_alloc((void**)&out->sc, (size_t)(K / 32) * npairs * 4 + 256)) != RCA_OK) { raw->release(); return rc; }   // + slack: the last batch's vector scale load
-    (void)hipMemsetAsync(out->sc, 0, (size_t)(K / 32) * npairs * 4 + 256, h->stream);
+        (rc = lm_alloc((void**)&out->sc, (size_t)((npairs + 7) / 8) * (K / 32) * 8 * 4)) != RCA_OK) { raw->release(); return rc; }   // groups of 8 pairs, zero padded
+    (void)hipMemsetAsync(out->sc, 0, (size_t)((npairs + 7) / 8) * (K / 32) * 8 * 4, h->stream);
     lm_q8_pack_kernel<<<4096, 256, 0, h->stream>>>(raw->q, raw->d, N, K, qkv_pairs, out->qs, out->sc);
     hipError_t e = hipStreamSynchronize(h->stream);
     raw->release();
@@ -2291,9 +2338,9 @@ __global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __
     // q8_0: a thread's stage is ONE 16-byte unit of the packed layout = 8 k of the two rows of pair (n0 / 2 + tid / 4); the pair's
     // rows are (2p, 2p + 1), or (d, d + 32) of one head in the fused QKV matrix (the only matrix that runs the RoPE epilogue)
     const int qp = tid >> 2;
-    const long q_npairs = N >> 1;
+    const long q_nkb = K >> 5;
     const u32x4* gQ = WF == WF_Q8 ? q8.qs + ((long)(n0 >> 1) + qp) * (K >> 3) + (ks >> 3) + (tid & 3) : nullptr;
-    const unsigned* gS = WF == WF_Q8 ? q8.sc + (long)(ks >> 5) * q_npairs + (n0 >> 1) + qp : nullptr;
+    const unsigned* gS = WF == WF_Q8 ? q8.sc + q8_sc_index((n0 >> 1) + qp, ks >> 5, q_nkb) : nullptr;   // next k block: + 8
     const int qra = EPI == GEMM_EPI_ROPE ? (qp >> 5) * 64 + (qp & 31) : 2 * qp;
     const int qsoff0 = qra * G128_PITCH + skc, qsoff1 = qsoff0 + (EPI == GEMM_EPI_ROPE ? 32 : 1) * G128_PITCH;
     // Software pipeline.  A workgroup's stage needs 8 KB of weights straight from HBM (~2 us away) and 16 KB of
@@ -2307,7 +2354,7 @@ __global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __
         if (WF == WF_Q8) {
             const u32x4 t = gQ[st * 4];
             rw[slot][0] = make_uint4(t.x, t.y, t.z, t.w);
-            rs[slot] = gS[(long)st * q_npairs];
+            rs[slot] = gS[(long)st * 8];
         } else {
             const int k = st << 5;
             rw[slot][0] = *reinterpret_cast<const uint4*>(gW + k); rw[slot][1] = *reinterpret_cast<const uint4*>(gW + rstep + k);
@@ -3074,11 +3121,11 @@ extern "C" int rca_lm_set_graphs(rca_lm_t* h, int32_t enable) {
     return RCA_OK;
 }
 
-__global__ __launch_bounds__(256) void lm_q8_zero_row_scales_kernel(unsigned* __restrict__ sc, long npairs, int nblk, int row_begin, int row_end) {
+__global__ __launch_bounds__(256) void lm_q8_zero_row_scales_kernel(unsigned* __restrict__ sc, int nblk, int row_begin, int row_end) {
     const long total = (long)(row_end - row_begin) * nblk;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int row = row_begin + (int)(i / nblk), j = (int)(i % nblk);
-        unsigned short* half = reinterpret_cast<unsigned short*>(sc + (long)j * npairs + (row >> 1)) + (row & 1);
+        unsigned short* half = reinterpret_cast<unsigned short*>(sc + q8_sc_index(row >> 1, j, nblk)) + (row & 1);
         *half = 0;
     }
 }
@@ -3093,7 +3140,7 @@ extern "C" int rca_lm_mask_head_rows(rca_lm_t* h, int32_t row_begin, int32_t row
     const long n = (long)(row_end - row_begin) * h->cfg.hidden;
     if (n > 0 && h->head.fmt != WF_Q8) lm_zero_rows_kernel<<<2048, 256, 0, h->stream>>>(h->head.w + (long)row_begin * h->cfg.hidden, n);   // bf16 / fp16: zero bits
     if (n > 0 && h->head.fmt == WF_Q8)   // the packed q8_0 head: a row is zero when its block scales are
-        lm_q8_zero_row_scales_kernel<<<256, 256, 0, h->stream>>>(h->head.sc, h->cfg.vocab_size / 2, h->cfg.hidden / 32, row_begin, row_end);
+        lm_q8_zero_row_scales_kernel<<<256, 256, 0, h->stream>>>(h->head.sc, h->cfg.hidden / 32, row_begin, row_end);
     RCA_LAUNCH_CHECK();
     RCA_HIP(hipStreamSynchronize(h->stream));
     return RCA_OK;
