@@ -42,13 +42,15 @@ typedef struct rca_lm rca_lm_t;
 #define RCA_BF16 1
 #define RCA_Q8_0 2   /* GGUF block_q8_0 as stored in the file: per 32 values one fp16 scale then 32 int8 (34 bytes); numel = values */
 #define RCA_F16 3    /* IEEE half (the reference's default model file is an F16 GGUF, realtime_agent_resources.py:12) */
+#define RCA_Q4_K 4   /* GGUF block_q4_K as stored in the file: per 256 values fp16 d, fp16 dmin, 12 bytes of 6-bit scales / minima, 128 bytes
+                        of nibbles (144 bytes); numel = values.  What llama-quantize Q4_K_M writes for most tensors (prep_test_model.sh:31) */
 
 /* A named host tensor handed to a create() call (weights). */
 typedef struct {
     const char* name;
     const void* data;  /* host pointer */
     int64_t numel;
-    int32_t dtype;     /* RCA_F32, RCA_BF16, RCA_F16 (LM matrices, embedding table) or RCA_Q8_0 (LM matrices, embedding table) */
+    int32_t dtype;     /* RCA_F32, RCA_BF16, RCA_F16, RCA_Q8_0 or RCA_Q4_K (the last two: LM matrices and embedding table only) */
 } rca_tensor_t;
 
 const char* rca_last_error(void);
@@ -226,9 +228,10 @@ typedef struct {
                                  de-quantised from by the prefill tiles.  0 = as supplied: RCA_BF16 / RCA_F16 / RCA_Q8_0 tensors keep their
                                  format (RCA_F32 is rounded to bf16); 1 = quantise to q8_0 at load the way llama-quantize writes the Q8_0 file
                                  the reference deploys (prep_test_model.sh:29; 8.5 bits per weight streamed); 2 = convert bf16 to fp16 (what
-                                 convert_hf_to_gguf.py --outtype f16 writes, prep_test_model.sh:28).  Tensors that arrive quantised stay as
+                                 convert_hf_to_gguf.py --outtype f16 writes, prep_test_model.sh:28); 3 = quantise to GGUF Q4_K blocks (4.6 bits per weight streamed;
+                                 this build's own min / max rule picks the scales, the format and its de-quantisation are llama.cpp's).  Tensors that arrive quantised stay as
                                  they are.  The embedding table is gathered, not streamed, and keeps full precision: f32 rows for RCA_F32 /
-                                 RCA_F16 / RCA_Q8_0 sources, bf16 rows for RCA_BF16. */
+                                 RCA_F16 / RCA_Q8_0 / RCA_Q4_K sources, bf16 rows for RCA_BF16. */
 } rca_lm_config_t;
 
 typedef struct {
@@ -326,7 +329,7 @@ int rca_lm_set_graphs(rca_lm_t* h, int32_t enable);
  * :725-733) run as 128-token tiles on bf16 MFMA with hi/lo-split activations (default; logits within ~1e-3 of the
  * decode path); 0 routes them through the 8-token GEMV chunks, which are bit-identical to decode */
 int rca_lm_set_mfma_prefill(rca_lm_t* h, int32_t enable);
-/* the format the projection matrices are kept and streamed in (0 bf16, 1 q8_0, 2 f16) and, optionally, the weight bytes one decode
+/* the format the projection matrices are kept and streamed in (0 bf16, 1 q8_0, 2 f16, 3 q4_k) and, optionally, the weight bytes one decode
  * step reads (llama.cpp prints the same two facts at load: file type and model size) */
 int rca_lm_weight_format(const rca_lm_t* h, int32_t* fmt, int64_t* bytes_per_step);
 /* decode steps merge the attention splits inside the attention launch (1, default: the workgroup that publishes its partial last

@@ -21,7 +21,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"
                "-Wno-unused-result"]
 
 MAX_STAGES = 8
-RCA_F32, RCA_BF16, RCA_Q8_0, RCA_F16 = 0, 1, 2, 3
+RCA_F32, RCA_BF16, RCA_Q8_0, RCA_F16, RCA_Q4_K = 0, 1, 2, 3, 4
 
 
 class RcaError(RuntimeError):
@@ -45,6 +45,37 @@ class Q8Blocks:
     def take_rows(self, index) -> "Q8Blocks":
         r = self.raw[index]
         return Q8Blocks(np.ascontiguousarray(r), (r.shape[0], self.shape[1]))
+
+
+class Q4KBlocks:
+    """A GGUF Q4_K tensor kept as its raw 144-byte super-blocks (fp16 d, fp16 dmin, 12 bytes of 6-bit scales / minima, 128 bytes of
+    nibbles per 256 values): raw uint8 [rows, cols / 256 * 144], logical shape (rows, cols)."""
+
+    def __init__(self, raw: np.ndarray, shape):
+        self.shape = tuple(int(x) for x in shape)
+        self.raw = raw.reshape(self.shape[0], self.shape[1] // 256 * 144)
+        self.dtype = np.dtype(np.uint8)
+
+    def dequantize(self) -> np.ndarray:
+        """llama.cpp's dequantize_row_q4_K: (d * sc) * q - (dmin * m), f32."""
+        blk = self.raw.reshape(-1, 144)
+        d = blk[:, 0:2].copy().view(np.float16).astype(np.float32)
+        dmin = blk[:, 2:4].copy().view(np.float16).astype(np.float32)
+        s = blk[:, 4:16]
+        sc = np.empty((blk.shape[0], 8), np.uint8)
+        m = np.empty_like(sc)
+        sc[:, 0:4], m[:, 0:4] = s[:, 0:4] & 63, s[:, 4:8] & 63
+        sc[:, 4:8] = (s[:, 8:12] & 0xF) | ((s[:, 0:4] >> 6) << 4)
+        m[:, 4:8] = (s[:, 8:12] >> 4) | ((s[:, 4:8] >> 6) << 4)
+        qs = blk[:, 16:144].reshape(-1, 4, 32)
+        q = np.stack([qs & 0xF, qs >> 4], axis=2).astype(np.float32)
+        d1 = (d * sc.astype(np.float32)).astype(np.float32).reshape(-1, 4, 2, 1)
+        m1 = (dmin * m.astype(np.float32)).astype(np.float32).reshape(-1, 4, 2, 1)
+        return ((d1 * q).astype(np.float32) - m1).astype(np.float32).reshape(self.shape)
+
+    def take_rows(self, index) -> "Q4KBlocks":
+        r = self.raw[index]
+        return Q4KBlocks(np.ascontiguousarray(r), (r.shape[0], self.shape[1]))
 
 
 class Tensor(C.Structure):
@@ -210,11 +241,11 @@ def make_tensors(weights: Dict[str, np.ndarray]) -> Tuple[C.Array, list]:
     keep = []
     arr = (Tensor * len(weights))()
     for i, (name, a) in enumerate(weights.items()):
-        if isinstance(a, Q8Blocks):      # GGUF q8_0 blocks, handed over as they sit in the file
+        if isinstance(a, (Q8Blocks, Q4KBlocks)):      # GGUF q8_0 / Q4_K blocks, handed over as they sit in the file
             raw = np.ascontiguousarray(a.raw)
             nb = name.encode()
             keep += [raw, nb]
-            arr[i] = Tensor(nb, raw.ctypes.data, int(np.prod(a.shape)), RCA_Q8_0)
+            arr[i] = Tensor(nb, raw.ctypes.data, int(np.prod(a.shape)), RCA_Q8_0 if isinstance(a, Q8Blocks) else RCA_Q4_K)
             continue
         if a.dtype == np.uint16:
             dt = RCA_BF16

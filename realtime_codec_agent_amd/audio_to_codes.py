@@ -372,9 +372,13 @@ def main(argv=None, encoder=None, backend: Optional[str] = None) -> dict:
     args = build_parser().parse_args(argv)
     rank, world, local = env_rank_world()
     if encoder is None:
+        # rehearsal hooks (several ranks on ONE card): RCA_DEVICE pins every rank to that device, RCA_DIST_BACKEND picks the backend
+        # of the start / stop barrier (RCCL refuses two ranks on one GPU; the data path has no collective either way)
+        if os.environ.get("RCA_DEVICE") is not None:
+            local = int(os.environ["RCA_DEVICE"])
         encoder = HipWindowEncoder(args.codec_model, local)
         encoder.model.hip.set_window_trim(args.receptive_field_trim)
-        backend = backend or "nccl"
+        backend = backend or os.environ.get("RCA_DIST_BACKEND", "nccl")
     dist = init_dist(backend or "gloo", local) if world > 1 else None
     files = list_audio_files(args.audio_path, args.audio_filter)
     shards = shard_by_duration([probe_duration(f) for f in files], world)

@@ -311,12 +311,20 @@ __device__ __forceinline__ unsigned q8_opaque(unsigned w) {
     return w;
 }
 __device__ __forceinline__ float q8_byte_to_f32(unsigned w, int b) { return (float)(signed char)((w >> (8 * b)) & 0xffu); }
-struct GemvQ8 {
-    const u32x4* qs;      // [N / 2][K / 8] 16-byte units
-    const unsigned* sc;   // [ceil(N / 16)][K / 32][8]: (fp16, fp16) per pair and 32-element block, pairs in groups of 8 -- the scales a
+struct GemvQ8 {          // the packed (quantised) forms: q8_0, and Q4_K (dd != nullptr)
+    const u32x4* qs;      // q8_0: [N / 2][K / 8] 16-byte units.  Q4_K: [N / 4][K / 8] units = 8 nibbles x 4 slots (q4k_* below)
+    const unsigned* sc;   // q8_0: [ceil(N / 16)][K / 32][8]: (fp16, fp16) per pair and 32-element block, pairs in groups of 8 -- the scales a
                           // wave needs for a batch (<= 8 pairs x its 16 blocks) are ONE contiguous run (was [K / 32][N / 2]: 16
-                          // separate lines per wave and load)
+                          // separate lines per wave and load).  Q4_K: ushort (sc | m << 8) per slot and 32-element sub-block,
+                          // [ceil(N / 16)][K / 32][16]
+    const unsigned* dd;   // Q4_K: (fp16 d | fp16 dmin << 16) per slot and 256-element super-block, [ceil(N / 16)][K / 256][16]
 };
+// Q4_K (GGUF block_q4_K, what llama-quantize Q4_K_M writes for most tensors, prep_test_model.sh:31): 4-bit values with a 6-bit scale
+// and a 6-bit minimum per 32 and two fp16 factors per 256: value = (d * sc) * q - (dmin * m).  Device layout, built once at load:
+// slots (rows in the order the GEMV's epilogues pair them) in quads, qs[quad][k / 8] = one dword per slot holding the 8 nibbles of
+// 8 consecutive k (nibble j at bits 4 j): a 16-byte lane load feeds four rows with the x values the lane holds; 4.6 bits per weight
+// streamed.  Arithmetic per lane, slot and 8-k chunk: p = fma chain of q_j x_j (j ascending), then val += (d * sc) p - (dmin * m) sum(x).
+__host__ __device__ __forceinline__ long q4k_scm_index(long slot, long kblock, long nkb) { return ((slot >> 4) * nkb + kblock) * 16 + (slot & 15); }
 __host__ __device__ __forceinline__ long q8_sc_index(long pair, long kblock, long nkb) { return ((pair >> 3) * nkb + kblock) * 8 + (pair & 7); }
 // The format a projection matrix is kept in (ONE copy per matrix; the decode GEMV streams it, the prefill tiles de-quantise it while
 // staging): the GEMV's template parameter Q.
@@ -326,13 +334,14 @@ __host__ __device__ __forceinline__ long q8_sc_index(long pair, long kblock, lon
 #define WF_BF16 0   // bf16 [N][K]
 #define WF_Q8 1     // GGUF q8_0, pair-interleaved (GemvQ8)
 #define WF_F16 2    // fp16 [N][K] (the reference's default GGUF is F16, realtime_agent_resources.py:12)
+#define WF_Q4K 3    // GGUF Q4_K, quad-interleaved nibbles (GemvQ8 with dd)
 // minimum waves per SIMD asked of the register allocator.  The q8_0 bodies otherwise spread over 200+ registers (one wave per
 // SIMD) although their live set is ~130: a streaming kernel wants the occupancy.
-constexpr int gemv_min_waves(int Q, int R, int NIT) { return Q != WF_Q8 ? 1 : (R * NIT >= 16 ? 2 : 4); }
+constexpr int gemv_min_waves(int Q, int R, int NIT) { return (Q != WF_Q8 && Q != WF_Q4K) ? 1 : (R * NIT >= 16 ? 2 : 4); }
 template <int M, int NIT, int R, int PRO, int EPI, int Q = 0>
 __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel(const LmDevState* __restrict__ stt, const bf16_t* __restrict__ W,
                                                       const float* __restrict__ x, float* __restrict__ y, int N, int K,
-                                                      int batches_per_wg, int ldy, GemvPro pro, GemvRope rope, GemvQ8 q8 = GemvQ8{nullptr, nullptr}) {
+                                                      int batches_per_wg, int ldy, GemvPro pro, GemvRope rope, GemvQ8 q8 = GemvQ8{nullptr, nullptr, nullptr}) {
     constexpr int V = R * M;
     static_assert(V % 4 == 0 && R % 2 == 0, "R * M must be a multiple of 4");
     __shared__ float kred[2][4][V];
@@ -356,9 +365,12 @@ __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel
         }
         return b * R + r;
     };
-    constexpr bool Q8 = Q == WF_Q8;
-    constexpr int NL = Q8 ? R / 2 : R;        // 16-byte weight loads per chunk: one per row, or one per slot pair (q8_0)
+    constexpr bool Q8 = Q == WF_Q8, Q4 = Q == WF_Q4K;
+    constexpr int NL = Q8 ? R / 2 : (Q4 ? R / 4 : R);   // 16-byte weight loads per chunk: one per row, per slot pair (q8_0) or per slot quad (Q4_K)
+    constexpr int H0 = NL / 2;                // the batch's registers refill in two halves: loads [0, H0) and [H0, NL)
     u32x4 wq[NL][NIT];
+    uint2 wscm[Q4 ? NIT : 1][Q4 ? NL : 1];    // Q4_K: (sc | m << 8) of a quad's four slots for this lane's 32-element sub-block
+    u32x4 wdd[Q4 ? NIT : 1][Q4 ? NL : 1];     //       (d | dmin << 16) of the four slots for this lane's 256-element super-block
     unsigned wsc[Q8 ? NIT : 1][Q8 ? R / 2 : 1];   // q8_0: (fp16, fp16) scales of the batch's pairs for this lane's 32-element block
     const int npairs = N >> 1;
     // Every lane loads from a VALID address, whatever its chunk: a lane past the wave's range (narrow test models) re-reads chunk 0
@@ -367,7 +379,17 @@ __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel
     const int cbase = cn > 0 ? c0 : 0;
     // weight loads of ONE row (bf16 / fp16) or row pair (q8_0) of batch b into its registers; the q8_0 scales of a batch separately
     auto issue_row = [&](int b, int r) {
-        if (Q8) {
+        if (Q4) {   // quad r of the batch: factors first (consumed with the quad), then the nibbles
+            const long quad = min((long)b * (R / 4) + r, (long)((N + 3) >> 2) - 1);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = lane + 64 * it;
+                const int cc = cbase + (c < cn ? c : 0);
+                wdd[it][r] = *reinterpret_cast<const u32x4*>(q8.dd + q4k_scm_index(4 * quad, cc >> 5, K >> 8));
+                wscm[it][r] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(q8.sc) + q4k_scm_index(4 * quad, cc >> 2, K >> 5));
+                wq[r][it] = __builtin_nontemporal_load(q8.qs + quad * nchunk + cc);
+            }
+        } else if (Q8) {
             const long pp = min((long)b * (R / 2) + r, (long)npairs - 1);
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -409,9 +431,10 @@ __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel
     };
     // half h (0 / 1) of batch b: its scales first (they are consumed with its first pair), then its rows
     auto load_half = [&](int b, int h) {
-        issue_scales(b, h * (NL / 2), (h + 1) * (NL / 2));
+        issue_scales(b, h ? H0 : 0, h ? NL : H0);
 #pragma unroll
-        for (int r = 0; r < NL / 2; ++r) issue_row(b, h * (NL / 2) + r);
+        for (int r = 0; r < NL; ++r)
+            if (h ? r >= H0 : r < H0) issue_row(b, r);
     };
     auto load_batch = [&](int b) { load_half(b, 0); load_half(b, 1); };
     // ---- this lane's x values.  Vector-memory results return in issue order, so the (short, L2-served) loads of x and of the
@@ -486,6 +509,18 @@ __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel
     }
     int pos0 = 0;
     if (EPI == 2) pos0 = stt->n_tokens;
+    float sx[Q4 ? M : 1][Q4 ? NIT : 1];   // Q4_K: sum of this lane's x values per chunk (the minimum term: - (dmin * m) * sum(x))
+    if (Q4) {
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                float t = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t = t + xr[m][it][j];
+                sx[m][it] = t;
+            }
+    }
 
     // The weight registers of a batch are two halves that refill separately: while the second half of batch b is being consumed the
     // first half of batch b + 1 is already in flight, and the other way round -- at least R / 2 loads per lane are outstanding from
@@ -494,7 +529,41 @@ __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel
     // the waits count down row by row.  Finer refills (row by row) make this compiler keep the next batch in a second register set
     // and copy it over behind a vmcnt(0) at the loop end, or spill (two-arm form): measured in profiles/r03/experiments.
     auto consume_row = [&](float (&val)[V], int r) {
-        if (Q8) {
+        if (Q4) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const u32x4 a = wq[r][it];
+                const u32x4 ddv = wdd[it][r];
+                const uint2 sm = wscm[it][r];
+                const unsigned aw[4] = {a.x, a.y, a.z, a.w}, dw[4] = {ddv.x, ddv.y, ddv.z, ddv.w}, sw[2] = {sm.x, sm.y};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned w = q8_opaque(aw[i]);
+                    const unsigned lo = w & 0x0F0F0F0Fu, hi = (w >> 4) & 0x0F0F0F0Fu;   // bytes of lo = nibbles 0, 2, 4, 6; of hi = 1, 3, 5, 7
+                    float pq[M];
+#pragma unroll
+                    for (int m = 0; m < M; ++m) pq[m] = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float fq = (float)(((j & 1) ? hi : lo) >> (8 * (j >> 1)) & 0xffu);   // v_cvt_f32_ubyteN
+#pragma unroll
+                        for (int m = 0; m < M; ++m) pq[m] = __builtin_fmaf(fq, xr[m][it][j], pq[m]);
+                    }
+                    const f16x2 d2 = __builtin_bit_cast(f16x2, dw[i]);
+                    const unsigned scm = (sw[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+                    const float d1 = (float)d2[0] * (float)(scm & 0xffu);
+                    const float m1 = (float)d2[1] * (float)(scm >> 8);
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+                        float acc = val[m * R + 4 * r + i];
+                        acc = __builtin_fmaf(d1, pq[m], acc);
+                        acc = __builtin_fmaf(-m1, sx[m][it], acc);
+                        val[m * R + 4 * r + i] = acc;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);   // one quad at a time (see the q8_0 branch)
+            }
+        } else if (Q8) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const u32x4 a = wq[r][it];
@@ -577,17 +646,17 @@ __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel
         }
 #else
 #pragma unroll
-        for (int r = 0; r < NL / 2; ++r) consume_row(val, r);
+        for (int r = 0; r < H0; ++r) consume_row(val, r);
         if (more) {
             load_half(b + 1, 0);
             // the second half's arithmetic does not depend on the refill above and would be scheduled in front of it (the refill
             // would then be requested only after the WHOLE batch has landed): one register of every row passes through a volatile
             // statement that sits behind the refill
 #pragma unroll
-            for (int r = NL / 2; r < NL; ++r) asm volatile("" : "+v"(wq[r][0].x));
+            for (int r = H0; r < NL; ++r) asm volatile("" : "+v"(wq[r][0].x));
         }
 #pragma unroll
-        for (int r = NL / 2; r < NL; ++r) consume_row(val, r);
+        for (int r = H0; r < NL; ++r) consume_row(val, r);
         if (more) load_half(b + 1, 1);
 #endif
         wave_reduce_transposed<V>(val);
@@ -1186,6 +1255,108 @@ __global__ __launch_bounds__(256) void lm_interleave_rows_bytes_kernel(const uns
         dst[i] = (row & 1) ? b[(row >> 1) * row_bytes + o] : a[(row >> 1) * row_bytes + o];
     }
 }
+// ---- Q4_K.  Plain form on the device: q [N][K] one byte per 4-bit value, scm [N][K / 32] ushort (sc | m << 8), dd [N][K / 256]
+// uint (d | dmin << 16).
+__global__ __launch_bounds__(256) void lm_q4k_unblock_kernel(const unsigned char* __restrict__ blocks, long nblocks, unsigned char* __restrict__ q,
+                                                             unsigned short* __restrict__ scm, unsigned* __restrict__ dd) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nblocks * 256; i += (long)gridDim.x * blockDim.x) {
+        const long blk = i >> 8;
+        const int e = (int)(i & 255);
+        const unsigned char* bp = blocks + blk * 144;
+        const int t = e >> 6, l = e & 31, high = (e >> 5) & 1;   // weights 64 t + 32 high + l: low / high nibble of qs[32 t + l]
+        const unsigned char byte = bp[16 + 32 * t + l];
+        q[i] = high ? (byte >> 4) : (byte & 0xF);
+        if ((e & 31) == 0) {   // sub-block j = e / 32: get_scale_min_k4
+            const int j = e >> 5;
+            const unsigned char* sc = bp + 4;
+            unsigned scv, mv;
+            if (j < 4) { scv = sc[j] & 63; mv = sc[j + 4] & 63; }
+            else { scv = (sc[j + 4] & 0xF) | ((sc[j - 4] >> 6) << 4); mv = (sc[j + 4] >> 4) | ((sc[j] >> 6) << 4); }
+            scm[blk * 8 + j] = (unsigned short)(scv | (mv << 8));
+        }
+        if (e == 0) dd[blk] = (unsigned)bp[0] | ((unsigned)bp[1] << 8) | ((unsigned)bp[2] << 16) | ((unsigned)bp[3] << 24);
+    }
+}
+// This build's Q4_K quantiser (oracle/q4k_ref.py::quantize_q4_k, operation for operation): per 32 values offset o = -min(0, min w)
+// and step s = (max w + o) / 15; per 256 d = max s / 63, dmin = max o / 63 (fp16); sc = round(s / d), m = round(o / dmin);
+// q = clamp(round((w + dmin m) / (d sc)), 0, 15).  llama-quantize searches for better scales; the FORMAT and its de-quantisation are GGUF's.
+__global__ __launch_bounds__(256) void lm_q4k_quantize_kernel(const bf16_t* __restrict__ w, int is_f16, long nblocks, unsigned char* __restrict__ q,
+                                                              unsigned short* __restrict__ scm, unsigned* __restrict__ dd) {
+    for (long blk = (long)blockIdx.x * blockDim.x + threadIdx.x; blk < nblocks; blk += (long)gridDim.x * blockDim.x) {
+        float s[8], o[8];
+        float smax = 0.0f, omax = 0.0f;
+        for (int j = 0; j < 8; ++j) {
+            float mn = 0.0f, mx = -INFINITY;
+            for (int l = 0; l < 32; ++l) {
+                const float v = w16_to_f32(w[blk * 256 + j * 32 + l], is_f16);
+                mn = fminf(mn, v);
+                mx = fmaxf(mx, v);
+            }
+            s[j] = (mx - mn) / 15.0f;
+            o[j] = -mn;
+            smax = fmaxf(smax, s[j]);
+            omax = fmaxf(omax, o[j]);
+        }
+        const f16_t dh = (f16_t)(smax / 63.0f), dminh = (f16_t)(omax / 63.0f);
+        const float df = (float)dh, dminf = (float)dminh;
+        for (int j = 0; j < 8; ++j) {
+            float sc = df > 0.0f ? floorf(s[j] / df + 0.5f) : 0.0f;
+            float mm = dminf > 0.0f ? floorf(o[j] / dminf + 0.5f) : 0.0f;
+            sc = fminf(fmaxf(sc, 0.0f), 63.0f);
+            mm = fminf(fmaxf(mm, 0.0f), 63.0f);
+            const float d1 = df * sc, m1 = dminf * mm;
+            for (int l = 0; l < 32; ++l) {
+                const float v = w16_to_f32(w[blk * 256 + j * 32 + l], is_f16);
+                float qq = d1 > 0.0f ? floorf((v + m1) / d1 + 0.5f) : 0.0f;
+                qq = fminf(fmaxf(qq, 0.0f), 15.0f);
+                q[blk * 256 + j * 32 + l] = (unsigned char)qq;
+            }
+            scm[blk * 8 + j] = (unsigned short)((unsigned)sc | ((unsigned)mm << 8));
+        }
+        dd[blk] = (unsigned)__builtin_bit_cast(unsigned short, dh) | ((unsigned)__builtin_bit_cast(unsigned short, dminh) << 16);
+    }
+}
+// dequantize_row_q4_K's arithmetic: (d * sc) * q - (dmin * m), two products and a subtraction in f32
+__device__ __forceinline__ float q4k_value(unsigned dd, unsigned scm, unsigned q) {
+    const f16x2 d2 = __builtin_bit_cast(f16x2, dd);
+    const float d1 = (float)d2[0] * (float)(scm & 0xffu), m1 = (float)d2[1] * (float)(scm >> 8);
+    return d1 * (float)q - m1;
+}
+__global__ __launch_bounds__(256) void lm_q4k_dequant_f32_kernel(const unsigned char* __restrict__ q, const unsigned short* __restrict__ scm,
+                                                                 const unsigned* __restrict__ dd, float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = q4k_value(dd[i >> 8], scm[i >> 5], q[i]);
+}
+// slot -> row of a packed matrix: plain, or (qkv_pairs) slots (2 s, 2 s + 1) = rows (d, d + 32) of one head
+__host__ __device__ __forceinline__ long packed_slot_row(long slot, int qkv_pairs) {
+    if (!qkv_pairs) return slot;
+    const long pp = slot >> 1;
+    return (pp >> 5) * 64 + (pp & 31) + 32 * (slot & 1);
+}
+// plain -> the quad-interleaved GEMV layout (GemvQ8 with dd)
+__global__ __launch_bounds__(256) void lm_q4k_pack_kernel(const unsigned char* __restrict__ q, const unsigned short* __restrict__ scm, const unsigned* __restrict__ dd,
+                                                          int N, int K, int qkv_pairs, u32x4* __restrict__ qs, unsigned short* __restrict__ oscm, unsigned* __restrict__ odd) {
+    const long nchunk = K >> 3, nquad = (N + 3) >> 2, nkb = K >> 5, nk256 = K >> 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nquad * nchunk; i += (long)gridDim.x * blockDim.x) {
+        const long quad = i / nchunk;
+        const int c = (int)(i - quad * nchunk);
+        unsigned dw[4];
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            const long slot = 4 * quad + sl, row = packed_slot_row(slot, qkv_pairs);
+            unsigned v = 0;
+            if (slot < N) {
+                const uint2 b8 = *reinterpret_cast<const uint2*>(q + row * K + 8 * c);
+                const unsigned bytes[2] = {b8.x, b8.y};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v |= ((bytes[j >> 2] >> (8 * (j & 3))) & 0xFu) << (4 * j);
+                if ((c & 3) == 0) oscm[q4k_scm_index(slot, c >> 2, nkb)] = scm[row * nkb + (c >> 2)];
+                if ((c & 31) == 0) odd[q4k_scm_index(slot, c >> 5, nk256)] = dd[row * nk256 + (c >> 5)];
+            }
+            dw[sl] = v;
+        }
+        qs[i] = u32x4{dw[0], dw[1], dw[2], dw[3]};
+    }
+}
 // plain -> GemvQ8.  pair pp = rows (2pp, 2pp+1), or for the fused QKV matrix (qkv_pairs) rows (d, d+32) of one head.
 __global__ __launch_bounds__(256) void lm_q8_pack_kernel(const signed char* __restrict__ q, const f16_t* __restrict__ d, int N, int K, int qkv_pairs,
                                                          u32x4* __restrict__ qs, unsigned* __restrict__ sc) {
@@ -1213,16 +1384,17 @@ struct WMat {
     int fmt = WF_BF16;
     int N = 0, K = 0;
     bf16_t* w = nullptr;        // WF_BF16 / WF_F16: row-major 16-bit values
-    u32x4* qs = nullptr;        // WF_Q8 (GemvQ8)
+    u32x4* qs = nullptr;        // WF_Q8 / WF_Q4K (GemvQ8)
     unsigned* sc = nullptr;
+    unsigned* dd = nullptr;     // WF_Q4K
     void release() {
-        for (void* p : {(void*)w, (void*)qs, (void*)sc})
+        for (void* p : {(void*)w, (void*)qs, (void*)sc, (void*)dd})
             if (p) (void)hipFree(p);
-        w = nullptr; qs = nullptr; sc = nullptr;
+        w = nullptr; qs = nullptr; sc = nullptr; dd = nullptr;
     }
     long stream_bytes() const {   // bytes one decode pass reads of it
         const long n = (long)N * K;
-        return fmt == WF_Q8 ? n + n / 16 : 2 * n;
+        return fmt == WF_Q8 ? n + n / 16 : (fmt == WF_Q4K ? n / 2 + n / 16 + n / 64 : 2 * n);
     }
 };
 struct LmLayer {
@@ -1367,7 +1539,7 @@ static int lm_check_cfg(const rca_lm_config_t* c) {
     if (c->ffn > LM_KSLICE * LM_MAXSPLIT) return fail(RCA_ERR_ARG, "ffn > %d unsupported", LM_KSLICE * LM_MAXSPLIT);
     if (c->ffn > LM_KSLICE && c->ffn % LM_KSLICE) return fail(RCA_ERR_ARG, "ffn above %d must be a multiple of it", LM_KSLICE);
     if (c->vocab_size < 2 || c->n_layers < 1 || c->n_ctx < 2) return fail(RCA_ERR_ARG, "bad sizes");
-    if (c->decode_weights < 0 || c->decode_weights > 2) return fail(RCA_ERR_ARG, "decode_weights %d (0 as supplied, 1 q8_0, 2 f16)", c->decode_weights);
+    if (c->decode_weights < 0 || c->decode_weights > 3) return fail(RCA_ERR_ARG, "decode_weights %d (0 as supplied, 1 q8_0, 2 f16, 3 q4_k)", c->decode_weights);
     return RCA_OK;
 }
 
@@ -1377,15 +1549,17 @@ struct RawMat {
     int fmt = WF_BF16;
     long rows = 0, cols = 0;
     bf16_t* w16 = nullptr;      // WF_BF16 / WF_F16
-    signed char* q = nullptr;   // WF_Q8: int8 [rows][cols]
-    f16_t* d = nullptr;         //        fp16 [rows][cols / 32]
+    signed char* q = nullptr;   // WF_Q8: int8 [rows][cols]; WF_Q4K: one byte per 4-bit value
+    f16_t* d = nullptr;         // WF_Q8: fp16 [rows][cols / 32]; WF_Q4K: ushort (sc | m << 8) [rows][cols / 32]
+    unsigned* dd = nullptr;     // WF_Q4K: (d | dmin << 16) [rows][cols / 256]
     void release() {
-        for (void* p : {(void*)w16, (void*)q, (void*)d})
+        for (void* p : {(void*)w16, (void*)q, (void*)d, (void*)dd})
             if (p) (void)hipFree(p);
-        w16 = nullptr; q = nullptr; d = nullptr;
+        w16 = nullptr; q = nullptr; d = nullptr; dd = nullptr;
     }
     // (array, bytes per row) of every component
     int parts(void** ptr, long* row_bytes) const {
+        if (fmt == WF_Q4K) { ptr[0] = q; row_bytes[0] = cols; ptr[1] = d; row_bytes[1] = cols / 32 * 2; ptr[2] = dd; row_bytes[2] = cols / 256 * 4; return 3; }
         if (fmt == WF_Q8) { ptr[0] = q; row_bytes[0] = cols; ptr[1] = d; row_bytes[1] = cols / 32 * 2; return 2; }
         ptr[0] = w16; row_bytes[0] = cols * 2;
         return 1;
@@ -1393,6 +1567,12 @@ struct RawMat {
     int alloc(int f, long r, long c) {
         fmt = f; rows = r; cols = c;
         int rc;
+        if (f == WF_Q4K) {
+            if (c % 256) return fail(RCA_ERR_ARG, "Q4_K needs rows of a multiple of 256 values (got %ld)", c);
+            if ((rc = lm_alloc((void**)&q, (size_t)r * c)) != RCA_OK || (rc = lm_alloc((void**)&d, (size_t)r * (c / 32) * 2)) != RCA_OK ||
+                (rc = lm_alloc((void**)&dd, (size_t)r * (c / 256) * 4)) != RCA_OK) { release(); return rc; }
+            return RCA_OK;
+        }
         if (f == WF_Q8) {
             if (c % 32) return fail(RCA_ERR_ARG, "q8_0 needs rows of a multiple of 32 values (got %ld)", c);
             if ((rc = lm_alloc((void**)&q, (size_t)r * c)) != RCA_OK || (rc = lm_alloc((void**)&d, (size_t)r * (c / 32) * 2)) != RCA_OK) { release(); return rc; }
@@ -1418,6 +1598,20 @@ static int lm_upload_raw(rca_lm* h, const rca_tensor_t* ts, int nt, const std::s
         hipError_t e = hipMemcpy(raw, t->data, (size_t)nblk * 34, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
             lm_q8_unblock_kernel<<<4096, 256, 0, h->stream>>>(raw, nblk, out->q, out->d);
+            e = hipStreamSynchronize(h->stream);
+        }
+        (void)hipFree(raw);
+        if (e != hipSuccess) { out->release(); return fail(RCA_ERR_HIP, "upload '%s': %s", name.c_str(), hipGetErrorString(e)); }
+        return RCA_OK;
+    }
+    if (t->dtype == RCA_Q4_K) {
+        if ((rc = out->alloc(WF_Q4K, rows, cols)) != RCA_OK) return rc;
+        const long nblk = numel / 256;
+        unsigned char* raw = nullptr;
+        if ((rc = lm_alloc((void**)&raw, (size_t)nblk * 144)) != RCA_OK) { out->release(); return rc; }
+        hipError_t e = hipMemcpy(raw, t->data, (size_t)nblk * 144, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            lm_q4k_unblock_kernel<<<4096, 256, 0, h->stream>>>(raw, nblk, (unsigned char*)out->q, (unsigned short*)out->d, out->dd);
             e = hipStreamSynchronize(h->stream);
         }
         (void)hipFree(raw);
@@ -1473,10 +1667,11 @@ static int lm_upload_embed(rca_lm* h, const rca_tensor_t* ts, int nt, const std:
         if (e != hipSuccess) return fail(RCA_ERR_HIP, "upload '%s': %s", name.c_str(), hipGetErrorString(e));
         return RCA_OK;
     }
-    if (t->dtype == RCA_Q8_0) {
+    if (t->dtype == RCA_Q8_0 || t->dtype == RCA_Q4_K) {
         RawMat raw;
         if ((rc = lm_upload_raw(h, ts, nt, name, rows, cols, &raw)) != RCA_OK) return rc;
-        lm_q8_dequant_f32_kernel<<<4096, 256, 0, h->stream>>>(raw.q, raw.d, (float*)h->embed, numel);
+        if (raw.fmt == WF_Q4K) lm_q4k_dequant_f32_kernel<<<4096, 256, 0, h->stream>>>((const unsigned char*)raw.q, (const unsigned short*)raw.d, raw.dd, (float*)h->embed, numel);
+        else lm_q8_dequant_f32_kernel<<<4096, 256, 0, h->stream>>>(raw.q, raw.d, (float*)h->embed, numel);
         hipError_t e = hipStreamSynchronize(h->stream);
         raw.release();
         if (e != hipSuccess) return fail(RCA_ERR_HIP, "upload '%s': %s", name.c_str(), hipGetErrorString(e));
@@ -1509,8 +1704,18 @@ static int lm_upload_f32(const rca_tensor_t* ts, int nt, const std::string& name
 // rca_lm_config_t::decode_weights applied to one plain matrix: 1 = quantise to q8_0 the way llama-quantize does, 2 = fp16.
 // A matrix that ARRIVED quantised stays what it is.
 static int lm_raw_convert(rca_lm* h, RawMat* m, int want) {
-    if (want == 0 || m->fmt == WF_Q8) return RCA_OK;
+    if (want == 0 || m->fmt == WF_Q8 || m->fmt == WF_Q4K) return RCA_OK;
     int rc;
+    if (want == 3) {
+        RawMat qd;
+        if ((rc = qd.alloc(WF_Q4K, m->rows, m->cols)) != RCA_OK) return rc;
+        lm_q4k_quantize_kernel<<<4096, 256, 0, h->stream>>>(m->w16, m->fmt == WF_F16, m->rows * m->cols / 256, (unsigned char*)qd.q, (unsigned short*)qd.d, qd.dd);
+        hipError_t e = hipStreamSynchronize(h->stream);
+        m->release();
+        if (e != hipSuccess) { qd.release(); return fail(RCA_ERR_HIP, "Q4_K quantise: %s", hipGetErrorString(e)); }
+        *m = qd;
+        return RCA_OK;
+    }
     if (want == 1) {
         RawMat qd;
         if ((rc = qd.alloc(WF_Q8, m->rows, m->cols)) != RCA_OK) return rc;
@@ -1542,11 +1747,11 @@ static int lm_raw_concat(rca_lm* h, std::vector<RawMat*> parts, RawMat* out, con
     }
     int rc;
     if ((rc = out->alloc(parts[0]->fmt, rows, parts[0]->cols)) != RCA_OK) return rc;
-    void* dp[2]; long drb[2];
+    void* dp[3]; long drb[3];
     const int np = out->parts(dp, drb);
     long r0 = 0;
     for (RawMat* p : parts) {
-        void* sp[2]; long srb[2];
+        void* sp[3]; long srb[3];
         p->parts(sp, srb);
         for (int i = 0; i < np; ++i)
             RCA_HIP(hipMemcpyAsync((char*)dp[i] + r0 * drb[i], sp[i], (size_t)p->rows * srb[i], hipMemcpyDeviceToDevice, h->stream));
@@ -1560,7 +1765,7 @@ static int lm_raw_interleave(rca_lm* h, RawMat* a, RawMat* b, RawMat* out, const
     if (a->fmt != b->fmt || a->cols != b->cols || a->rows != b->rows) return fail(RCA_ERR_ARG, "%s: its parts arrived in different formats", what);
     int rc;
     if ((rc = out->alloc(a->fmt, 2 * a->rows, a->cols)) != RCA_OK) return rc;
-    void *dp[2], *ap[2], *bp[2]; long rb[2];
+    void *dp[3], *ap[3], *bp[3]; long rb[3];
     const int np = out->parts(dp, rb);
     a->parts(ap, rb);
     b->parts(bp, rb);
@@ -1572,6 +1777,23 @@ static int lm_raw_interleave(rca_lm* h, RawMat* a, RawMat* b, RawMat* out, const
 // plain -> the layout the decode GEMV streams.  Takes ownership of `raw` (released or moved into `out`).
 static int lm_finish_mat(rca_lm* h, RawMat* raw, int qkv_pairs, WMat* out, const char* what) {
     out->fmt = raw->fmt; out->N = (int)raw->rows; out->K = (int)raw->cols;
+    if (raw->fmt == WF_Q4K) {
+        const int N = out->N, K = out->K;
+        if ((K % 256) || (N % 4) || (qkv_pairs && (N % 64))) { raw->release(); return fail(RCA_ERR_ARG, "Q4_K weights: %s is %d x %d (K must be a multiple of 256, N of 4)", what, N, K); }
+        int rc;
+        const long nquad = N / 4, nchunk = K / 8, g16 = (N + 15) / 16;
+        const size_t scm_bytes = (size_t)g16 * (K / 32) * 16 * 2, dd_bytes = (size_t)g16 * (K / 256) * 16 * 4;
+        if ((rc = lm_alloc((void**)&out->qs, (size_t)nquad * nchunk * 16)) != RCA_OK || (rc = lm_alloc((void**)&out->sc, scm_bytes)) != RCA_OK ||
+            (rc = lm_alloc((void**)&out->dd, dd_bytes)) != RCA_OK) { raw->release(); return rc; }
+        (void)hipMemsetAsync(out->sc, 0, scm_bytes, h->stream);
+        (void)hipMemsetAsync(out->dd, 0, dd_bytes, h->stream);
+        lm_q4k_pack_kernel<<<4096, 256, 0, h->stream>>>((const unsigned char*)raw->q, (const unsigned short*)raw->d, raw->dd, N, K, qkv_pairs, out->qs,
+                                                        (unsigned short*)out->sc, out->dd);
+        hipError_t e = hipStreamSynchronize(h->stream);
+        raw->release();
+        if (e != hipSuccess) return fail(RCA_ERR_HIP, "Q4_K pack of %s: %s", what, hipGetErrorString(e));
+        return RCA_OK;
+    }
     if (raw->fmt != WF_Q8) {
         out->w = raw->w16;
         raw->w16 = nullptr;
@@ -1868,7 +2090,7 @@ template <int M, int NIT, int PRO, int EPI, int Q>
 static void launch_gemv_r(const GemvGeom& g, rca_lm* h, const WMat& w, const float* x, float* y, int N, int K, int ldy, const GemvPro& pro,
                           const GemvRope& rope, hipStream_t st) {
     const int grid = cdiv(cdiv(N, g.R), g.bpw);
-    const GemvQ8 qa{w.qs, w.sc};
+    const GemvQ8 qa{w.qs, w.sc, w.dd};
     switch (g.R) {
         case 4: lm_gemv_kernel<M, NIT, 4, PRO, EPI, Q><<<grid, 256, 0, st>>>(h->stt, w.w, x, y, N, K, g.bpw, ldy, pro, rope, qa); break;
         case 8: lm_gemv_kernel<M, NIT, 8, PRO, EPI, Q><<<grid, 256, 0, st>>>(h->stt, w.w, x, y, N, K, g.bpw, ldy, pro, rope, qa); break;
@@ -1880,8 +2102,10 @@ static void launch_gemv_q(GemvGeom g, rca_lm* h, int M, const WMat& w, const flo
                           const GemvRope& rope, hipStream_t st) {
     const int nit = cdiv(cdiv(K >> 3, 4), 64);
     // 16-byte weight loads in flight per lane: at most 16 (registers); q8_0 needs one load per row PAIR
-    const int lpr = Q == WF_Q8 ? 2 : 1;
-    while (g.R > 4 && (g.R / lpr) * (nit == 3 ? 4 : nit) > 16) g.R >>= 1;
+    const int lpr = Q == WF_Q8 ? 2 : (Q == WF_Q4K ? 4 : 1);
+    const int max_loads = Q == WF_Q4K ? 8 : 16;   // Q4_K also holds the factors of every quad in registers
+    while (g.R > 4 && (g.R / lpr) * (nit == 3 ? 4 : nit) > max_loads) g.R >>= 1;
+    if (Q == WF_Q4K && g.R < 8) g.R = 8;   // a Q4_K batch is at least two quads (one per register half)
     if (PRO == 0 && EPI == 3 && nit > 1) {
         if (nit == 2) {
             if (M == 1) launch_gemv_r<1, 2, 0, 3, Q>(g, h, w, x, y, N, K, ldy, pro, rope, st);
@@ -1900,8 +2124,9 @@ static void launch_gemv_q(GemvGeom g, rca_lm* h, int M, const WMat& w, const flo
 template <int PRO, int EPI>
 static void launch_gemv(int kind, rca_lm* h, int M, const WMat& w, const float* x, float* y, int N, int K, int ldy, const GemvPro& pro,
                         const GemvRope& rope, hipStream_t st) {
-    const GemvGeom g = gemv_geom(kind, N, w.fmt == WF_Q8);
-    if (w.fmt == WF_Q8) launch_gemv_q<PRO, EPI, WF_Q8>(g, h, M, w, x, y, N, K, ldy, pro, rope, st);
+    const GemvGeom g = gemv_geom(kind, N, w.fmt == WF_Q8 || w.fmt == WF_Q4K);
+    if (w.fmt == WF_Q4K) launch_gemv_q<PRO, EPI, WF_Q4K>(g, h, M, w, x, y, N, K, ldy, pro, rope, st);
+    else if (w.fmt == WF_Q8) launch_gemv_q<PRO, EPI, WF_Q8>(g, h, M, w, x, y, N, K, ldy, pro, rope, st);
     else if (w.fmt == WF_F16) launch_gemv_q<PRO, EPI, WF_F16>(g, h, M, w, x, y, N, K, ldy, pro, rope, st);
     else launch_gemv_q<PRO, EPI, WF_BF16>(g, h, M, w, x, y, N, K, ldy, pro, rope, st);
 }
@@ -2341,6 +2566,15 @@ __global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __
     const long q_nkb = K >> 5;
     const u32x4* gQ = WF == WF_Q8 ? q8.qs + ((long)(n0 >> 1) + qp) * (K >> 3) + (ks >> 3) + (tid & 3) : nullptr;
     const unsigned* gS = WF == WF_Q8 ? q8.sc + q8_sc_index((n0 >> 1) + qp, ks >> 5, q_nkb) : nullptr;   // next k block: + 8
+    // Q4_K: a thread's stage is HALF a 16-byte unit = 8 k of two adjacent slots: quad tid / 8, chunk (tid / 2) % 4, slots 2 (tid % 2) + {0, 1}
+    const int q4quad = tid >> 3, q4half = tid & 1, q4slot = 4 * ((n0 >> 2) + q4quad) + 2 * q4half;
+    const uint2* gQ4 = WF == WF_Q4K ? reinterpret_cast<const uint2*>(q8.qs + ((long)(n0 >> 2) + q4quad) * (K >> 3) + (ks >> 3) + ((tid >> 1) & 3)) + q4half : nullptr;
+    const unsigned short* gS4 = WF == WF_Q4K ? reinterpret_cast<const unsigned short*>(q8.sc) + q4k_scm_index(q4slot, ks >> 5, q_nkb) : nullptr;   // next sub-block: + 16
+    const unsigned* gD4 = WF == WF_Q4K ? q8.dd + q4k_scm_index(q4slot, 0, K >> 8) : nullptr;                                                     // super-block k / 256: + 16 each
+    int q4row[2];   // LDS rows of the two slots
+#pragma unroll
+    for (int i = 0; i < 2; ++i) q4row[i] = (int)packed_slot_row(4 * q4quad + 2 * q4half + i, EPI == GEMM_EPI_ROPE);
+    const int q4soff0 = q4row[0] * G128_PITCH + ((tid >> 1) & 3) * 8, q4soff1 = q4row[1] * G128_PITCH + ((tid >> 1) & 3) * 8;
     const int qra = EPI == GEMM_EPI_ROPE ? (qp >> 5) * 64 + (qp & 31) : 2 * qp;
     const int qsoff0 = qra * G128_PITCH + skc, qsoff1 = qsoff0 + (EPI == GEMM_EPI_ROPE ? 32 : 1) * G128_PITCH;
     // Software pipeline.  A workgroup's stage needs 8 KB of weights straight from HBM (~2 us away) and 16 KB of
@@ -2349,9 +2583,15 @@ __global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __
     constexpr int DW = 1, DX = 1;   // measured: deeper register prefetch (4 / 2) is slower at 2 workgroups per CU
     uint4 rw[DW][2], rh[DX][2], rl[DX][2];
     unsigned rs[DW];
+    uint2 rdd[DW];
     auto gload_w = [&](int slot, int s) {
         const int st = min(s, nstage - 1);
-        if (WF == WF_Q8) {
+        if (WF == WF_Q4K) {
+            const uint2 t = gQ4[(long)st * 8];                       // + 4 units of 16 bytes per stage
+            rw[slot][0] = make_uint4(t.x, t.y, 0u, 0u);
+            rs[slot] = *reinterpret_cast<const unsigned*>(gS4 + (long)st * 16);          // (sc | m << 8) of the two slots
+            rdd[slot] = *reinterpret_cast<const uint2*>(gD4 + (long)(((ks >> 5) + st) >> 3) * 16);   // (d | dmin << 16) of the two slots
+        } else if (WF == WF_Q8) {
             const u32x4 t = gQ[st * 4];
             rw[slot][0] = make_uint4(t.x, t.y, t.z, t.w);
             rs[slot] = gS[(long)st * 8];
@@ -2383,6 +2623,19 @@ __global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __
                 split_w8(wv, hi, lo);
                 *reinterpret_cast<uint4*>(&sm[buf][0][c ? soff1 : soff0]) = hi;
                 *reinterpret_cast<uint4*>(&sm[buf][3][c ? soff1 : soff0]) = lo;
+            }
+        } else if (WF == WF_Q4K) {   // .x / .y = 8 nibbles of the first / second slot; the value is dequantize_row_q4_K's (d sc) q - (dmin m)
+            const unsigned qw[2] = {rw[ws][0].x, rw[ws][0].y}, ddw[2] = {rdd[ws].x, rdd[ws].y};
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const unsigned scm = (rs[ws] >> (16 * c)) & 0xffffu;
+                float wv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wv[j] = q4k_value(ddw[c], scm, (qw[c] >> (4 * j)) & 0xFu);
+                uint4 hi, lo;
+                split_w8(wv, hi, lo);
+                *reinterpret_cast<uint4*>(&sm[buf][0][c ? q4soff1 : q4soff0]) = hi;
+                *reinterpret_cast<uint4*>(&sm[buf][3][c ? q4soff1 : q4soff0]) = lo;
             }
         } else {   // q8_0: .x .y = 8 int8 of the pair's first row, .z .w = of its second row; rs = (fp16 d_a, fp16 d_b)
             const f16x2 d2 = __builtin_bit_cast(f16x2, rs[ws]);
@@ -2669,10 +2922,13 @@ static void launch_gemm128(rca_lm* h, const WMat& w, dim3 grid, hipStream_t st, 
     if (!attr_done) {   // the four-tile variants need 80 KB of LDS
         (void)hipFuncSetAttribute((const void*)lm_gemm128_kernel<EPI, WF_Q8>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS_T(4));
         (void)hipFuncSetAttribute((const void*)lm_gemm128_kernel<EPI, WF_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS_T(4));
+        (void)hipFuncSetAttribute((const void*)lm_gemm128_kernel<EPI, WF_Q4K>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS_T(4));
         attr_done = true;
     }
-    const GemvQ8 qa{w.qs, w.sc};
-    if (w.fmt == WF_Q8)
+    const GemvQ8 qa{w.qs, w.sc, w.dd};
+    if (w.fmt == WF_Q4K)
+        lm_gemm128_kernel<EPI, WF_Q4K><<<grid, 256, G128_LDS_T(4), st>>>(h->stt, w.w, qa, xh, xl, N, K, kslice, y, ldy, oh, ol, h->gpart, rope, nseq);
+    else if (w.fmt == WF_Q8)
         lm_gemm128_kernel<EPI, WF_Q8><<<grid, 256, G128_LDS_T(4), st>>>(h->stt, w.w, qa, xh, xl, N, K, kslice, y, ldy, oh, ol, h->gpart, rope, nseq);
     else if (w.fmt == WF_F16)
         lm_gemm128_kernel<EPI, WF_F16><<<grid, 256, G128_LDS_T(4), st>>>(h->stt, w.w, qa, xh, xl, N, K, kslice, y, ldy, oh, ol, h->gpart, rope, nseq);
@@ -3129,6 +3385,13 @@ __global__ __launch_bounds__(256) void lm_q8_zero_row_scales_kernel(unsigned* __
         *half = 0;
     }
 }
+__global__ __launch_bounds__(256) void lm_q4k_zero_row_factors_kernel(unsigned* __restrict__ dd, int nk256, int row_begin, int row_end) {
+    const long total = (long)(row_end - row_begin) * nk256;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int row = row_begin + (int)(i / nk256), j = (int)(i % nk256);
+        dd[q4k_scm_index(row, j, nk256)] = 0u;   // lm_head is packed with plain slots: slot == row
+    }
+}
 __global__ __launch_bounds__(256) void lm_zero_rows_kernel(bf16_t* __restrict__ w, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) w[i] = 0;
 }
@@ -3138,7 +3401,9 @@ extern "C" int rca_lm_mask_head_rows(rca_lm_t* h, int32_t row_begin, int32_t row
     if (!h || row_begin < 0 || row_end > h->cfg.vocab_size || row_begin > row_end) return fail(RCA_ERR_ARG, "mask_head_rows: bad range");
     RCA_HIP(hipSetDevice(h->device));
     const long n = (long)(row_end - row_begin) * h->cfg.hidden;
-    if (n > 0 && h->head.fmt != WF_Q8) lm_zero_rows_kernel<<<2048, 256, 0, h->stream>>>(h->head.w + (long)row_begin * h->cfg.hidden, n);   // bf16 / fp16: zero bits
+    if (n > 0 && h->head.fmt == WF_Q4K)   // Q4_K: d = dmin = 0 makes every value of the row (0 * sc) * q - (0 * m) = 0
+        lm_q4k_zero_row_factors_kernel<<<256, 256, 0, h->stream>>>(h->head.dd, h->cfg.hidden / 256, row_begin, row_end);
+    if (n > 0 && (h->head.fmt == WF_BF16 || h->head.fmt == WF_F16)) lm_zero_rows_kernel<<<2048, 256, 0, h->stream>>>(h->head.w + (long)row_begin * h->cfg.hidden, n);   // zero bits
     if (n > 0 && h->head.fmt == WF_Q8)   // the packed q8_0 head: a row is zero when its block scales are
         lm_q8_zero_row_scales_kernel<<<256, 256, 0, h->stream>>>(h->head.sc, h->cfg.hidden / 32, row_begin, row_end);
     RCA_LAUNCH_CHECK();
@@ -3244,7 +3509,7 @@ extern "C" int rca_lm_set_attn_fuse(rca_lm_t* h, int32_t enable) {
     h->fuse_attn = enable != 0;
     return RCA_OK;
 }
-// the format the projection matrices are kept (and streamed) in: 0 bf16, 1 q8_0, 2 f16; bytes = weight bytes one decode step reads
+// the format the projection matrices are kept (and streamed) in: 0 bf16, 1 q8_0, 2 f16, 3 q4_k; bytes = weight bytes one decode step reads
 extern "C" int rca_lm_weight_format(const rca_lm_t* h, int32_t* fmt, int64_t* bytes_per_step) {
     if (!h || !fmt) return fail(RCA_ERR_ARG, "null");
     *fmt = h->layers.empty() ? h->head.fmt : h->layers[0].gu.fmt;

@@ -20,6 +20,14 @@ def synth_signal(n: int, seed: int = 0) -> np.ndarray:
     return np.clip(x, -1.0, 1.0).astype(np.float32)
 
 
+def session_resources_kwargs(seed: int = 0, n_ctx: int = 16384, weight_format=None) -> dict:
+    """RealtimeAgentResources keyword arguments of the bench session (picklable: RealtimeAgentMultiprocessing builds the resources in
+    its worker process from them, realtime_agent_v2.py:832-836)."""
+    from .llm import LMConfig
+    return dict(llm_model_path="random:Llama-3.2-1B-codec", llm_n_ctx=n_ctx, llm_config=LMConfig.llama_3_2_1b(), with_aux_llm=False,
+                llm_random_seed=seed, llm_weight_format=weight_format)
+
+
 def run_duplex_bench(dev=None, secs: float = 125.0, chunk_size_secs: float = 0.08, n_ctx: int = 16384, lm_steps_probe: int = 64,
                      max_context_secs: float = 80.0, trim_by_secs: float = 20.0, weight_format=None) -> dict:
     import torch
@@ -30,8 +38,7 @@ def run_duplex_bench(dev=None, secs: float = 125.0, chunk_size_secs: float = 0.0
 
     cfg = LMConfig.llama_3_2_1b()
     t0 = time.perf_counter()
-    res = RealtimeAgentResources(llm_model_path="random:Llama-3.2-1B-codec", llm_n_ctx=n_ctx, llm_config=cfg, with_aux_llm=False,
-                                 llm_weight_format=weight_format)
+    res = RealtimeAgentResources(**session_resources_kwargs(0, n_ctx, weight_format))
     config = RealtimeAgentConfig(chunk_size_secs=chunk_size_secs, use_whisper=False, top_k=100, temperature=1.0, seed=42,
                                  max_context_secs=max_context_secs, trim_by_secs=trim_by_secs,
                                  force_trans_after_inactivity_secs=0.0, force_response_after_inactivity_secs=0.0)

@@ -197,9 +197,10 @@ class LlamaForAlternatingCodeChannels:
         """weight_format: the format every projection matrix and lm_head is KEPT in (one copy: the decode step streams it, the prefill
         tiles de-quantise it while staging).  None = as the checkpoint supplies it (bf16 / fp16 / Q8_0 tensors keep their format, f32 is
         rounded to bf16); "q8_0" = quantised at load like the Q8_0 file the reference deploys (prep_test_model.sh:29); "f16" = bf16
-        values converted to fp16 (the F16 file of prep_test_model.sh:28, the reference's default model)."""
-        if weight_format not in (None, "bf16", "q8_0", "f16"):
-            raise ValueError(f"weight_format {weight_format!r}: None / 'bf16' (as supplied), 'q8_0' or 'f16'")
+        values converted to fp16 (the F16 file of prep_test_model.sh:28, the reference's default model); "q4_k" = GGUF Q4_K blocks
+        (the bulk of the Q4_K_M file of prep_test_model.sh:31), quantised at load with this build's own min / max rule."""
+        if weight_format not in (None, "bf16", "q8_0", "f16", "q4_k"):
+            raise ValueError(f"weight_format {weight_format!r}: None / 'bf16' (as supplied), 'q8_0', 'f16' or 'q4_k'")
         self._lib = N.lib()
         self.model_path = model_path
         self.verbose = verbose
@@ -237,7 +238,7 @@ class LlamaForAlternatingCodeChannels:
             n_kv_heads=config.n_kv_heads, head_dim=config.head_dim, ffn=config.ffn, n_ctx=self._n_ctx, rms_eps=config.rms_eps,
             rope_theta=config.rope_theta, rope_scaling=1 if config.rope_scaling == "llama3" else 0, rope_factor=config.rope_factor,
             rope_low_freq_factor=config.rope_low_freq_factor, rope_high_freq_factor=config.rope_high_freq_factor,
-            rope_orig_ctx=config.rope_orig_ctx, logits_all=1 if logits_all else 0, decode_weights={"q8_0": 1, "f16": 2}.get(weight_format, 0),
+            rope_orig_ctx=config.rope_orig_ctx, logits_all=1 if logits_all else 0, decode_weights={"q8_0": 1, "f16": 2, "q4_k": 3}.get(weight_format, 0),
         )
         self._h = C.c_void_p()
         if random_init:
@@ -258,7 +259,7 @@ class LlamaForAlternatingCodeChannels:
     def _query_format(self):
         fmt, nbytes = C.c_int32(), C.c_int64()
         N.check(self._lib.rca_lm_weight_format(self._h, C.byref(fmt), C.byref(nbytes)), "rca_lm_weight_format")
-        return {0: "bf16", 1: "q8_0", 2: "f16"}[fmt.value], int(nbytes.value)
+        return {0: "bf16", 1: "q8_0", 2: "f16", 3: "q4_k"}[fmt.value], int(nbytes.value)
 
     def _finish_init(self, seed: int) -> None:
         self._ctx = _Ctx(self)

@@ -4,7 +4,7 @@ import struct
 
 import numpy as np
 
-F32, F16, Q8_0, BF16 = 0, 1, 8, 30
+F32, F16, Q8_0, Q4_K, BF16 = 0, 1, 8, 12, 30
 
 
 def _s(b: bytes) -> bytes:
@@ -37,6 +37,11 @@ def quantize(a: np.ndarray, ttype: int) -> bytes:
         out[:, :2] = d.astype(np.float16).view(np.uint8).reshape(-1, 2)
         out[:, 2:] = q.view(np.uint8)
         return out.tobytes()
+    if ttype == Q4_K:      # 144-byte super-blocks, scales chosen by this repo's simple min / max rule (oracle/q4k_ref.py)
+        import os, sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from oracle import q4k_ref
+        return q4k_ref.pack_blocks(q4k_ref.quantize_q4_k(a.reshape(-1, 256))).tobytes()
     raise ValueError(ttype)
 
 

@@ -4,6 +4,7 @@ itself pinned to the reference's codec_llama.py classes by tests/golden/lm_tiny.
 slice at 1B).  About 0.3 TFLOP and 10 GB of host memory.
     python tests/golden/make_lm_1b_golden.py          # bf16 model -> lm_1b_topk.npz
     python tests/golden/make_lm_1b_golden.py q8_0     # its q8_0 twin (llama.cpp's quantize_row_q8_0 rule) -> lm_1b_q8_topk.npz
+    python tests/golden/make_lm_1b_golden.py q4_k     # its Q4_K twin (oracle/q4k_ref.py) -> lm_1b_q4k_topk.npz
 """
 import os
 import sys
@@ -28,7 +29,7 @@ def main():
         print(f"point {i}: top id {int(out[f'p{i}/top_ids'][0])} {float(out[f'p{i}/top_vals'][0]):.5f}  std {float(out[f'p{i}/std']):.5f}")
     ctx, steps = case.token_ids()
     out["ctx_ids"], out["step_ids"] = ctx, np.stack(steps)
-    path = os.path.join(HERE, "lm_1b_q8_topk.npz" if fmt == "q8_0" else "lm_1b_topk.npz")
+    path = os.path.join(HERE, {"q8_0": "lm_1b_q8_topk.npz", "q4_k": "lm_1b_q4k_topk.npz"}.get(fmt, "lm_1b_topk.npz"))
     np.savez_compressed(path, **out)
     print(f"wrote {path} ({os.path.getsize(path)} bytes) in {time.time() - t:.0f} s")
 

@@ -32,18 +32,20 @@ def summarize(logits: np.ndarray) -> dict:
 
 def oracle_points(weight_format=None):
     """LMRef (fp16 KV, like the HIP cache) over the case: [logits after the context, after step 1, after step 2].
-    weight_format="q8_0": over the model whose projections and lm_head went through llama.cpp's q8_0 rule (oracle/q8_ref.py)."""
+    weight_format="q8_0": over the model whose projections and lm_head went through llama.cpp's q8_0 rule (oracle/q8_ref.py);
+    "q4_k": through this build's Q4_K quantiser and llama.cpp's dequantize_row_q4_K (oracle/q4k_ref.py)."""
     import torch
     from oracle import lm_ref
     cfg = config()
     ctx, steps = token_ids()
     used = np.concatenate([ctx] + steps)
     w = lm_ref.random_weights(cfg, SEED, INIT_STD, embed_rows=used)
-    if weight_format == "q8_0":
-        from oracle import q8_ref
+    if weight_format in ("q8_0", "q4_k"):
+        from oracle import q4k_ref, q8_ref
+        fq = q8_ref.fake_quant if weight_format == "q8_0" else q4k_ref.fake_quant
         for k in list(w):
             if k.endswith("_proj.weight") or k == "lm_head.weight":
-                w[k] = q8_ref.fake_quant(w[k])       # one matrix at a time: the 1B lm_head alone is 2 GB in f32
+                w[k] = fq(w[k])       # one matrix at a time: the 1B lm_head alone is 2 GB in f32
     ref = lm_ref.LMRef(cfg, w, kv_dtype=torch.float16)
     pts = [ref.eval(ctx)[-1].numpy()]
     for s in steps:

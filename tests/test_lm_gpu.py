@@ -508,6 +508,76 @@ def test_f16_gguf_keeps_fp16_weights_and_an_exact_table(tmp_path):
     assert d < TOL_ORACLE and g._scores[-1].argmax() == want.argmax()
 
 
+def test_q4_k_decode_and_prefill_match_oracle_over_the_dequantised_model():
+    """SURVEY 8f-4, the reference's third deployed format (llama-quantize Q4_K_M, prep_test_model.sh:31): weight_format='q4_k' turns
+    every projection and lm_head into GGUF Q4_K super-blocks on the device (this build's min / max rule; oracle/q4k_ref.py does the
+    same on the host, block for block); the decode GEMVs stream the quad-interleaved nibbles (4.6 bits / weight), the prefill tiles
+    de-quantise the same blocks while staging with llama.cpp's dequantize_row_q4_K arithmetic.  Against LMRef over the host's blocks
+    de-quantised by that rule: decode and prefill within the tolerances the other formats get; argmax equal; graph == eager."""
+    from oracle import q4k_ref
+    from realtime_codec_agent_amd.llm import LlamaForAlternatingCodeChannels, LMConfig
+    cfg = LMConfig(vocab_size=8192, hidden=512, n_layers=4, n_heads=8, n_kv_heads=2, head_dim=64, ffn=4096)
+    llm = LlamaForAlternatingCodeChannels(model_path="random:mid", config=cfg, n_ctx=1024, random_seed=11, init_std=0.05, device=0, weight_format="q4_k")
+    assert llm.weight_format == "q4_k" and llm.weight_bytes_per_step() < 0.30 * cfg.weight_bytes_per_step()
+    llm.set_mfma_prefill(False)
+    ref = lm_ref.LMRef(cfg, q4k_ref.quantized_model(lm_ref.random_weights(cfg, 11, 0.05)), kv_dtype=torch.float16)
+    ids = np.random.default_rng(0).integers(0, 8192, 300)
+    llm.eval(ids[:39].tolist())
+    ref.eval(ids[:39])
+    llm.eval(ids[39:41].tolist())
+    got = llm._scores[-1].copy()
+    want = ref.eval(ids[39:41])[-1].numpy()
+    d = np.abs(got - want).max()
+    print(f"q4_k decode vs LMRef over the de-quantised blocks: max|dlogit| = {d:.3e} (|logit| max {np.abs(want).max():.2f})")
+    assert d < 1e-3 * max(1.0, np.abs(want).max()) and got.argmax() == want.argmax()
+    llm.init_sampler_for_generate(top_k=50, top_p=1.0, min_p=0.0, temp=1.0, seed=3)
+    llm.n_tokens = 39
+    t_graph = llm.step(ids[39:41].tolist())
+    assert np.array_equal(llm._scores[-1], got) and t_graph == lm_ref.sample(got, 50, 1.0, 0.0, 1.0, 3, 0)
+    llm.set_mfma_prefill(True)
+    llm.reset(); ref.reset()
+    llm.eval(ids[:298].tolist())
+    ref.eval(ids[:298])
+    llm.eval(ids[298:300].tolist())
+    got2 = llm._scores[-1].copy()
+    want2 = ref.eval(ids[298:300])[-1].numpy()
+    d2 = np.abs(got2 - want2).max()
+    print(f"q4_k MFMA prefill (staged de-quantisation) + decode vs LMRef: max|dlogit| = {d2:.3e} (|logit| max {np.abs(want2).max():.2f})")
+    assert d2 < 2e-3 * max(1.0, np.abs(want2).max()) and got2.argmax() == want2.argmax()
+    llm.mask_head_rows(0, 100)
+    llm.n_tokens = 298
+    llm.eval(ids[298:300].tolist())
+    assert np.all(llm._scores[-1][:100] == 0) and np.array_equal(llm._scores[-1][100:], got2[100:])
+
+
+def test_q4_k_gguf_blocks_stay_packed_and_match_their_dequantisation(tmp_path):
+    """A GGUF whose matrices are Q4_K (type 12, 144-byte super-blocks as llama-quantize lays them out) through model_path=: the blocks
+    go to the device as they are (RCA_Q4_K), are re-laid-out there and streamed packed; Q/K rows un-permuted on the raw blocks; the
+    embedding table is de-quantised exactly.  Logits equal LMRef over the file's own blocks de-quantised on the host."""
+    import gguf_writer as gw
+    from realtime_codec_agent_amd.gguf import load_llama_gguf
+    from realtime_codec_agent_amd.llm import LlamaForAlternatingCodeChannels, LMConfig, bf16_bits_to_f32
+    cfg = LMConfig(vocab_size=1024, hidden=256, n_layers=2, n_heads=4, n_kv_heads=2, head_dim=64, ffn=512, rope_scaling=None, rope_theta=10000.0)
+    w = lm_ref.random_weights(cfg, 5, 0.05)
+    wf = {k: (bf16_bits_to_f32(v) if v.dtype == np.uint16 else v.astype(np.float32)) for k, v in w.items()}
+    path = str(tmp_path / "small-q4k.gguf")
+    gw.write_llama_gguf(path, cfg, wf, matrix_type=gw.Q4_K)
+    g = LlamaForAlternatingCodeChannels(model_path=path, n_ctx=512, device=0)
+    assert g.weight_format == "q4_k"
+    _, file_w, _ = load_llama_gguf(path)
+    deq = {k: (v.dequantize() if hasattr(v, "dequantize") else v) for k, v in file_w.items() if k != "rope.inv_freq"}
+    ref = lm_ref.LMRef(cfg, deq, kv_dtype=torch.float16)
+    ids = np.random.default_rng(1).integers(0, 1024, 40)
+    for mfma in (False, True):
+        g.set_mfma_prefill(mfma)
+        g.reset(); ref.reset()
+        g.eval(ids.tolist())
+        want = ref.eval(ids)[-1].numpy()
+        d = np.abs(g._scores[-1] - want).max()
+        print(f"Q4_K GGUF (mfma_prefill={mfma}) vs LMRef over the file's blocks: max|dlogit| = {d:.3e} (|logit| max {np.abs(want).max():.2f})")
+        assert d < (2e-3 if mfma else 1e-3) * max(1.0, np.abs(want).max()) and g._scores[-1].argmax() == want.argmax()
+
+
 def test_full_size_1b_properties():
     """BASELINE config 3 dims (Llama-3.2-1B, V=259344) with random-init weights: checks that do not
     need a CPU forward -- graph replay == eager, prefill == incremental, rollback, determinism."""
@@ -633,24 +703,26 @@ def test_1b_logits_match_oracle_and_committed_slice(mfma_prefill):
 
 
 @pytest.mark.parametrize("mfma_prefill", [False, True])
-def test_1b_q8_0_logits_match_oracle(mfma_prefill):
-    """The same case with weight_format='q8_0' at LMConfig.llama_3_2_1b(): the kernels the q8_0 duplex leg of bench.py runs
+@pytest.mark.parametrize("fmt", ["q8_0", "q4_k"])
+def test_1b_quantised_logits_match_oracle(mfma_prefill, fmt):
+    """The same case with weight_format='q8_0' / 'q4_k' at LMConfig.llama_3_2_1b(): the kernels the quantised duplex legs of bench.py run
     (lm_gemv_kernel<..., Q = q8_0> at K = 2048 / 8192, the packed head at V = 259 344, the prefill tiles de-quantising the blocks
     while staging) against LMRef over the same hash weights put through llama.cpp's quantize_row_q8_0 rule on the host
-    (oracle/q8_ref.py) -- all 259 344 logits live, and the committed slice tests/golden/lm_1b_q8_topk.npz
-    (make_lm_1b_golden.py q8_0); graph step == eager."""
+    (oracle/q8_ref.py; for q4_k: through oracle/q4k_ref.py's quantiser and llama.cpp's dequantize_row_q4_K) -- all 259 344 logits
+    live, and the committed slices tests/golden/lm_1b_q8_topk.npz / lm_1b_q4k_topk.npz (make_lm_1b_golden.py q8_0 / q4_k); graph
+    step == eager."""
     import lm_1b_case as case
     from realtime_codec_agent_amd.llm import LlamaForAlternatingCodeChannels
-    fix = np.load(f"{GOLDEN}/lm_1b_q8_topk.npz")
+    fix = np.load(f"{GOLDEN}/" + {"q8_0": "lm_1b_q8_topk.npz", "q4_k": "lm_1b_q4k_topk.npz"}[fmt])
     ctx, steps = case.token_ids()
     assert np.array_equal(ctx, fix["ctx_ids"]) and np.array_equal(np.stack(steps), fix["step_ids"])
-    want = case.oracle_points("q8_0")
+    want = case.oracle_points(fmt)
     llm = LlamaForAlternatingCodeChannels(model_path="random:1b", config=case.config(), n_ctx=1024, random_seed=case.SEED,
-                                          init_std=case.INIT_STD, device=0, weight_format="q8_0")
-    assert llm.weight_format == "q8_0"
+                                          init_std=case.INIT_STD, device=0, weight_format=fmt)
+    assert llm.weight_format == fmt
     llm.set_mfma_prefill(mfma_prefill)
     tol = TOL_1B[mfma_prefill]
-    tag = "q8_0 mfma-prefill" if mfma_prefill else "q8_0 exact"
+    tag = f"{fmt} mfma-prefill" if mfma_prefill else f"{fmt} exact"
     llm.eval(ctx.tolist())
     _check_1b_point(llm._scores[-1], want[0], fix, 0, tol, tag)
     for i, s in enumerate(steps):
