@@ -70,7 +70,8 @@ def main():
     from realtime_codec_agent_amd.realtime_agent_config import RealtimeAgentConfig
     from realtime_codec_agent_amd.realtime_agent_mp import RealtimeAgentMultiprocessing
     from realtime_codec_agent_amd.duplex_bench import session_resources_kwargs
-    cfg = RealtimeAgentConfig(chunk_size_secs=0.08)
+    cfg = RealtimeAgentConfig(chunk_size_secs=0.08, use_whisper=False, top_k=100, temperature=1.0, seed=42,
+                              force_trans_after_inactivity_secs=0.0, force_response_after_inactivity_secs=0.0)   # the bench session's settings
     t0 = time.perf_counter()
     sessions = [RealtimeAgentMultiprocessing(wait_until_running=False, config=cfg, gpu_id=0, **session_resources_kwargs(seed=s)) for s in (0, 1)]
     for s in sessions:
