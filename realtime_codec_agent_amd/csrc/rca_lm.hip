@@ -2431,10 +2431,223 @@ __global__ __launch_bounds__(64) void lm_attn_mfma_combine_kernel(const LmDevSta
     }
 }
 
+// ------------------------------------------------------------------ prefill attention, flash shape
+// The decode-shaped kernel above gives every block of 32 query rows one workgroup PER 256 keys and merges the partial results in a
+// second launch: at 6 k tokens of context a 1024-token pass wrote and re-read 0.2 GB of partials per layer and spent 245 us in
+// attention for ~50 us of MFMA work.  Prefill passes (M > 8) run this kernel instead: a WAVE owns 32 query rows (32 / G tokens x
+// the G heads of one kv head) and walks the key blocks of 32 at ABSOLUTE positions 0, 32, 64, ... up to its last visible key with an
+// online softmax -- no partials, no cross-wave merge, no second launch.  Per key block, as in the decode kernel:
+//   S^T = K Q^T   (v_mfma_f32_32x32x16_f16, K straight from the fp16 cache, Q split into fp16 hi + lo once per wave)
+//                 -> lane <-> query row, registers <-> keys: max / sum / rescale are per-lane scalars
+//   O^T += V^T P^T: A = V^T from a per-wave LDS transpose of the block's V, B = P exactly as it sits in the S^T registers
+//                 (hi + lo fp16) -> O^T has dims on registers and the query row on the lane, so the running rescale exp(m - m')
+//                 and the final 1 / l are per-lane multiplies, and a lane stores 4 consecutive dims (16 bytes) at a time.
+// A query row's result depends only on its own position (every row sees the same key blocks in the same order; blocks past its
+// position contribute exact zeros behind alpha = 1), so the bits do not depend on how a prompt is cut into evals or passes -- the
+// property the shadow KV cache rests on (test_mfma_prefill_is_tiling_invariant).  The next block's K / V loads are issued before the
+// current block's arithmetic.
+#define FLASH_WAVES 4
+template <int G>
+__global__ __launch_bounds__(64 * FLASH_WAVES) void lm_attn_flash_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ qkv,
+                                                                        const f16_t* __restrict__ kc, const f16_t* __restrict__ vc,
+                                                                        float* __restrict__ attn_out, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo,
+                                                                        int nh, int nkv, float scale, int n_ctx) {
+    constexpr int HD = 64;
+    constexpr int TPB = 32 / G;   // tokens per wave
+    __shared__ __attribute__((aligned(16))) _Float16 vt_all[FLASH_WAVES][HD][ATTM_VT_PITCH];
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5, col = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    _Float16 (*vt)[ATTM_VT_PITCH] = vt_all[wave];
+    const int qb = blockIdx.y * FLASH_WAVES + wave;
+    const int M = stt->m;
+    const int t0 = qb * TPB;
+    if (t0 >= M) return;
+    const int pos0 = stt->n_tokens;
+    const int ntok = min(TPB, M - t0);
+    const int tl = col / G, hq = col % G;
+    const int ld = (nh + 2 * nkv) * HD;
+    const bool qvalid = tl < ntok;
+    const int qpos = pos0 + t0 + tl;
+    const int kmax = min(pos0 + t0 + ntok, n_ctx);   // keys [0, kmax) are visible to the last token of this wave
+    const int nblk = (kmax + 31) >> 5;
+    // ---- K / V of a key block: lane (key = col, half) takes 4 x 16 bytes of its key's row from each cache
+    u32x4 kf[4], vf[4];
+    auto load_block = [&](int kb) {
+        const long row = ((long)min(32 * kb + col, n_ctx - 1) * nkv + g) * HD + 8 * half;
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            kf[sub] = *reinterpret_cast<const u32x4*>(kc + row + 16 * sub);
+            vf[sub] = *reinterpret_cast<const u32x4*>(vc + row + 16 * sub);
+        }
+    };
+    load_block(0);
+    // ---- Q of this lane's query row, fp16 hi + lo (rows past the pass read the last valid token's: they are never stored)
+    f16x8 qh[4], ql[4];
+    {
+        const float* qp = qkv + (long)(t0 + min(tl, ntok - 1)) * ld + (g * G + hq) * HD + 8 * half;
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(qp + 16 * sub), b = *reinterpret_cast<const f32x4*>(qp + 16 * sub + 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float q = j < 4 ? a[j] : b[j - 4];
+                const _Float16 h16 = (_Float16)q;
+                qh[sub][j] = h16;
+                ql[sub][j] = (_Float16)(q - (float)h16);
+            }
+        }
+    }
+    float m_run = -INFINITY, l_run = 0.0f;
+    f32x16 oacc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[nt][r] = 0.0f;
+    for (int kb = 0; kb < nblk; ++kb) {
+        u32x4 kcur[4], vcur[4];
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) { kcur[sub] = kf[sub]; vcur[sub] = vf[sub]; }
+        load_block(min(kb + 1, nblk - 1));   // unconditional (the last iteration re-reads its own block): no merge of wait states
+        // ---- this block's V, transposed into the wave's LDS region: vt[dim][key]
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            const f16x8 v8 = __builtin_bit_cast(f16x8, vcur[sub]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vt[8 * half + 16 * sub + j][col] = v8[j];
+        }
+        // ---- S^T = K Q^T (hi + lo)
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            const f16x8 kfr = __builtin_bit_cast(f16x8, kcur[sub]);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfr, qh[sub], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfr, ql[sub], sacc, 0, 0, 0);
+        }
+        // ---- online softmax for query row `col`: registers are keys 32 kb + (r & 3) + 8 (r >> 2) + 4 half
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float sv = (qvalid && key <= qpos) ? sacc[r] * scale : -INFINITY;
+            sacc[r] = sv;
+            mx = fmaxf(mx, sv);
+        }
+        {
+            float a = mx, b = mx;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+            mx = fmaxf(a, b);
+        }
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = (m_run == -INFINITY) ? 0.0f : __expf(m_run - m_new);   // m_new >= m_run; a row with nothing visible yet keeps 0
+        float lsum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = (sacc[r] == -INFINITY) ? 0.0f : __expf(sacc[r] - m_new);
+            sacc[r] = e;
+            lsum += e;
+        }
+        {
+            float a = lsum, b = lsum;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+            lsum = a + b;
+        }
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[nt][r] *= alpha;
+        // P as the B operand of O^T += V^T P^T: registers 8 i .. 8 i + 7 feed MFMA i (hi + lo fp16)
+        f16x8 ph[2], pl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float pv = sacc[8 * i + j];
+                const _Float16 h16 = (_Float16)pv;
+                ph[i][j] = h16;
+                pl[i][j] = (_Float16)(pv - (float)h16);
+            }
+        // vt is written and read by this wave only
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const bool tail = kb == nblk - 1;   // keys of the last block past kmax may hold anything (their p is 0): zero them
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const _Float16* vrow = &vt[32 * nt + col][16 * i + 4 * half];   // lane <-> dim; slot j <-> key 16 i + 4 half + 8 (j >> 2) + (j & 3)
+                const f16x4 v0 = *reinterpret_cast<const f16x4*>(vrow);
+                const f16x4 v1 = *reinterpret_cast<const f16x4*>(vrow + 8);
+                f16x8 vb;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int key = 32 * kb + 16 * i + 4 * half + 8 * (j >> 2) + (j & 3);
+                    const _Float16 x = j < 4 ? v0[j] : v1[j - 4];
+                    vb[j] = (tail && key >= kmax) ? (_Float16)0.0f : x;
+                }
+                oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vb, ph[i], oacc[nt], 0, 0, 0);
+                oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vb, pl[i], oacc[nt], 0, 0, 0);
+            }
+        }
+        // the next iteration overwrites vt: its reads are done (one wave, LDS operations complete in order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (!qvalid) return;
+    // ---- O = O^T / l: this lane holds, for its query row, dims 32 nt + 8 (r >> 2) + 4 half + (r & 3)
+    const float inv = 1.0f / l_run;
+    const long obase = (long)(t0 + tl) * nh * HD + (long)(g * G + hq) * HD;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const int d0 = 32 * nt + 8 * rq + 4 * half;
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = oacc[nt][4 * rq + j] * inv;
+            if (hi) {   // prefill tiles: the O-projection GEMM reads bf16 hi + lo
+                unsigned ph2[2], pl2[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bf16_t h0 = f32_to_bf16_rne(o[2 * j]), h1 = f32_to_bf16_rne(o[2 * j + 1]);
+                    const bf16_t l0 = f32_to_bf16_rne(o[2 * j] - __uint_as_float((unsigned)h0 << 16));
+                    const bf16_t l1 = f32_to_bf16_rne(o[2 * j + 1] - __uint_as_float((unsigned)h1 << 16));
+                    ph2[j] = (unsigned)h0 | ((unsigned)h1 << 16);
+                    pl2[j] = (unsigned)l0 | ((unsigned)l1 << 16);
+                }
+                *reinterpret_cast<uint2*>(hi + obase + d0) = make_uint2(ph2[0], ph2[1]);
+                *reinterpret_cast<uint2*>(lo + obase + d0) = make_uint2(pl2[0], pl2[1]);
+            } else {
+                *reinterpret_cast<float4*>(attn_out + obase + d0) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+}
+static void launch_attention_flash(rca_lm* h, int M, const f16_t* kc, const f16_t* vc, hipStream_t st, bf16_t* hi, bf16_t* lo) {
+    const rca_lm_config_t& c = h->cfg;
+    const int G = c.n_heads / c.n_kv_heads;
+    const float scale = 1.0f / sqrtf((float)c.head_dim);
+    const dim3 grid(c.n_kv_heads, cdiv(cdiv(M * G, 32), FLASH_WAVES));
+    if (G == 4) lm_attn_flash_kernel<4><<<grid, 64 * FLASH_WAVES, 0, st>>>(h->stt, h->qkv, kc, vc, h->attn, hi, lo, c.n_heads, c.n_kv_heads, scale, c.n_ctx);
+    else if (G == 2) lm_attn_flash_kernel<2><<<grid, 64 * FLASH_WAVES, 0, st>>>(h->stt, h->qkv, kc, vc, h->attn, hi, lo, c.n_heads, c.n_kv_heads, scale, c.n_ctx);
+    else lm_attn_flash_kernel<1><<<grid, 64 * FLASH_WAVES, 0, st>>>(h->stt, h->qkv, kc, vc, h->attn, hi, lo, c.n_heads, c.n_kv_heads, scale, c.n_ctx);
+}
+
 // split attention on MFMA + merge of the splits, for the M tokens of the current pass
 static void launch_attention_mfma(rca_lm* h, int M, int nsp_launch, const f16_t* kc, const f16_t* vc, hipStream_t st,
-                                  bf16_t* hi = nullptr, bf16_t* lo = nullptr) {
+                                  bf16_t* hi = nullptr, bf16_t* lo = nullptr, bool prefill = false) {
     const rca_lm_config_t& c = h->cfg;
+    static const bool flash = !(getenv("RCA_LM_FLASH") && atoi(getenv("RCA_LM_FLASH")) == 0);   // 0: A/B runs against the split kernel
+    if (prefill && flash) {   // every pass of the prefill-tile path, whatever its size: pieces of one long eval must use ONE arithmetic
+        launch_attention_flash(h, M, kc, vc, st, hi, lo);
+        return;
+    }
     const int G = c.n_heads / c.n_kv_heads;
     const float scale = 1.0f / sqrtf((float)c.head_dim);
     dim3 agm(c.n_kv_heads, nsp_launch, cdiv(M * G, 32));
@@ -2885,7 +3098,7 @@ static int lm_enqueue_prefill_tile(rca_lm* h, int M, hipStream_t st, int nsp_lau
         lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.attn_norm, h->xn, H, c.rms_eps);
         lm_split_bf16_kernel<<<dim3(cdiv(H, 256), M), 256, 0, st>>>(h->stt, h->xn, h->xh, h->xl, H);
         lm_gemm_mfma_kernel<GEMM_EPI_ROPE><<<QKV / 32, 256, 0, st>>>(h->stt, L.qkv.w, h->xh, h->xl, QKV, H, h->qkv, QKV, nullptr, nullptr, rope);
-        launch_attention_mfma(h, M, nsp_launch, kc, vc, st);
+        launch_attention_mfma(h, M, nsp_launch, kc, vc, st, nullptr, nullptr, true);
         lm_split_bf16_kernel<<<dim3(cdiv(AO, 256), M), 256, 0, st>>>(h->stt, h->attn, h->xh, h->xl, AO);
         lm_gemm_mfma_kernel<GEMM_EPI_RESID><<<H / 32, 256, 0, st>>>(h->stt, L.o.w, h->xh, h->xl, H, AO, x, H, nullptr, nullptr, norope);
         lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.ffn_norm, h->xn, H, c.rms_eps);
@@ -2958,7 +3171,7 @@ static int lm_enqueue_prefill_tile128(rca_lm* h, int M, hipStream_t st, int nsp_
         lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.attn_norm, h->xn, H, c.rms_eps, h->xh, h->xl);
         launch_gemm128<GEMM_EPI_ROPE>(h, L.qkv, dim3(QKV / 128, q_seq ? 1 : sq, tbz), st, h->xh, h->xl, QKV, H, H / sq, h->qkv, QKV, nullptr, nullptr, rope, q_seq ? sq : 1);
         if (sq > 1 && !q_seq) lm_gemm128_epilogue_kernel<GEMM_EPI_ROPE><<<dim3(QKV / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sq, QKV, h->qkv, nullptr, nullptr, rope);
-        launch_attention_mfma(h, M, nsp_launch, kc, vc, st, h->xh, h->xl);
+        launch_attention_mfma(h, M, nsp_launch, kc, vc, st, h->xh, h->xl, true);
         launch_gemm128<GEMM_EPI_RESID>(h, L.o, dim3(H / 128, o_seq ? 1 : so, tbz), st, h->xh, h->xl, H, AO, AO / so, x, H, nullptr, nullptr, norope, o_seq ? so : 1);
         if (so > 1 && !o_seq) lm_gemm128_epilogue_kernel<GEMM_EPI_RESID><<<dim3(H / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, so, H, x, nullptr, nullptr, norope);
         lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.ffn_norm, h->xn, H, c.rms_eps, h->xh, h->xl);

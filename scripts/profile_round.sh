@@ -13,6 +13,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python3 $R
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lm -- python3 $R/scripts/lm_profile.py 1000 50 > $OUT/lm_stdout.log 2>&1
 # 2b. the same with the decode step streaming q8_0 weights (the program after -- is python3 itself; the format goes in through the environment)
 ( export RCA_LM_FORMAT=q8_0; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lm_q8 -- python3 $R/scripts/lm_profile.py 1000 50 > $OUT/lm_q8_stdout.log 2>&1 )
+( export RCA_LM_FORMAT=q4_k; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lm_q4k -- python3 $R/scripts/lm_profile.py 1000 50 > $OUT/lm_q4k_stdout.log 2>&1 )
+# 2c. the bf16 step at the context of the bench's duplex leg (6.6 k tokens)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lm_6k -- python3 $R/scripts/lm_profile.py 6600 50 > $OUT/lm_6k_stdout.log 2>&1
 # 3. PMC pass (own run, kernel-trace only): MFMA busy, waits, clock, LDS conflicts
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-duplex --no-trim-leg > $OUT/pmc_sq_stdout.log 2>&1
 # 4. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes (TCC slots)
@@ -20,5 +23,5 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-duplex --no-trim-leg > $OUT/pmc_write_stdout.log 2>&1
 python3 $R/scripts/summarize_profile.py $OUT > $OUT/SUMMARY.txt 2>&1
 # the raw per-dispatch traces of the two --stats runs are large (gpurun merges at most 64 MiB back): keep the stats tables
-rm -f $OUT/bench/*/*kernel_trace.csv $OUT/lm/*/*kernel_trace.csv $OUT/lm_q8/*/*kernel_trace.csv
+rm -f $OUT/bench/*/*kernel_trace.csv $OUT/lm/*/*kernel_trace.csv $OUT/lm_q8/*/*kernel_trace.csv $OUT/lm_q4k/*/*kernel_trace.csv $OUT/lm_6k/*/*kernel_trace.csv
 tail -60 $OUT/SUMMARY.txt

@@ -56,7 +56,7 @@ def pmc(sub):
 
 
 print(f"source_hash={source_hash()}  (sha256/16 over {', '.join(__import__('profile_common').HASHED)}; scripts/collect_profiles.py adds the commit)")
-for sub in ("bench", "lm", "lm_q8", "lm_q4k"):
+for sub in ("bench", "lm", "lm_6k", "lm_q8", "lm_q4k"):
     if os.path.isdir(f"{d}/{sub}"):
         stats(sub)
 sq = pmc("pmc_sq")
