@@ -191,3 +191,56 @@ def test_frame_graph_session_equals_step_by_step_session():
         assert agent.frame_graph_active == frame_graph
     assert runs[0][0] == runs[1][0]
     assert np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+
+
+def test_full_size_duplex_session_equals_the_oracle_session():
+    """BASELINE config [3] at full size against the oracle, not only inside bench.py: the default codec (131072 x 16 codebook, hop 320) and
+    the Llama-3.2-1B-dims LM (V = 259 344, hash-generated weights, text rows of lm_head zeroed like a trained codec LM in audio mode) run
+    2 s of duplex audio through the SAME RealtimeAgent twice -- over the HIP objects (frame graph, streaming codec tails, graph steps) and
+    over the CPU oracle objects (C codec oracle + LMRef + C sampler), greedy sampling.  Token stream, KV position and emitted PCM must
+    be equal (ids exactly, PCM bit for bit); the last logits within the 1B decode tolerance."""
+    from types import SimpleNamespace
+    from agent_fakes import OracleCodecModel, OracleLLM
+    from oracle import lm_ref
+    from oracle.codec import OracleCodec
+    from realtime_codec_agent_amd.audio_tokenizer import AudioTokenizer
+    from realtime_codec_agent_amd.codec import MagiCodecHIP
+    from realtime_codec_agent_amd.codec_model import CodecConfig, init_codec_weights
+    from realtime_codec_agent_amd.llm import LlamaForAlternatingCodeChannels, LMConfig
+    from realtime_codec_agent_amd.realtime_agent_config import RealtimeAgentConfig
+    from realtime_codec_agent_amd.realtime_agent_v2 import RealtimeAgent
+    from realtime_codec_agent_amd.tokenizer import CodecTokenizer
+    ccfg = CodecConfig()
+    cw = init_codec_weights(ccfg, seed=0)
+    tok = CodecTokenizer(codebook_size=ccfg.codebook_size)
+    lcfg = LMConfig.llama_3_2_1b()
+    assert len(tok) <= lcfg.vocab_size
+    w = lm_ref.random_weights(lcfg, 0, 0.02)                   # what rca_lm_create_random(seed 0) generates on the device
+    head = w["lm_head.weight"].copy()
+    head[: tok.codec_vocab_start] = 0
+    head[len(tok):] = 0
+    w["lm_head.weight"] = head
+    hip_llm = LlamaForAlternatingCodeChannels(model_path="random:1b", config=lcfg, n_ctx=4096, random_seed=0, init_std=0.02, device=0)
+    hip_llm.mask_head_rows(0, tok.codec_vocab_start)
+    hip_llm.mask_head_rows(len(tok), lcfg.vocab_size)
+    hip = SimpleNamespace(llm=hip_llm, aux_llm=None, tokenizer=tok, audio_tokenizer=AudioTokenizer(codec_model=MagiCodecHIP(ccfg, cw)),
+                          whisper_model=None, llm_model_dir="")
+    ora = SimpleNamespace(llm=OracleLLM(lcfg, w, n_ctx=4096), aux_llm=None, tokenizer=tok,
+                          audio_tokenizer=AudioTokenizer(codec_model=OracleCodecModel(OracleCodec(ccfg, cw)), device="cpu"),
+                          whisper_model=None, llm_model_dir="")
+    cfg = dict(chunk_size_secs=0.08, use_whisper=False, force_trans_after_inactivity_secs=0.0, force_response_after_inactivity_secs=0.0, temperature=0.0)
+    a_hip = RealtimeAgent(resources=hip, config=RealtimeAgentConfig(**cfg))
+    a_ora = RealtimeAgent(resources=ora, config=RealtimeAgentConfig(**cfg))
+    assert a_hip.input_ids == a_ora.input_ids                  # header incl. the 3 s enrollment encoded by both codecs
+    sig = rich_signal(1280 * 25, 33)
+    for s in range(0, len(sig), 1280):
+        o_hip = a_hip.process_audio(sig[s:s + 1280])
+        o_ora = a_ora.process_audio(sig[s:s + 1280])
+        assert a_hip.input_ids == a_ora.input_ids, f"token streams diverge in frame {s // 1280}"
+        assert np.array_equal(o_hip, o_ora), f"emitted PCM differs in frame {s // 1280}"
+        assert hip.llm.n_tokens == ora.llm.n_tokens
+    d = np.abs(hip.llm._scores[-1] - ora.llm._logits).max()
+    print(f"full-size session: {len(a_hip.input_ids)} tokens, last-step logits HIP vs oracle max|d| = {d:.2e}")
+    assert d < 1.5e-3
+    assert a_hip.frame_graph_active and not getattr(a_ora, "frame_graph_active", False)   # one graph replay per chunk on the HIP side
+    assert len(set(a_hip.input_ids[a_hip.context_start_pos + 8::2])) > 10
