@@ -42,6 +42,8 @@ typedef struct rca_lm rca_lm_t;
 #define RCA_BF16 1
 #define RCA_Q8_0 2   /* GGUF block_q8_0 as stored in the file: per 32 values one fp16 scale then 32 int8 (34 bytes); numel = values */
 #define RCA_F16 3    /* IEEE half (the reference's default model file is an F16 GGUF, realtime_agent_resources.py:12) */
+#define RCA_Q6_K 5   /* GGUF block_q6_K as stored in the file (210 bytes per 256 values: low nibbles, high bit pairs, 16 int8 scales, fp16 d): the
+                        format llama-quantize Q4_K_M gives output.weight and some attn_v / ffn_down tensors */
 #define RCA_Q4_K 4   /* GGUF block_q4_K as stored in the file: per 256 values fp16 d, fp16 dmin, 12 bytes of 6-bit scales / minima, 128 bytes
                         of nibbles (144 bytes); numel = values.  What llama-quantize Q4_K_M writes for most tensors (prep_test_model.sh:31) */
 
@@ -50,7 +52,7 @@ typedef struct {
     const char* name;
     const void* data;  /* host pointer */
     int64_t numel;
-    int32_t dtype;     /* RCA_F32, RCA_BF16, RCA_F16, RCA_Q8_0 or RCA_Q4_K (the last two: LM matrices and embedding table only) */
+    int32_t dtype;     /* RCA_F32, RCA_BF16, RCA_F16, RCA_Q8_0, RCA_Q4_K or RCA_Q6_K (the last three: LM matrices and embedding table only) */
 } rca_tensor_t;
 
 const char* rca_last_error(void);

@@ -108,3 +108,76 @@ def quantized_model(weights: dict) -> dict:
         is_proj = k.endswith("_proj.weight") or k == "lm_head.weight"
         out[k] = fake_quant(v) if is_proj else v
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------ Q6_K
+# `Q4_K_M` is a MIX: llama-quantize writes output.weight and (in the layers its use_more_bits() picks) attn_v / ffn_down as Q6_K.
+# ggml-common.h `block_q6_K` (210 bytes, 256 weights) = { uint8 ql[128]; uint8 qh[64]; int8 scales[16]; fp16 d }, and
+# ggml-quants.c `dequantize_row_q6_K`: for each half n of 128 weights (ql += 64, qh += 32, scales += 8) and l = 0..31, is = l / 16:
+#     q1 = ((ql[l]      & 0xF) | (((qh[l] >> 0) & 3) << 4)) - 32    -> y[l]      = d * scales[is + 0] * q1
+#     q2 = ((ql[l + 32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32    -> y[l + 32] = d * scales[is + 2] * q2
+#     q3 = ((ql[l]      >> 4)  | (((qh[l] >> 4) & 3) << 4)) - 32    -> y[l + 64] = d * scales[is + 4] * q3
+#     q4 = ((ql[l + 32] >> 4)  | (((qh[l] >> 6) & 3) << 4)) - 32    -> y[l + 96] = d * scales[is + 6] * q4
+# i.e. weight k of a block has the 6-bit value q_k - 32, the int8 scale of its group of 16 and the block's fp16 d; d * scale * q is
+# exact in f32 (11 + 7 + 6 bits).
+def quantize_q6_k(w: np.ndarray):
+    """float32 [..., K] (K % 256 == 0) -> dict(q int8 [..., K] in -32..31, sc int8 [..., K/16], d float16 [..., K/256]).  This build's
+    simple symmetric rule (llama-quantize searches with make_qx_quants)."""
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    lead, K = w.shape[:-1], w.shape[-1]
+    assert K % 256 == 0
+    g = w.reshape(-1, K // 256, 16, 16)
+    amax = np.abs(g).max(axis=-1)                                        # per group of 16
+    s = (amax / np.float32(31.0)).astype(np.float32)                     # group step
+    d = (s.max(axis=-1) / np.float32(127.0)).astype(np.float16)
+    df = d.astype(np.float32)[..., None]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sc = np.where(df > 0, _round_half_up(s / np.where(df > 0, df, 1)), 0)
+    sc = np.clip(sc, 0, 127).astype(np.float32)
+    step = (df * sc).astype(np.float32)[..., None]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        q = np.where(step > 0, np.floor(g / np.where(step > 0, step, 1) + np.float32(0.5)), 0)
+    q = np.clip(q, -32, 31).astype(np.int8)
+    return dict(q=q.reshape(*lead, K), sc=sc.astype(np.int8).reshape(*lead, K // 16), d=d.reshape(*lead, K // 256))
+
+
+def pack_blocks_q6_k(p: dict) -> np.ndarray:
+    """-> raw GGUF block_q6_K bytes uint8 [n_blocks, 210]"""
+    u = (p["q"].reshape(-1, 2, 4, 32).astype(np.int16) + 32).astype(np.uint8)        # [blk][half n][quarter 0..3][l]; weight 128 n + 32 quarter + l
+    nb = u.shape[0]
+    lo, hi = u & 0xF, u >> 4
+    ql = np.empty((nb, 2, 64), np.uint8)
+    ql[:, :, 0:32] = lo[:, :, 0] | (lo[:, :, 2] << 4)          # ql[l]      : low nibble q1 (quarter 0), high nibble q3 (quarter 2)
+    ql[:, :, 32:64] = lo[:, :, 1] | (lo[:, :, 3] << 4)         # ql[l + 32] : low nibble q2 (quarter 1), high nibble q4 (quarter 3)
+    qh = hi[:, :, 0] | (hi[:, :, 1] << 2) | (hi[:, :, 2] << 4) | (hi[:, :, 3] << 6)   # [nb, 2, 32]
+    out = np.empty((nb, 210), np.uint8)
+    out[:, 0:128] = ql.reshape(nb, 128)
+    out[:, 128:192] = qh.reshape(nb, 64)
+    out[:, 192:208] = p["sc"].reshape(nb, 16).view(np.uint8)
+    out[:, 208:210] = p["d"].reshape(-1, 1).view(np.uint8)
+    return out
+
+
+def dequantize_blocks_q6_k(raw: np.ndarray) -> np.ndarray:
+    """raw blocks uint8 [nb, 210] -> float32 [nb * 256] by dequantize_row_q6_K's rule"""
+    raw = raw.reshape(-1, 210)
+    nb = raw.shape[0]
+    ql = raw[:, 0:128].reshape(nb, 2, 64)
+    qh = raw[:, 128:192].reshape(nb, 2, 32)
+    sc = raw[:, 192:208].copy().view(np.int8).astype(np.float32).reshape(nb, 2, 8)       # per half: scales[is + 0 / 2 / 4 / 6], is = l / 16
+    d = raw[:, 208:210].copy().view(np.float16).astype(np.float32).reshape(nb, 1, 1)
+    q = np.empty((nb, 2, 4, 32), np.int16)
+    q[:, :, 0] = (ql[:, :, 0:32] & 0xF) | (((qh >> 0) & 3) << 4)
+    q[:, :, 1] = (ql[:, :, 32:64] & 0xF) | (((qh >> 2) & 3) << 4)
+    q[:, :, 2] = (ql[:, :, 0:32] >> 4) | (((qh >> 4) & 3) << 4)
+    q[:, :, 3] = (ql[:, :, 32:64] >> 4) | (((qh >> 6) & 3) << 4)
+    q = (q - 32).astype(np.float32)
+    # quarter j, l -> scale index is + 2 j with is = l / 16
+    scq = np.stack([np.repeat(sc[:, :, 2 * j:2 * j + 2], 16, axis=-1) for j in range(4)], axis=2)     # [nb, 2, 4, 32]
+    return ((d[..., None] * scq).astype(np.float32) * q).astype(np.float32).reshape(-1)
+
+
+def fake_quant_q6_k(w: np.ndarray) -> np.ndarray:
+    if w.dtype == np.uint16:
+        w = (w.astype(np.uint32) << 16).view(np.float32)
+    return dequantize_blocks_q6_k(pack_blocks_q6_k(quantize_q6_k(w))).reshape(w.shape)

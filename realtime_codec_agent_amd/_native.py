@@ -21,7 +21,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"
                "-Wno-unused-result"]
 
 MAX_STAGES = 8
-RCA_F32, RCA_BF16, RCA_Q8_0, RCA_F16, RCA_Q4_K = 0, 1, 2, 3, 4
+RCA_F32, RCA_BF16, RCA_Q8_0, RCA_F16, RCA_Q4_K, RCA_Q6_K = 0, 1, 2, 3, 4, 5
 
 
 class RcaError(RuntimeError):
@@ -76,6 +76,37 @@ class Q4KBlocks:
     def take_rows(self, index) -> "Q4KBlocks":
         r = self.raw[index]
         return Q4KBlocks(np.ascontiguousarray(r), (r.shape[0], self.shape[1]))
+
+
+class Q6KBlocks:
+    """A GGUF Q6_K tensor kept as its raw 210-byte super-blocks (128 bytes of low nibbles, 64 bytes of high bit pairs, 16 int8 scales,
+    fp16 d per 256 values): raw uint8 [rows, cols / 256 * 210], logical shape (rows, cols).  llama-quantize Q4_K_M writes
+    output.weight and some attn_v / ffn_down tensors in this format."""
+
+    def __init__(self, raw: np.ndarray, shape):
+        self.shape = tuple(int(x) for x in shape)
+        self.raw = raw.reshape(self.shape[0], self.shape[1] // 256 * 210)
+        self.dtype = np.dtype(np.uint8)
+
+    def dequantize(self) -> np.ndarray:
+        """llama.cpp's dequantize_row_q6_K: d * scale(group of 16) * (6-bit value - 32), f32 (exact)."""
+        blk = self.raw.reshape(-1, 210)
+        nb = blk.shape[0]
+        ql = blk[:, 0:128].reshape(nb, 2, 64)
+        qh = blk[:, 128:192].reshape(nb, 2, 32)
+        sc = blk[:, 192:208].copy().view(np.int8).astype(np.float32)                 # [nb, 16], natural group order
+        d = blk[:, 208:210].copy().view(np.float16).astype(np.float32)                # [nb, 1]
+        q = np.empty((nb, 2, 4, 32), np.int16)
+        q[:, :, 0] = (ql[:, :, 0:32] & 0xF) | (((qh >> 0) & 3) << 4)
+        q[:, :, 1] = (ql[:, :, 32:64] & 0xF) | (((qh >> 2) & 3) << 4)
+        q[:, :, 2] = (ql[:, :, 0:32] >> 4) | (((qh >> 4) & 3) << 4)
+        q[:, :, 3] = (ql[:, :, 32:64] >> 4) | (((qh >> 6) & 3) << 4)
+        q = (q.reshape(nb, 256) - 32).astype(np.float32)
+        return ((d * sc).astype(np.float32).repeat(16, axis=1) * q).astype(np.float32).reshape(self.shape)
+
+    def take_rows(self, index) -> "Q6KBlocks":
+        r = self.raw[index]
+        return Q6KBlocks(np.ascontiguousarray(r), (r.shape[0], self.shape[1]))
 
 
 class Tensor(C.Structure):
@@ -241,11 +272,11 @@ def make_tensors(weights: Dict[str, np.ndarray]) -> Tuple[C.Array, list]:
     keep = []
     arr = (Tensor * len(weights))()
     for i, (name, a) in enumerate(weights.items()):
-        if isinstance(a, (Q8Blocks, Q4KBlocks)):      # GGUF q8_0 / Q4_K blocks, handed over as they sit in the file
+        if isinstance(a, (Q8Blocks, Q4KBlocks, Q6KBlocks)):      # GGUF q8_0 / Q4_K / Q6_K blocks, handed over as they sit in the file
             raw = np.ascontiguousarray(a.raw)
             nb = name.encode()
             keep += [raw, nb]
-            arr[i] = Tensor(nb, raw.ctypes.data, int(np.prod(a.shape)), RCA_Q8_0 if isinstance(a, Q8Blocks) else RCA_Q4_K)
+            arr[i] = Tensor(nb, raw.ctypes.data, int(np.prod(a.shape)), RCA_Q8_0 if isinstance(a, Q8Blocks) else (RCA_Q4_K if isinstance(a, Q4KBlocks) else RCA_Q6_K))
             continue
         if a.dtype == np.uint16:
             dt = RCA_BF16

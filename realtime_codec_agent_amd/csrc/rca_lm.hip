@@ -261,6 +261,8 @@ struct GemvPro {
 };
 struct GemvRope {
     const float* cos_t; const float* sin_t; f16_t* kc; f16_t* vc; int nh, nkv, n_ctx;
+    int row_base;   // first row of this matrix inside the fused [q; k; v] layout (a multiple of 64): a Q4_K_M file keeps some attn_v tensors
+                    // in another format than attn_q / attn_k, and such a layer's V projection is a matrix of its own
 };
 __device__ __forceinline__ void lane_swap32(float& a, float& b) {   // a = [a.lo, b.lo], b = [a.hi, b.hi]
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
@@ -335,9 +337,12 @@ __host__ __device__ __forceinline__ long q8_sc_index(long pair, long kblock, lon
 #define WF_Q8 1     // GGUF q8_0, pair-interleaved (GemvQ8)
 #define WF_F16 2    // fp16 [N][K] (the reference's default GGUF is F16, realtime_agent_resources.py:12)
 #define WF_Q4K 3    // GGUF Q4_K, quad-interleaved nibbles (GemvQ8 with dd)
+#define WF_Q6K 4    // GGUF Q6_K re-encoded losslessly: int8 values (the 6-bit value - 32) in the q8_0 pair layout + one f32 scale d * sc per
+                    // row and group of 16 ((s_a, s_b) per pair, pairs in groups of 8: [ceil(N / 16)][K / 16][8][2] floats); 10 bits per
+                    // weight streamed (the file holds 6.6); d * sc * q is exact in f32, so the values are llama.cpp's dequantize_row_q6_K's
 // minimum waves per SIMD asked of the register allocator.  The q8_0 bodies otherwise spread over 200+ registers (one wave per
 // SIMD) although their live set is ~130: a streaming kernel wants the occupancy.
-constexpr int gemv_min_waves(int Q, int R, int NIT) { return (Q != WF_Q8 && Q != WF_Q4K) ? 1 : (R * NIT >= 16 ? 2 : 4); }
+constexpr int gemv_min_waves(int Q, int R, int NIT) { return (Q != WF_Q8 && Q != WF_Q4K && Q != WF_Q6K) ? 1 : (R * NIT >= 16 ? 2 : 4); }
 template <int M, int NIT, int R, int PRO, int EPI, int Q = 0>
 __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel(const LmDevState* __restrict__ stt, const bf16_t* __restrict__ W,
                                                       const float* __restrict__ x, float* __restrict__ y, int N, int K,
@@ -365,13 +370,15 @@ __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel
         }
         return b * R + r;
     };
-    constexpr bool Q8 = Q == WF_Q8, Q4 = Q == WF_Q4K;
-    constexpr int NL = Q8 ? R / 2 : (Q4 ? R / 4 : R);   // 16-byte weight loads per chunk: one per row, per slot pair (q8_0) or per slot quad (Q4_K)
+    constexpr bool Q6 = Q == WF_Q6K;                 // the q8_0 body with another scale: f32 per group of 16 instead of fp16 per 32
+    constexpr bool Q8 = Q == WF_Q8 || Q6, Q4 = Q == WF_Q4K;
+    constexpr int NL = Q8 ? R / 2 : (Q4 ? R / 4 : R);   // 16-byte weight loads per chunk: one per row, per slot pair (q8_0 / Q6_K) or per slot quad (Q4_K)
     constexpr int H0 = NL / 2;                // the batch's registers refill in two halves: loads [0, H0) and [H0, NL)
     u32x4 wq[NL][NIT];
     uint2 wscm[Q4 ? NIT : 1][Q4 ? NL : 1];    // Q4_K: (sc | m << 8) of a quad's four slots for this lane's 32-element sub-block
     u32x4 wdd[Q4 ? NIT : 1][Q4 ? NL : 1];     //       (d | dmin << 16) of the four slots for this lane's 256-element super-block
     unsigned wsc[Q8 ? NIT : 1][Q8 ? R / 2 : 1];   // q8_0: (fp16, fp16) scales of the batch's pairs for this lane's 32-element block
+    unsigned wsc2[Q6 ? NIT : 1][Q6 ? R / 2 : 1];  // Q6_K: wsc / wsc2 = the f32 scales (bits) of the pair's first / second row for this lane's group of 16
     const int npairs = N >> 1;
     // Every lane loads from a VALID address, whatever its chunk: a lane past the wave's range (narrow test models) re-reads chunk 0
     // and multiplies it by x = 0.  A select or an exec mask on the loaded value would be a vector instruction on the load's
@@ -410,6 +417,21 @@ __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel
     auto issue_scales = [&](int b, int s_beg, int s_end) {
         if (!Q8) return;
         const long p0 = (long)b * (R / 2);
+        if (Q6) {   // (s_a, s_b) floats per pair: two pairs per 16-byte load
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = lane + 64 * it;
+                const int cc = cbase + (c < cn ? c : 0);
+                const unsigned* sp = q8.sc + 2 * q8_sc_index(p0, cc >> 1, K >> 4);
+#pragma unroll
+                for (int s2 = 0; s2 < R / 2; s2 += 2) {
+                    if (s2 < s_beg || s2 >= s_end) continue;
+                    const u32x4 t = *reinterpret_cast<const u32x4*>(sp + 2 * s2);
+                    wsc[it][s2] = t.x; wsc2[it][s2] = t.y; wsc[it][s2 + 1] = t.z; wsc2[it][s2 + 1] = t.w;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int c = lane + 64 * it;
@@ -582,7 +604,7 @@ __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel
                     }
                 }
                 const f16x2 d2 = __builtin_bit_cast(f16x2, wsc[it][r]);
-                const float da = (float)d2[0], db = (float)d2[1];
+                const float da = Q6 ? __uint_as_float(wsc[it][r]) : (float)d2[0], db = Q6 ? __uint_as_float(wsc2[it][r]) : (float)d2[1];
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
                     val[m * R + 2 * r] = __builtin_fmaf(da, pa[m], val[m * R + 2 * r]);
@@ -685,9 +707,10 @@ __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel
         } else {
             if (tid < V / 2) {
                 const int m = tid / (R / 2), s = tid % (R / 2);
-                const int r0 = row_of(b, 2 * s);
+                const int rl = row_of(b, 2 * s);             // row inside this matrix
+                const int r0 = rl + rope.row_base;           // row inside [q; k; v]
                 const int pos = pos0 + m;
-                if (r0 + 32 < N && pos < rope.n_ctx) {
+                if (rl + 32 < N && pos < rope.n_ctx) {
                     const float x1 = total(m * R + 2 * s), x2 = total(m * R + 2 * s + 1);
                     const int head = r0 >> 6, d = r0 & 63;   // d < 32
                     if (head < rope.nh + rope.nkv) {
@@ -1357,6 +1380,50 @@ __global__ __launch_bounds__(256) void lm_q4k_pack_kernel(const unsigned char* _
         qs[i] = u32x4{dw[0], dw[1], dw[2], dw[3]};
     }
 }
+// ---- Q6_K.  Plain form on the device: q [N][K] int8 (the 6-bit value - 32), sc [N][K / 16] int8, d [N][K / 256] fp16.
+__global__ __launch_bounds__(256) void lm_q6k_unblock_kernel(const unsigned char* __restrict__ blocks, long nblocks, signed char* __restrict__ q,
+                                                             signed char* __restrict__ sc, f16_t* __restrict__ d) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nblocks * 256; i += (long)gridDim.x * blockDim.x) {
+        const long blk = i >> 8;
+        const int e = (int)(i & 255);
+        const unsigned char* bp = blocks + blk * 210;
+        const int n = e >> 7, j = (e >> 5) & 3, l = e & 31;          // weight 128 n + 32 j + l (dequantize_row_q6_K's q1..q4 = j 0..3)
+        const unsigned char lb = bp[64 * n + 32 * (j & 1) + l];
+        const unsigned lo = (j >> 1) ? (lb >> 4) : (lb & 0xF);
+        const unsigned hi = (bp[128 + 32 * n + l] >> (2 * j)) & 3u;
+        q[i] = (signed char)((int)(lo | (hi << 4)) - 32);
+        if ((e & 15) == 0) sc[blk * 16 + (e >> 4)] = (signed char)bp[192 + (e >> 4)];
+        if (e == 0) {
+            const unsigned short bits = (unsigned short)bp[208] | ((unsigned short)bp[209] << 8);
+            d[blk] = __builtin_bit_cast(f16_t, bits);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void lm_q6k_dequant_f32_kernel(const signed char* __restrict__ q, const signed char* __restrict__ sc, const f16_t* __restrict__ d,
+                                                                 float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = ((float)d[i >> 8] * (float)sc[i >> 4]) * (float)q[i];
+}
+// plain -> the q8_0 pair layout for the values + (s_a, s_b) f32 scales per pair and group of 16
+__global__ __launch_bounds__(256) void lm_q6k_pack_kernel(const signed char* __restrict__ q, const signed char* __restrict__ sc, const f16_t* __restrict__ d,
+                                                          int N, int K, int qkv_pairs, u32x4* __restrict__ qs, float* __restrict__ osc) {
+    const long nchunk = K >> 3, npairs = N >> 1, nk16 = K >> 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npairs * nchunk; i += (long)gridDim.x * blockDim.x) {
+        const long pp = i / nchunk;
+        const int c = (int)(i - pp * nchunk);
+        const long ra = qkv_pairs ? (pp >> 5) * 64 + (pp & 31) : 2 * pp;
+        const long rb = qkv_pairs ? ra + 32 : ra + 1;
+        const uint2 a = *reinterpret_cast<const uint2*>(q + ra * K + 8 * c);
+        const uint2 b = *reinterpret_cast<const uint2*>(q + rb * K + 8 * c);
+        qs[i] = u32x4{a.x, a.y, b.x, b.y};
+        if ((c & 1) == 0) {
+            const long k16 = c >> 1;
+            float* o = osc + 2 * q8_sc_index(pp, k16, nk16);
+            o[0] = (float)d[ra * (K >> 8) + (k16 >> 4)] * (float)sc[ra * nk16 + k16];
+            o[1] = (float)d[rb * (K >> 8) + (k16 >> 4)] * (float)sc[rb * nk16 + k16];
+        }
+    }
+}
 // plain -> GemvQ8.  pair pp = rows (2pp, 2pp+1), or for the fused QKV matrix (qkv_pairs) rows (d, d+32) of one head.
 __global__ __launch_bounds__(256) void lm_q8_pack_kernel(const signed char* __restrict__ q, const f16_t* __restrict__ d, int N, int K, int qkv_pairs,
                                                          u32x4* __restrict__ qs, unsigned* __restrict__ sc) {
@@ -1394,11 +1461,13 @@ struct WMat {
     }
     long stream_bytes() const {   // bytes one decode pass reads of it
         const long n = (long)N * K;
-        return fmt == WF_Q8 ? n + n / 16 : (fmt == WF_Q4K ? n / 2 + n / 16 + n / 64 : 2 * n);
+        return fmt == WF_Q8 ? n + n / 16 : (fmt == WF_Q4K ? n / 2 + n / 16 + n / 64 : (fmt == WF_Q6K ? n + n / 4 : 2 * n));
     }
 };
 struct LmLayer {
     WMat qkv, o, gu, down;
+    WMat vseg;              // split_v: qkv holds [q; k] only and the V projection is a matrix of its own (formats differ)
+    bool split_v = false;
     float *attn_norm = nullptr, *ffn_norm = nullptr;
 };
 
@@ -1458,7 +1527,7 @@ static int lm_alloc(void** p, size_t bytes) {
 
 static void lm_free_weights(rca_lm* h) {
     for (auto& L : h->layers) {
-        for (WMat* m : {&L.qkv, &L.o, &L.gu, &L.down}) m->release();
+        for (WMat* m : {&L.qkv, &L.o, &L.gu, &L.down, &L.vseg}) m->release();
         for (void* p : {(void*)L.attn_norm, (void*)L.ffn_norm})
             if (p) (void)hipFree(p);
     }
@@ -1560,6 +1629,7 @@ struct RawMat {
     // (array, bytes per row) of every component
     int parts(void** ptr, long* row_bytes) const {
         if (fmt == WF_Q4K) { ptr[0] = q; row_bytes[0] = cols; ptr[1] = d; row_bytes[1] = cols / 32 * 2; ptr[2] = dd; row_bytes[2] = cols / 256 * 4; return 3; }
+        if (fmt == WF_Q6K) { ptr[0] = q; row_bytes[0] = cols; ptr[1] = d; row_bytes[1] = cols / 16; ptr[2] = dd; row_bytes[2] = cols / 256 * 2; return 3; }   // d: int8 scales, dd: fp16 d
         if (fmt == WF_Q8) { ptr[0] = q; row_bytes[0] = cols; ptr[1] = d; row_bytes[1] = cols / 32 * 2; return 2; }
         ptr[0] = w16; row_bytes[0] = cols * 2;
         return 1;
@@ -1571,6 +1641,12 @@ struct RawMat {
             if (c % 256) return fail(RCA_ERR_ARG, "Q4_K needs rows of a multiple of 256 values (got %ld)", c);
             if ((rc = lm_alloc((void**)&q, (size_t)r * c)) != RCA_OK || (rc = lm_alloc((void**)&d, (size_t)r * (c / 32) * 2)) != RCA_OK ||
                 (rc = lm_alloc((void**)&dd, (size_t)r * (c / 256) * 4)) != RCA_OK) { release(); return rc; }
+            return RCA_OK;
+        }
+        if (f == WF_Q6K) {
+            if (c % 256) return fail(RCA_ERR_ARG, "Q6_K needs rows of a multiple of 256 values (got %ld)", c);
+            if ((rc = lm_alloc((void**)&q, (size_t)r * c)) != RCA_OK || (rc = lm_alloc((void**)&d, (size_t)r * (c / 16))) != RCA_OK ||
+                (rc = lm_alloc((void**)&dd, (size_t)r * (c / 256) * 2)) != RCA_OK) { release(); return rc; }
             return RCA_OK;
         }
         if (f == WF_Q8) {
@@ -1598,6 +1674,20 @@ static int lm_upload_raw(rca_lm* h, const rca_tensor_t* ts, int nt, const std::s
         hipError_t e = hipMemcpy(raw, t->data, (size_t)nblk * 34, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
             lm_q8_unblock_kernel<<<4096, 256, 0, h->stream>>>(raw, nblk, out->q, out->d);
+            e = hipStreamSynchronize(h->stream);
+        }
+        (void)hipFree(raw);
+        if (e != hipSuccess) { out->release(); return fail(RCA_ERR_HIP, "upload '%s': %s", name.c_str(), hipGetErrorString(e)); }
+        return RCA_OK;
+    }
+    if (t->dtype == RCA_Q6_K) {
+        if ((rc = out->alloc(WF_Q6K, rows, cols)) != RCA_OK) return rc;
+        const long nblk = numel / 256;
+        unsigned char* raw = nullptr;
+        if ((rc = lm_alloc((void**)&raw, (size_t)nblk * 210)) != RCA_OK) { out->release(); return rc; }
+        hipError_t e = hipMemcpy(raw, t->data, (size_t)nblk * 210, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            lm_q6k_unblock_kernel<<<4096, 256, 0, h->stream>>>(raw, nblk, out->q, (signed char*)out->d, (f16_t*)out->dd);
             e = hipStreamSynchronize(h->stream);
         }
         (void)hipFree(raw);
@@ -1667,10 +1757,11 @@ static int lm_upload_embed(rca_lm* h, const rca_tensor_t* ts, int nt, const std:
         if (e != hipSuccess) return fail(RCA_ERR_HIP, "upload '%s': %s", name.c_str(), hipGetErrorString(e));
         return RCA_OK;
     }
-    if (t->dtype == RCA_Q8_0 || t->dtype == RCA_Q4_K) {
+    if (t->dtype == RCA_Q8_0 || t->dtype == RCA_Q4_K || t->dtype == RCA_Q6_K) {
         RawMat raw;
         if ((rc = lm_upload_raw(h, ts, nt, name, rows, cols, &raw)) != RCA_OK) return rc;
-        if (raw.fmt == WF_Q4K) lm_q4k_dequant_f32_kernel<<<4096, 256, 0, h->stream>>>((const unsigned char*)raw.q, (const unsigned short*)raw.d, raw.dd, (float*)h->embed, numel);
+        if (raw.fmt == WF_Q6K) lm_q6k_dequant_f32_kernel<<<4096, 256, 0, h->stream>>>(raw.q, (const signed char*)raw.d, (const f16_t*)raw.dd, (float*)h->embed, numel);
+        else if (raw.fmt == WF_Q4K) lm_q4k_dequant_f32_kernel<<<4096, 256, 0, h->stream>>>((const unsigned char*)raw.q, (const unsigned short*)raw.d, raw.dd, (float*)h->embed, numel);
         else lm_q8_dequant_f32_kernel<<<4096, 256, 0, h->stream>>>(raw.q, raw.d, (float*)h->embed, numel);
         hipError_t e = hipStreamSynchronize(h->stream);
         raw.release();
@@ -1704,7 +1795,7 @@ static int lm_upload_f32(const rca_tensor_t* ts, int nt, const std::string& name
 // rca_lm_config_t::decode_weights applied to one plain matrix: 1 = quantise to q8_0 the way llama-quantize does, 2 = fp16.
 // A matrix that ARRIVED quantised stays what it is.
 static int lm_raw_convert(rca_lm* h, RawMat* m, int want) {
-    if (want == 0 || m->fmt == WF_Q8 || m->fmt == WF_Q4K) return RCA_OK;
+    if (want == 0 || m->fmt == WF_Q8 || m->fmt == WF_Q4K || m->fmt == WF_Q6K) return RCA_OK;
     int rc;
     if (want == 3) {
         RawMat qd;
@@ -1792,6 +1883,20 @@ static int lm_finish_mat(rca_lm* h, RawMat* raw, int qkv_pairs, WMat* out, const
         hipError_t e = hipStreamSynchronize(h->stream);
         raw->release();
         if (e != hipSuccess) return fail(RCA_ERR_HIP, "Q4_K pack of %s: %s", what, hipGetErrorString(e));
+        return RCA_OK;
+    }
+    if (raw->fmt == WF_Q6K) {
+        const int N = out->N, K = out->K;
+        if ((K % 256) || (N % 2) || (qkv_pairs && (N % 64))) { raw->release(); return fail(RCA_ERR_ARG, "Q6_K weights: %s is %d x %d (K must be a multiple of 256, N even)", what, N, K); }
+        int rc;
+        const long npairs = N / 2, nchunk = K / 8;
+        const size_t sc_bytes = (size_t)((npairs + 7) / 8) * (K / 16) * 8 * 2 * 4;
+        if ((rc = lm_alloc((void**)&out->qs, (size_t)npairs * nchunk * 16)) != RCA_OK || (rc = lm_alloc((void**)&out->sc, sc_bytes)) != RCA_OK) { raw->release(); return rc; }
+        (void)hipMemsetAsync(out->sc, 0, sc_bytes, h->stream);
+        lm_q6k_pack_kernel<<<4096, 256, 0, h->stream>>>(raw->q, (const signed char*)raw->d, (const f16_t*)raw->dd, N, K, qkv_pairs, out->qs, (float*)out->sc);
+        hipError_t e = hipStreamSynchronize(h->stream);
+        raw->release();
+        if (e != hipSuccess) return fail(RCA_ERR_HIP, "Q6_K pack of %s: %s", what, hipGetErrorString(e));
         return RCA_OK;
     }
     if (raw->fmt != WF_Q8) {
@@ -1931,7 +2036,11 @@ static int lm_build_layer(rca_lm* h, LmLayer& L, RawMat& q, RawMat& k, RawMat& v
     auto done = [&](int code) { for (RawMat* m : {&q, &k, &v, &o, &g, &u, &dn, &qkv, &gu}) m->release(); return code; };
     for (RawMat* m : {&q, &k, &v, &o, &g, &u, &dn})
         if ((rc = lm_raw_convert(h, m, want)) != RCA_OK) return done(rc);
-    if ((rc = lm_raw_concat(h, {&q, &k, &v}, &qkv, "the fused QKV projection")) != RCA_OK) return done(rc);
+    if (q.fmt == k.fmt && k.fmt != v.fmt) {   // llama-quantize Q4_K_M: attn_v is Q6_K in the layers use_more_bits() picks, attn_q / attn_k Q4_K
+        if ((rc = lm_raw_concat(h, {&q, &k}, &qkv, "the fused QK projection")) != RCA_OK) return done(rc);
+        if ((rc = lm_finish_mat(h, &v, 1, &L.vseg, "v_proj")) != RCA_OK) return done(rc);
+        L.split_v = true;
+    } else if ((rc = lm_raw_concat(h, {&q, &k, &v}, &qkv, "the fused QKV projection")) != RCA_OK) return done(rc);
     q.release(); k.release(); v.release();
     if ((rc = lm_raw_interleave(h, &g, &u, &gu, "the fused gate/up projection")) != RCA_OK) return done(rc);
     g.release(); u.release();
@@ -2102,10 +2211,10 @@ static void launch_gemv_q(GemvGeom g, rca_lm* h, int M, const WMat& w, const flo
                           const GemvRope& rope, hipStream_t st) {
     const int nit = cdiv(cdiv(K >> 3, 4), 64);
     // 16-byte weight loads in flight per lane: at most 16 (registers); q8_0 needs one load per row PAIR
-    const int lpr = Q == WF_Q8 ? 2 : (Q == WF_Q4K ? 4 : 1);
+    const int lpr = (Q == WF_Q8 || Q == WF_Q6K) ? 2 : (Q == WF_Q4K ? 4 : 1);
     const int max_loads = Q == WF_Q4K ? 8 : 16;   // Q4_K also holds the factors of every quad in registers
     while (g.R > 4 && (g.R / lpr) * (nit == 3 ? 4 : nit) > max_loads) g.R >>= 1;
-    if (Q == WF_Q4K && g.R < 8) g.R = 8;   // a Q4_K batch is at least two quads (one per register half)
+    if ((Q == WF_Q4K || Q == WF_Q6K) && g.R < 8) g.R = 8;   // a Q4_K batch is at least two quads (one per register half); Q6_K scale loads cover two pairs
     if (PRO == 0 && EPI == 3 && nit > 1) {
         if (nit == 2) {
             if (M == 1) launch_gemv_r<1, 2, 0, 3, Q>(g, h, w, x, y, N, K, ldy, pro, rope, st);
@@ -2124,8 +2233,9 @@ static void launch_gemv_q(GemvGeom g, rca_lm* h, int M, const WMat& w, const flo
 template <int PRO, int EPI>
 static void launch_gemv(int kind, rca_lm* h, int M, const WMat& w, const float* x, float* y, int N, int K, int ldy, const GemvPro& pro,
                         const GemvRope& rope, hipStream_t st) {
-    const GemvGeom g = gemv_geom(kind, N, w.fmt == WF_Q8 || w.fmt == WF_Q4K);
-    if (w.fmt == WF_Q4K) launch_gemv_q<PRO, EPI, WF_Q4K>(g, h, M, w, x, y, N, K, ldy, pro, rope, st);
+    const GemvGeom g = gemv_geom(kind, N, w.fmt == WF_Q8 || w.fmt == WF_Q4K || w.fmt == WF_Q6K);
+    if (w.fmt == WF_Q6K) launch_gemv_q<PRO, EPI, WF_Q6K>(g, h, M, w, x, y, N, K, ldy, pro, rope, st);
+    else if (w.fmt == WF_Q4K) launch_gemv_q<PRO, EPI, WF_Q4K>(g, h, M, w, x, y, N, K, ldy, pro, rope, st);
     else if (w.fmt == WF_Q8) launch_gemv_q<PRO, EPI, WF_Q8>(g, h, M, w, x, y, N, K, ldy, pro, rope, st);
     else if (w.fmt == WF_F16) launch_gemv_q<PRO, EPI, WF_F16>(g, h, M, w, x, y, N, K, ldy, pro, rope, st);
     else launch_gemv_q<PRO, EPI, WF_BF16>(g, h, M, w, x, y, N, K, ldy, pro, rope, st);
@@ -2684,8 +2794,8 @@ static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st, in
     const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim, F = c.ffn;
     if (M < 1 || M > LM_GEMV_M) return fail(RCA_ERR_ARG, "decode pass of %d tokens", M);
     const GemvPro nopro{nullptr, nullptr, 0.0f, 0};
-    GemvRope rope{h->cos_t, h->sin_t, nullptr, nullptr, c.n_heads, c.n_kv_heads, c.n_ctx};
-    const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    GemvRope rope{h->cos_t, h->sin_t, nullptr, nullptr, c.n_heads, c.n_kv_heads, c.n_ctx, 0};
+    const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
     float* x = h->x;
     lm_embed_kernel<<<M, 256, 0, st>>>(h->stt, h->embed, h->embed_f32, x, H, c.vocab_size);
     for (int l = 0; l < c.n_layers; ++l) {
@@ -2693,7 +2803,12 @@ static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st, in
         f16_t* kc = h->kc + (long)l * h->kv_layer_stride;
         f16_t* vc = h->vc + (long)l * h->kv_layer_stride;
         rope.kc = kc; rope.vc = vc;
-        launch_gemv<1, 2>(GEMV_QKV, h, M, L.qkv, nullptr, h->qkv, QKV, H, QKV, GemvPro{x, L.attn_norm, c.rms_eps, 0}, rope, st);
+        launch_gemv<1, 2>(GEMV_QKV, h, M, L.qkv, nullptr, h->qkv, L.qkv.N, H, QKV, GemvPro{x, L.attn_norm, c.rms_eps, 0}, rope, st);
+        if (L.split_v) {   // the V projection of this layer is kept in another format than Q / K (a Q4_K_M file): its own launch
+            rope.row_base = L.qkv.N;
+            launch_gemv<1, 2>(GEMV_QKV, h, M, L.vseg, nullptr, h->qkv, L.vseg.N, H, QKV, GemvPro{x, L.attn_norm, c.rms_eps, 0}, rope, st);
+            rope.row_base = 0;
+        }
         launch_attention_mfma(h, M, nsp_launch, kc, vc, st);
         launch_gemv<0, 3>(GEMV_O, h, M, L.o, h->attn, x, H, AO, H, nopro, norope, st);
         launch_gemv<1, 1>(GEMV_GU, h, M, L.gu, nullptr, h->hbuf, 2 * F, H, F, GemvPro{x, L.ffn_norm, c.rms_eps, 0}, norope, st);
@@ -2777,8 +2892,9 @@ __global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __
     // rows are (2p, 2p + 1), or (d, d + 32) of one head in the fused QKV matrix (the only matrix that runs the RoPE epilogue)
     const int qp = tid >> 2;
     const long q_nkb = K >> 5;
-    const u32x4* gQ = WF == WF_Q8 ? q8.qs + ((long)(n0 >> 1) + qp) * (K >> 3) + (ks >> 3) + (tid & 3) : nullptr;
+    const u32x4* gQ = (WF == WF_Q8 || WF == WF_Q6K) ? q8.qs + ((long)(n0 >> 1) + qp) * (K >> 3) + (ks >> 3) + (tid & 3) : nullptr;
     const unsigned* gS = WF == WF_Q8 ? q8.sc + q8_sc_index((n0 >> 1) + qp, ks >> 5, q_nkb) : nullptr;   // next k block: + 8
+    const float* gS6 = WF == WF_Q6K ? reinterpret_cast<const float*>(q8.sc) + 2 * q8_sc_index((n0 >> 1) + qp, (ks >> 4) + ((tid & 3) >> 1), K >> 4) : nullptr;   // next stage: + 2 groups of 16
     // Q4_K: a thread's stage is HALF a 16-byte unit = 8 k of two adjacent slots: quad tid / 8, chunk (tid / 2) % 4, slots 2 (tid % 2) + {0, 1}
     const int q4quad = tid >> 3, q4half = tid & 1, q4slot = 4 * ((n0 >> 2) + q4quad) + 2 * q4half;
     const uint2* gQ4 = WF == WF_Q4K ? reinterpret_cast<const uint2*>(q8.qs + ((long)(n0 >> 2) + q4quad) * (K >> 3) + (ks >> 3) + ((tid >> 1) & 3)) + q4half : nullptr;
@@ -2804,6 +2920,10 @@ __global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __
             rw[slot][0] = make_uint4(t.x, t.y, 0u, 0u);
             rs[slot] = *reinterpret_cast<const unsigned*>(gS4 + (long)st * 16);          // (sc | m << 8) of the two slots
             rdd[slot] = *reinterpret_cast<const uint2*>(gD4 + (long)(((ks >> 5) + st) >> 3) * 16);   // (d | dmin << 16) of the two slots
+        } else if (WF == WF_Q6K) {
+            const u32x4 t = gQ[st * 4];
+            rw[slot][0] = make_uint4(t.x, t.y, t.z, t.w);
+            rdd[slot] = *reinterpret_cast<const uint2*>(gS6 + (long)st * 2 * 16);   // (s_a, s_b): two groups of 16 per stage, 8 pairs x 2 floats per group
         } else if (WF == WF_Q8) {
             const u32x4 t = gQ[st * 4];
             rw[slot][0] = make_uint4(t.x, t.y, t.z, t.w);
@@ -2850,12 +2970,12 @@ __global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __
                 *reinterpret_cast<uint4*>(&sm[buf][0][c ? q4soff1 : q4soff0]) = hi;
                 *reinterpret_cast<uint4*>(&sm[buf][3][c ? q4soff1 : q4soff0]) = lo;
             }
-        } else {   // q8_0: .x .y = 8 int8 of the pair's first row, .z .w = of its second row; rs = (fp16 d_a, fp16 d_b)
+        } else {   // q8_0: .x .y = 8 int8 of the pair's first row, .z .w = of its second row; rs = (fp16 d_a, fp16 d_b); Q6_K: rdd = (f32 s_a, f32 s_b)
             const f16x2 d2 = __builtin_bit_cast(f16x2, rs[ws]);
             const unsigned u[4] = {rw[ws][0].x, rw[ws][0].y, rw[ws][0].z, rw[ws][0].w};
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const float dd = (float)d2[c];
+                const float dd = WF == WF_Q6K ? __uint_as_float(c ? rdd[ws].y : rdd[ws].x) : (float)d2[c];
                 float wv[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) wv[j] = dd * (float)(signed char)((u[2 * c + (j >> 2)] >> (8 * (j & 3))) & 0xffu);
@@ -2959,7 +3079,7 @@ __global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __
             // the wave's 64 rows are one head: rows d (tile 0) and d + 32 (tile 1) sit in the same register slot
             const int pos = stt->n_tokens + tok;
             if (pos >= rope.n_ctx) continue;
-            const int head = (n0 + wr * 64) >> 6;
+            const int head = (n0 + wr * 64 + rope.row_base) >> 6;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int d = (r & 3) + 8 * (r >> 2) + 4 * half;   // < 32
@@ -3004,7 +3124,7 @@ __global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __
 // hi/lo split (the 64 rows are 32 interleaved gate/up pairs).
 template <int EPI>
 __global__ __launch_bounds__(256) void lm_gemm128_epilogue_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ part, int nsplit, int N,
-                                                                  float* __restrict__ y, bf16_t* __restrict__ oh, bf16_t* __restrict__ ol,
+                                                                  float* __restrict__ y, int ldy, bf16_t* __restrict__ oh, bf16_t* __restrict__ ol,
                                                                   GemvRope rope) {
     __shared__ float tile[64][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // ty 0..7
@@ -3032,21 +3152,21 @@ __global__ __launch_bounds__(256) void lm_gemm128_epilogue_kernel(const LmDevSta
         const int tok = t0 + tl;
         if (tok >= Mv) continue;
         if (EPI == GEMM_EPI_RESID) {
-            float* yr = y + (long)tok * N + n0;
+            float* yr = y + (long)tok * ldy + n0;
             yr[tx] = yr[tx] + tile[tx][tl];
             yr[tx + 32] = yr[tx + 32] + tile[tx + 32][tl];
         } else if (EPI == GEMM_EPI_ROPE) {
             const int pos = stt->n_tokens + tok;
             if (pos >= rope.n_ctx) continue;
-            const int head = n0 >> 6, d = tx;
+            const int head = (n0 + rope.row_base) >> 6, d = tx;
             const float x1 = tile[d][tl], x2 = tile[d + 32][tl];
             if (head < rope.nh + rope.nkv) {
                 const float c = rope.cos_t[(long)pos * 32 + d], sn = rope.sin_t[(long)pos * 32 + d];
                 const float o1 = x1 * c + (-x2) * sn;
                 const float o2 = x2 * c + x1 * sn;
                 if (head < rope.nh) {
-                    y[(long)tok * N + n0 + d] = o1;
-                    y[(long)tok * N + n0 + d + 32] = o2;
+                    y[(long)tok * ldy + head * 64 + d] = o1;
+                    y[(long)tok * ldy + head * 64 + d + 32] = o2;
                 } else {
                     f16_t* kp = rope.kc + ((long)pos * rope.nkv + (head - rope.nh)) * 64;
                     kp[d] = (f16_t)o1;
@@ -3072,7 +3192,7 @@ __global__ __launch_bounds__(256) void lm_gemm128_epilogue_kernel(const LmDevSta
 static bool lm_all_bf16(const rca_lm* h) {
     for (const LmLayer& L : h->layers)
         for (const WMat* m : {&L.qkv, &L.o, &L.gu, &L.down})
-            if (m->fmt != WF_BF16) return false;
+            if (m->fmt != WF_BF16 || L.split_v) return false;
     return true;
 }
 static bool lm_can_gemm128(const rca_lm* h);
@@ -3086,8 +3206,8 @@ static bool lm_can_mfma_prefill(const rca_lm* h) {
 static int lm_enqueue_prefill_tile(rca_lm* h, int M, hipStream_t st, int nsp_launch) {
     const rca_lm_config_t& c = h->cfg;
     const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim, F = c.ffn;
-    GemvRope rope{h->cos_t, h->sin_t, nullptr, nullptr, c.n_heads, c.n_kv_heads, c.n_ctx};
-    const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    GemvRope rope{h->cos_t, h->sin_t, nullptr, nullptr, c.n_heads, c.n_kv_heads, c.n_ctx, 0};
+    const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
     float* x = h->x;
     lm_embed_kernel<<<M, 256, 0, st>>>(h->stt, h->embed, h->embed_f32, x, H, c.vocab_size);
     for (int l = 0; l < c.n_layers; ++l) {
@@ -3125,6 +3245,8 @@ static bool lm_can_gemm128(const rca_lm* h) {
     const rca_lm_config_t& c = h->cfg;
     const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim, F = c.ffn;
     const int G = c.n_heads / c.n_kv_heads;
+    for (const LmLayer& L : h->layers)   // a V projection kept apart from [q; k] (formats differ): both parts are tiled by 128 rows
+        if (L.split_v && ((L.qkv.N % 128) || (L.vseg.N % 128))) return false;
     return c.head_dim == 64 && (G == 1 || G == 2 || G == 4) && H % 128 == 0 && QKV % 128 == 0 && (2 * F) % 128 == 0 && AO % 32 == 0 && F % 32 == 0;
 }
 // one 128-row GEMM launch in the format the matrix is kept in
@@ -3136,10 +3258,13 @@ static void launch_gemm128(rca_lm* h, const WMat& w, dim3 grid, hipStream_t st, 
         (void)hipFuncSetAttribute((const void*)lm_gemm128_kernel<EPI, WF_Q8>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS_T(4));
         (void)hipFuncSetAttribute((const void*)lm_gemm128_kernel<EPI, WF_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS_T(4));
         (void)hipFuncSetAttribute((const void*)lm_gemm128_kernel<EPI, WF_Q4K>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS_T(4));
+        (void)hipFuncSetAttribute((const void*)lm_gemm128_kernel<EPI, WF_Q6K>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS_T(4));
         attr_done = true;
     }
     const GemvQ8 qa{w.qs, w.sc, w.dd};
-    if (w.fmt == WF_Q4K)
+    if (w.fmt == WF_Q6K)
+        lm_gemm128_kernel<EPI, WF_Q6K><<<grid, 256, G128_LDS_T(4), st>>>(h->stt, w.w, qa, xh, xl, N, K, kslice, y, ldy, oh, ol, h->gpart, rope, nseq);
+    else if (w.fmt == WF_Q4K)
         lm_gemm128_kernel<EPI, WF_Q4K><<<grid, 256, G128_LDS_T(4), st>>>(h->stt, w.w, qa, xh, xl, N, K, kslice, y, ldy, oh, ol, h->gpart, rope, nseq);
     else if (w.fmt == WF_Q8)
         lm_gemm128_kernel<EPI, WF_Q8><<<grid, 256, G128_LDS_T(4), st>>>(h->stt, w.w, qa, xh, xl, N, K, kslice, y, ldy, oh, ol, h->gpart, rope, nseq);
@@ -3151,16 +3276,16 @@ static void launch_gemm128(rca_lm* h, const WMat& w, dim3 grid, hipStream_t st, 
 static int lm_enqueue_prefill_tile128(rca_lm* h, int M, hipStream_t st, int nsp_launch) {
     const rca_lm_config_t& c = h->cfg;
     const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim, F = c.ffn;
-    GemvRope rope{h->cos_t, h->sin_t, nullptr, nullptr, c.n_heads, c.n_kv_heads, c.n_ctx};
-    const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
-    const int sq = g128_splits(QKV, H), so = g128_splits(H, AO), sg = g128_splits(2 * F, H), sd = g128_splits(H, F);
+    GemvRope rope{h->cos_t, h->sin_t, nullptr, nullptr, c.n_heads, c.n_kv_heads, c.n_ctx, 0};
+    const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+    const int so = g128_splits(H, AO), sg = g128_splits(2 * F, H), sd = g128_splits(H, F);
     const int tbz = cdiv(M, 128);   // token blocks of this pass
     // A projection whose token blocks alone put `seq_min` workgroups on the chip is run with every workgroup walking the k slices itself
     // (same sums in the same order, no partial sums through HBM, no epilogue launch); RCA_LM_SEQ_MIN_WGS overrides the threshold
     // (0 = never) for A/B runs.
     static const int seq_min = getenv("RCA_LM_SEQ_MIN_WGS") ? atoi(getenv("RCA_LM_SEQ_MIN_WGS")) : 512;
     auto seq = [&](int N, int ns) { return ns > 1 && seq_min > 0 && (N / 128) * tbz >= seq_min; };
-    const bool q_seq = seq(QKV, sq), o_seq = seq(H, so), gu_seq = seq(2 * F, sg), d_seq = seq(H, sd);
+    const bool o_seq = seq(H, so), gu_seq = seq(2 * F, sg), d_seq = seq(H, sd);
     float* x = h->x;
     lm_embed_kernel<<<M, 256, 0, st>>>(h->stt, h->embed, h->embed_f32, x, H, c.vocab_size);
     for (int l = 0; l < c.n_layers; ++l) {
@@ -3169,11 +3294,18 @@ static int lm_enqueue_prefill_tile128(rca_lm* h, int M, hipStream_t st, int nsp_
         f16_t* vc = h->vc + (long)l * h->kv_layer_stride;
         rope.kc = kc; rope.vc = vc;
         lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.attn_norm, h->xn, H, c.rms_eps, h->xh, h->xl);
-        launch_gemm128<GEMM_EPI_ROPE>(h, L.qkv, dim3(QKV / 128, q_seq ? 1 : sq, tbz), st, h->xh, h->xl, QKV, H, H / sq, h->qkv, QKV, nullptr, nullptr, rope, q_seq ? sq : 1);
-        if (sq > 1 && !q_seq) lm_gemm128_epilogue_kernel<GEMM_EPI_ROPE><<<dim3(QKV / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sq, QKV, h->qkv, nullptr, nullptr, rope);
+        for (int seg = 0; seg < (L.split_v ? 2 : 1); ++seg) {   // [q; k; v] as one matrix, or [q; k] and v when their formats differ
+            const WMat& w = seg ? L.vseg : L.qkv;
+            const int Ns = w.N, ss = g128_splits(Ns, H);
+            const bool s_seq = seq(Ns, ss);
+            rope.row_base = seg ? L.qkv.N : 0;
+            launch_gemm128<GEMM_EPI_ROPE>(h, w, dim3(Ns / 128, s_seq ? 1 : ss, tbz), st, h->xh, h->xl, Ns, H, H / ss, h->qkv, QKV, nullptr, nullptr, rope, s_seq ? ss : 1);
+            if (ss > 1 && !s_seq) lm_gemm128_epilogue_kernel<GEMM_EPI_ROPE><<<dim3(Ns / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, ss, Ns, h->qkv, QKV, nullptr, nullptr, rope);
+        }
+        rope.row_base = 0;
         launch_attention_mfma(h, M, nsp_launch, kc, vc, st, h->xh, h->xl, true);
         launch_gemm128<GEMM_EPI_RESID>(h, L.o, dim3(H / 128, o_seq ? 1 : so, tbz), st, h->xh, h->xl, H, AO, AO / so, x, H, nullptr, nullptr, norope, o_seq ? so : 1);
-        if (so > 1 && !o_seq) lm_gemm128_epilogue_kernel<GEMM_EPI_RESID><<<dim3(H / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, so, H, x, nullptr, nullptr, norope);
+        if (so > 1 && !o_seq) lm_gemm128_epilogue_kernel<GEMM_EPI_RESID><<<dim3(H / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, so, H, x, H, nullptr, nullptr, norope);
         lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.ffn_norm, h->xn, H, c.rms_eps, h->xh, h->xl);
         // SwiGLU epilogue writes the hi/lo split of h straight into the (ffn-wide) split buffers of the down projection:
         // it reads xh/xl [M][H] and writes [M][F] -- distinct regions are needed, so h goes to the second half of hbuf
@@ -3183,10 +3315,10 @@ static int lm_enqueue_prefill_tile128(rca_lm* h, int M, hipStream_t st, int nsp_
             launch_gemm128<GEMM_EPI_SWIGLU>(h, L.gu, dim3(2 * F / 128, 1, tbz), st, h->xh, h->xl, 2 * F, H, H / sg, nullptr, F, hh, hl, norope, sg);
         } else {
             launch_gemm128<GEMM_EPI_SWIGLU>(h, L.gu, dim3(2 * F / 128, sg, tbz), st, h->xh, h->xl, 2 * F, H, H / sg, nullptr, F, hh, hl, norope, 1);
-            if (sg > 1) lm_gemm128_epilogue_kernel<GEMM_EPI_SWIGLU><<<dim3(2 * F / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sg, 2 * F, nullptr, hh, hl, norope);
+            if (sg > 1) lm_gemm128_epilogue_kernel<GEMM_EPI_SWIGLU><<<dim3(2 * F / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sg, 2 * F, nullptr, 0, hh, hl, norope);
         }
         launch_gemm128<GEMM_EPI_RESID>(h, L.down, dim3(H / 128, d_seq ? 1 : sd, tbz), st, hh, hl, H, F, F / sd, x, H, nullptr, nullptr, norope, d_seq ? sd : 1);
-        if (sd > 1 && !d_seq) lm_gemm128_epilogue_kernel<GEMM_EPI_RESID><<<dim3(H / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sd, H, x, nullptr, nullptr, norope);
+        if (sd > 1 && !d_seq) lm_gemm128_epilogue_kernel<GEMM_EPI_RESID><<<dim3(H / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sd, H, x, H, nullptr, nullptr, norope);
     }
     RCA_LAUNCH_CHECK();
     return RCA_OK;
@@ -3270,7 +3402,7 @@ static int lm_eval_impl(rca_lm_t* h, const int32_t* ids, int32_t n, bool wait_la
             if (rc != RCA_OK) return rc;
             if (last) {   // logits of the final token: final norm + head on the register GEMV path
                 const rca_lm_config_t& c = h->cfg;
-                const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+                const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
                 launch_gemv<1, 0>(GEMV_HEAD, h, 1, h->head, nullptr, h->logits, c.vocab_size, c.hidden, c.vocab_size,
                                   GemvPro{h->x, h->final_norm, c.rms_eps, 1}, norope, st);
                 RCA_LAUNCH_CHECK();
@@ -3598,6 +3730,13 @@ __global__ __launch_bounds__(256) void lm_q8_zero_row_scales_kernel(unsigned* __
         *half = 0;
     }
 }
+__global__ __launch_bounds__(256) void lm_q6k_zero_row_scales_kernel(float* __restrict__ sc, int nk16, int row_begin, int row_end) {
+    const long total = (long)(row_end - row_begin) * nk16;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int row = row_begin + (int)(i / nk16), j = (int)(i % nk16);
+        sc[2 * q8_sc_index(row >> 1, j, nk16) + (row & 1)] = 0.0f;
+    }
+}
 __global__ __launch_bounds__(256) void lm_q4k_zero_row_factors_kernel(unsigned* __restrict__ dd, int nk256, int row_begin, int row_end) {
     const long total = (long)(row_end - row_begin) * nk256;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -3614,6 +3753,8 @@ extern "C" int rca_lm_mask_head_rows(rca_lm_t* h, int32_t row_begin, int32_t row
     if (!h || row_begin < 0 || row_end > h->cfg.vocab_size || row_begin > row_end) return fail(RCA_ERR_ARG, "mask_head_rows: bad range");
     RCA_HIP(hipSetDevice(h->device));
     const long n = (long)(row_end - row_begin) * h->cfg.hidden;
+    if (n > 0 && h->head.fmt == WF_Q6K)   // Q6_K (what a Q4_K_M file keeps output.weight in): the row's f32 scales
+        lm_q6k_zero_row_scales_kernel<<<256, 256, 0, h->stream>>>((float*)h->head.sc, h->cfg.hidden / 16, row_begin, row_end);
     if (n > 0 && h->head.fmt == WF_Q4K)   // Q4_K: d = dmin = 0 makes every value of the row (0 * sc) * q - (0 * m) = 0
         lm_q4k_zero_row_factors_kernel<<<256, 256, 0, h->stream>>>(h->head.dd, h->cfg.hidden / 256, row_begin, row_end);
     if (n > 0 && (h->head.fmt == WF_BF16 || h->head.fmt == WF_F16)) lm_zero_rows_kernel<<<2048, 256, 0, h->stream>>>(h->head.w + (long)row_begin * h->cfg.hidden, n);   // zero bits
@@ -3722,13 +3863,14 @@ extern "C" int rca_lm_set_attn_fuse(rca_lm_t* h, int32_t enable) {
     h->fuse_attn = enable != 0;
     return RCA_OK;
 }
-// the format the projection matrices are kept (and streamed) in: 0 bf16, 1 q8_0, 2 f16, 3 q4_k; bytes = weight bytes one decode step reads
+// the format the projection matrices are kept (and streamed) in: 0 bf16, 1 q8_0, 2 f16, 3 q4_k (4 = Q6_K, which only ever appears next to Q4_K
+// tensors); bytes = weight bytes one decode step reads
 extern "C" int rca_lm_weight_format(const rca_lm_t* h, int32_t* fmt, int64_t* bytes_per_step) {
     if (!h || !fmt) return fail(RCA_ERR_ARG, "null");
     *fmt = h->layers.empty() ? h->head.fmt : h->layers[0].gu.fmt;
     if (bytes_per_step) {
         long b = h->head.stream_bytes();
-        for (const LmLayer& L : h->layers) b += L.qkv.stream_bytes() + L.o.stream_bytes() + L.gu.stream_bytes() + L.down.stream_bytes();
+        for (const LmLayer& L : h->layers) b += L.qkv.stream_bytes() + L.o.stream_bytes() + L.gu.stream_bytes() + L.down.stream_bytes() + (L.split_v ? L.vseg.stream_bytes() : 0);
         *bytes_per_step = b;
     }
     return RCA_OK;

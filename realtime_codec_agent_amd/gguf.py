@@ -10,8 +10,9 @@ Supported tensor types: F32 (stored as bf16 on the device), BF16, F16 (2-D tenso
 is the F16 one, realtime_agent_resources.py:12) and Q8_0: the projection matrices and output.weight of a Q8_0 file are handed to
 the library as their raw 34-byte blocks (RCA_Q8_0) and stay packed in HBM, one copy, for decode and prefill; the embedding table is
 de-quantised exactly (f32 rows on the device: llama.cpp's get_rows does the same per looked-up row).  K-quants (Q4_K_M ...) are
-rejected with a clear error -- except Q4_K (the bulk of a Q4_K_M file, prep_test_model.sh:31), whose 144-byte super-blocks are kept
-packed the same way (RCA_Q4_K); the Q6_K tensors llama-quantize mixes into a Q4_K_M file are not built.
+rejected with a clear error -- except the two a Q4_K_M file (prep_test_model.sh:31) is made of: Q4_K (144-byte super-blocks, kept packed,
+RCA_Q4_K) and Q6_K (210-byte super-blocks: output.weight and the attn_v / ffn_down tensors llama-quantize's use_more_bits() picks;
+RCA_Q6_K, re-encoded losslessly on the device as int8 values + one f32 scale per 16).
 
 Two things convert_hf_to_gguf.py does to a Llama checkpoint are undone here:
   * q_proj / k_proj rows are permuted from the rotate-half layout to interleaved pairs (LlamaModel.permute);
@@ -28,7 +29,7 @@ from typing import Any, BinaryIO, Dict, Tuple
 import numpy as np
 
 GGUF_MAGIC = 0x46554747  # "GGUF"
-GGML_F32, GGML_F16, GGML_Q8_0, GGML_Q4_K, GGML_BF16 = 0, 1, 8, 12, 30
+GGML_F32, GGML_F16, GGML_Q8_0, GGML_Q4_K, GGML_Q6_K, GGML_BF16 = 0, 1, 8, 12, 14, 30
 _TYPE_NAMES = {0: "F32", 1: "F16", 2: "Q4_0", 3: "Q4_1", 6: "Q5_0", 7: "Q5_1", 8: "Q8_0", 9: "Q8_1", 10: "Q2_K", 11: "Q3_K",
                12: "Q4_K", 13: "Q5_K", 14: "Q6_K", 15: "Q8_K", 30: "BF16"}
 # metadata value types
@@ -93,7 +94,10 @@ def _dequant(raw: np.ndarray, ttype: int, numel: int) -> np.ndarray:
     if ttype == GGML_Q4_K:
         from ._native import Q4KBlocks
         return Q4KBlocks(raw[: numel // 256 * 144], (numel // 256, 256)).dequantize().reshape(-1)
-    raise GGUFError(f"tensor type {_TYPE_NAMES.get(ttype, ttype)} is not supported (F32, F16, BF16, Q8_0, Q4_K are)")
+    if ttype == GGML_Q6_K:
+        from ._native import Q6KBlocks
+        return Q6KBlocks(raw[: numel // 256 * 210], (numel // 256, 256)).dequantize().reshape(-1)
+    raise GGUFError(f"tensor type {_TYPE_NAMES.get(ttype, ttype)} is not supported (F32, F16, BF16, Q8_0, Q4_K, Q6_K are)")
 
 
 def _nbytes(ttype: int, numel: int) -> int:
@@ -109,8 +113,12 @@ def _nbytes(ttype: int, numel: int) -> int:
         if numel % 256:
             raise GGUFError("Q4_K tensor whose size is not a multiple of 256")
         return numel // 256 * 144
-    raise GGUFError(f"tensor type {_TYPE_NAMES.get(ttype, ttype)} is not supported (F32, F16, BF16, Q8_0, Q4_K are; a Q4_K_M file "
-                    "also holds Q6_K tensors (output.weight, some attn_v / ffn_down), which are not)")
+    if ttype == GGML_Q6_K:
+        if numel % 256:
+            raise GGUFError("Q6_K tensor whose size is not a multiple of 256")
+        return numel // 256 * 210
+    raise GGUFError(f"tensor type {_TYPE_NAMES.get(ttype, ttype)} is not supported (F32, F16, BF16, Q8_0, Q4_K, Q6_K are: the types of the "
+                    "reference's F16 / Q8_0 / Q4_K_M files)")
 
 
 def read_gguf(path: str, keep_q8_0: bool = False) -> Tuple[Dict[str, Any], Dict[str, np.ndarray]]:
@@ -152,6 +160,10 @@ def read_gguf(path: str, keep_q8_0: bool = False) -> Tuple[Dict[str, Any], Dict[
             if keep_q8_0 and ttype == GGML_Q4_K and len(ne) == 2 and ne[0] % 256 == 0:
                 from ._native import Q4KBlocks
                 tensors[name] = Q4KBlocks(raw, tuple(reversed(ne)))
+                continue
+            if keep_q8_0 and ttype == GGML_Q6_K and len(ne) == 2 and ne[0] % 256 == 0:
+                from ._native import Q6KBlocks
+                tensors[name] = Q6KBlocks(raw, tuple(reversed(ne)))
                 continue
             tensors[name] = _dequant(raw, ttype, numel).reshape(tuple(reversed(ne)) if ne else ())
         return meta, tensors

@@ -4,7 +4,7 @@ import struct
 
 import numpy as np
 
-F32, F16, Q8_0, Q4_K, BF16 = 0, 1, 8, 12, 30
+F32, F16, Q8_0, Q4_K, Q6_K, BF16 = 0, 1, 8, 12, 14, 30
 
 
 def _s(b: bytes) -> bytes:
@@ -42,11 +42,32 @@ def quantize(a: np.ndarray, ttype: int) -> bytes:
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from oracle import q4k_ref
         return q4k_ref.pack_blocks(q4k_ref.quantize_q4_k(a.reshape(-1, 256))).tobytes()
+    if ttype == Q6_K:      # 210-byte super-blocks
+        import os, sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from oracle import q4k_ref
+        return q4k_ref.pack_blocks_q6_k(q4k_ref.quantize_q6_k(a.reshape(-1, 256))).tobytes()
     raise ValueError(ttype)
 
 
+def q4_k_m_type(gguf_name: str, n_layers: int) -> int:
+    """The mix llama-quantize writes for LLAMA_FTYPE_MOSTLY_Q4_K_M (llama.cpp llama_tensor_get_type): output.weight Q6_K; attn_v and
+    ffn_down Q6_K in the layers use_more_bits() picks (first and last eighth, every third in between), Q4_K otherwise."""
+    if gguf_name == "output.weight":
+        return Q6_K
+    if ".attn_v." in gguf_name or ".ffn_down." in gguf_name:
+        i = int(gguf_name.split(".")[1])
+        more = i < n_layers // 8 or i >= 7 * n_layers // 8 or (i - n_layers // 8) % 3 == 2
+        return Q6_K if more else Q4_K
+    return Q4_K
+
+
 def write_llama_gguf(path, cfg, weights, matrix_type=F32, tokens=None, rope_freqs=None):
-    """cfg: LMConfig; weights: HF-named float32 arrays.  Matrices get `matrix_type`, norms stay F32 (as llama.cpp does)."""
+    """cfg: LMConfig; weights: HF-named float32 arrays.  Matrices get `matrix_type` (or, for matrix_type="Q4_K_M", llama-quantize's
+    Q4_K / Q6_K mix), norms stay F32 (as llama.cpp does)."""
+    mix = matrix_type == "Q4_K_M"
+    if mix:
+        matrix_type = Q4_K
     kv = []
     kv.append(_kv("general.architecture", 8, _s(b"llama")))
     kv.append(_kv("general.alignment", 4, struct.pack("<I", 32)))
@@ -73,6 +94,8 @@ def write_llama_gguf(path, cfg, weights, matrix_type=F32, tokens=None, rope_freq
             elif gg == "attn_k":
                 a = permute(a, cfg.n_kv_heads)
             ts.append((f"blk.{l}.{gg}.weight", a, F32 if a.ndim == 1 else matrix_type))
+    if mix:
+        ts = [(name, a, tt if (tt == F32 or a.ndim == 1) else q4_k_m_type(name, cfg.n_layers)) for name, a, tt in ts]
     infos, blobs, off = [], [], 0
     for name, a, tt in ts:
         data = quantize(a, tt)

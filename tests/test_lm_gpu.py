@@ -578,6 +578,50 @@ def test_q4_k_gguf_blocks_stay_packed_and_match_their_dequantisation(tmp_path):
         assert d < (2e-3 if mfma else 1e-3) * max(1.0, np.abs(want).max()) and g._scores[-1].argmax() == want.argmax()
 
 
+def test_q4_k_m_gguf_mix_of_q4_k_and_q6_k_loads_and_matches_its_dequantisation(tmp_path):
+    """The reference's third model file is `llama-quantize ... Q4_K_M` (prep_test_model.sh:31): a MIX -- output.weight and the attn_v /
+    ffn_down tensors of the layers use_more_bits() picks are Q6_K (210-byte super-blocks), everything else Q4_K.  Such a file loads as
+    it is: Q6_K tensors are re-encoded losslessly on the device (int8 values + f32 scale per 16, streamed by the q8_0 GEMV body), a
+    layer whose attn_v differs in format from attn_q / attn_k runs its V projection as a matrix of its own (row base in the RoPE /
+    KV-write epilogue).  Logits equal LMRef over the file's own blocks de-quantised by llama.cpp's rules, decode and prefill tiles;
+    masked Q6_K head rows read exactly zero."""
+    import gguf_writer as gw
+    from realtime_codec_agent_amd._native import Q4KBlocks, Q6KBlocks
+    from realtime_codec_agent_amd.gguf import load_llama_gguf
+    from realtime_codec_agent_amd.llm import LlamaForAlternatingCodeChannels, LMConfig, bf16_bits_to_f32
+    cfg = LMConfig(vocab_size=1024, hidden=256, n_layers=8, n_heads=4, n_kv_heads=2, head_dim=64, ffn=512, rope_scaling=None, rope_theta=10000.0)
+    w = lm_ref.random_weights(cfg, 5, 0.05)
+    wf = {k: (bf16_bits_to_f32(v) if v.dtype == np.uint16 else v.astype(np.float32)) for k, v in w.items()}
+    path = str(tmp_path / "small-q4_k_m.gguf")
+    gw.write_llama_gguf(path, cfg, wf, matrix_type="Q4_K_M")
+    _, file_w, _ = load_llama_gguf(path)
+    kinds = {k: type(v).__name__ for k, v in file_w.items()}
+    assert kinds["lm_head.weight"] == "Q6KBlocks" and kinds["model.layers.0.self_attn.v_proj.weight"] == "Q6KBlocks"
+    assert kinds["model.layers.1.self_attn.v_proj.weight"] == "Q4KBlocks" and kinds["model.layers.0.self_attn.q_proj.weight"] == "Q4KBlocks"
+    assert sum(v == "Q6KBlocks" for v in kinds.values()) >= 1 + 2 * 3        # head + attn_v / ffn_down of at least three layers
+    g = LlamaForAlternatingCodeChannels(model_path=path, n_ctx=512, device=0)
+    assert g.weight_format == "q4_k"
+    deq = {k: (v.dequantize() if hasattr(v, "dequantize") else v) for k, v in file_w.items() if k != "rope.inv_freq"}
+    ref = lm_ref.LMRef(cfg, deq, kv_dtype=torch.float16)
+    ids = np.random.default_rng(1).integers(0, 1024, 40)
+    for mfma in (False, True):
+        g.set_mfma_prefill(mfma)
+        g.reset(); ref.reset()
+        g.eval(ids.tolist())
+        want = ref.eval(ids)[-1].numpy()
+        d = np.abs(g._scores[-1] - want).max()
+        print(f"Q4_K_M GGUF (mfma_prefill={mfma}) vs LMRef over the file's blocks: max|dlogit| = {d:.3e} (|logit| max {np.abs(want).max():.2f})")
+        assert d < (2e-3 if mfma else 1e-3) * max(1.0, np.abs(want).max()) and g._scores[-1].argmax() == want.argmax()
+    g.init_sampler_for_generate(top_k=50, top_p=1.0, min_p=0.0, temp=0.0, seed=1)
+    g.n_tokens = 38
+    assert g.step(ids[38:40].tolist()) == int(np.argmax(want))                 # graph step over the split V projection
+    got = g._scores[-1].copy()
+    g.mask_head_rows(0, 64)
+    g.n_tokens = 38
+    g.eval(ids[38:40].tolist())
+    assert np.all(g._scores[-1][:64] == 0) and np.array_equal(g._scores[-1][64:], got[64:])
+
+
 def test_full_size_1b_properties():
     """BASELINE config 3 dims (Llama-3.2-1B, V=259344) with random-init weights: checks that do not
     need a CPU forward -- graph replay == eager, prefill == incremental, rollback, determinism."""
