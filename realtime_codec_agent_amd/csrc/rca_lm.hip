@@ -870,15 +870,6 @@ __global__ __launch_bounds__(256) void lm_gemm_mfma_kernel(const LmDevState* __r
 
 // advance the device-side KV position after a pass
 __global__ void lm_advance_kernel(LmDevState* stt) { stt->n_tokens += stt->m; }
-// between two steps of a frame graph: the pair just evaluated is in the cache, the next pair is [agent token just sampled,
-// user's token of this frame] (realtime_agent_v2.py:355-363)
-__global__ void lm_frame_next_kernel(LmDevState* stt, int i) {
-    const int tok = stt->out_token;
-    stt->frame_out[i] = tok;
-    stt->n_tokens += 2;
-    stt->ids[0] = tok;
-    stt->ids[1] = stt->ids[LM_FRAME_USER0 + i];
-}
 // steady-state step: next pass's first id is the token just sampled (realtime_agent_v2.py:355-363)
 __global__ void lm_copy_logits_row_kernel(const float* __restrict__ src, float* __restrict__ dst, int V) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) dst[i] = src[i];
@@ -996,8 +987,20 @@ __global__ __launch_bounds__(256) void samp_gather_kernel(const float* __restric
     }
 }
 
+// Inside a frame graph samp_final_kernel's tail also does what a one-thread "next pair" launch and the next step's embedding launch
+// did: record the token, advance the position, make [token, user id of this frame] the next pair and gather their embedding rows
+// into x (two launches less per step of a frame).  (One launch for the WHOLE sampler -- histogram, last-arriver gather + selection --
+// was built and measured: the single workgroup that then scans the 1 MB of logits for candidates is bound by one CU's memory pipe,
+// 0.917 -> 0.996 ms per step: profiles/r03/experiments/one_launch_sampler.txt.)
+struct SampTail {
+    int frame_i;          // >= 0: step i of a frame graph (advance + next pair + embedding); -1: plain sample
+    const void* table;    // embedding table
+    int f32tab;
+    float* x;
+    int H;
+};
 __global__ __launch_bounds__(1024) void samp_final_kernel(const float* __restrict__ logits, int V, const SamplerDev* __restrict__ sp,
-                                                          LmDevState* __restrict__ stt, SampWork* __restrict__ w) {
+                                                          LmDevState* __restrict__ stt, SampWork* __restrict__ w, SampTail tail) {
     __shared__ unsigned hist[256];
     __shared__ unsigned long long sel_prefix;
     __shared__ int sel_shift;      // bits already fixed (from the top)
@@ -1015,6 +1018,7 @@ __global__ __launch_bounds__(1024) void samp_final_kernel(const float* __restric
     };
     __shared__ unsigned long long ck[SAMP_FAST_CAP];
     __shared__ float e_plain[SAMP_MAXK], e_temp[SAMP_MAXK];
+    __shared__ int s_tok;
     int n;
     if (!full && NN <= SAMP_FAST_CAP) {
         // the usual case, a few hundred candidates: every thread ranks its own key by counting the larger ones
@@ -1132,13 +1136,31 @@ __global__ __launch_bounds__(1024) void samp_final_kernel(const float* __restric
                 if (cum > target) { pick = i; break; }
             }
         }
+        const int tok = (int)(0xFFFFFFFFu - (unsigned)(cand[pick] & 0xFFFFFFFFull));
         stt->rng_counter += 1ull;
-        stt->out_token = (int)(0xFFFFFFFFu - (unsigned)(cand[pick] & 0xFFFFFFFFull));
+        stt->out_token = tok;
+        if (tail.frame_i >= 0) {   // the pair just evaluated is in the cache; the next pair is [token just sampled, user's token of this frame]
+            stt->frame_out[tail.frame_i] = tok;
+            stt->n_tokens += 2;
+            stt->ids[0] = tok;
+            stt->ids[1] = stt->ids[LM_FRAME_USER0 + tail.frame_i];
+        }
+        s_tok = tok;
     }
     // re-arm the shared work area for the next call
     __syncthreads();
     for (int b = tid; b < SAMP_BINS; b += 1024) w->hist[b] = 0u;
     if (tid == 0) { w->ncand = 0u; w->overflow = 0u; }
+    if (tail.frame_i >= 0) {   // lm_embed_kernel for the next pair (m = 2)
+        const int id1 = stt->ids[LM_FRAME_USER0 + tail.frame_i];
+        for (int e = tid; e < 2 * tail.H; e += 1024) {
+            const int m = e / tail.H, hh = e - m * tail.H;
+            int id = m == 0 ? s_tok : id1;
+            id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+            tail.x[e] = tail.f32tab ? reinterpret_cast<const float*>(tail.table)[(long)id * tail.H + hh]
+                                    : __uint_as_float((unsigned)reinterpret_cast<const bf16_t*>(tail.table)[(long)id * tail.H + hh] << 16);
+        }
+    }
 }
 
 // probs[i] = softmax(logits)[ids[i]] : one workgroup, two sweeps (max, sum)
@@ -2789,7 +2811,7 @@ static int lm_splits_needed(const rca_lm* h, int m) { return std::min(h->n_split
 // want_logits: 0 none, 1 last token only, 2 every token (logits_all).
 // Per layer: [norm+QKV+RoPE/KV-write] -> [split attention] -> [combine] -> [O proj + residual] -> [norm+gate/up+SwiGLU] -> [down + residual]
 // nsp_launch: attention split blocks to launch (>= ceil((n_tokens + M) / ATT_KEYS); later splits exit at once).
-static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st, int nsp_launch) {
+static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st, int nsp_launch, bool skip_embed = false) {
     const rca_lm_config_t& c = h->cfg;
     const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim, F = c.ffn;
     if (M < 1 || M > LM_GEMV_M) return fail(RCA_ERR_ARG, "decode pass of %d tokens", M);
@@ -2797,7 +2819,7 @@ static int lm_enqueue_pass(rca_lm* h, int M, int want_logits, hipStream_t st, in
     GemvRope rope{h->cos_t, h->sin_t, nullptr, nullptr, c.n_heads, c.n_kv_heads, c.n_ctx, 0};
     const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
     float* x = h->x;
-    lm_embed_kernel<<<M, 256, 0, st>>>(h->stt, h->embed, h->embed_f32, x, H, c.vocab_size);
+    if (!skip_embed) lm_embed_kernel<<<M, 256, 0, st>>>(h->stt, h->embed, h->embed_f32, x, H, c.vocab_size);   // (inside a frame graph the previous step's sampler has gathered the rows)
     for (int l = 0; l < c.n_layers; ++l) {
         const LmLayer& L = h->layers[l];
         f16_t* kc = h->kc + (long)l * h->kv_layer_stride;
@@ -3529,11 +3551,13 @@ extern "C" int rca_lm_sampler_init(rca_lm_t* h, const rca_sampler_params_t* p) {
     return RCA_OK;
 }
 
-static void lm_enqueue_sample(rca_lm* h, const float* lg, hipStream_t st) {
+// frame_i >= 0: step i of a frame graph -- the sampler's tail also advances the device state and gathers the next pair's embeddings
+static void lm_enqueue_sample(rca_lm* h, const float* lg, hipStream_t st, int frame_i = -1) {
     const int V = h->cfg.vocab_size;
+    const SampTail tail{frame_i, h->embed, h->embed_f32, h->x, h->cfg.hidden};
     samp_hist_kernel<<<128, 256, 0, st>>>(lg, V, h->samp, h->swork);
     samp_gather_kernel<<<128, 256, 0, st>>>(lg, V, h->samp, h->swork);
-    samp_final_kernel<<<1, 1024, 0, st>>>(lg, V, h->samp, h->stt, h->swork);
+    samp_final_kernel<<<1, 1024, 0, st>>>(lg, V, h->samp, h->stt, h->swork, tail);
 }
 
 static int lm_fetch_token(rca_lm* h, int32_t* token, hipStream_t st) {
@@ -3648,10 +3672,9 @@ extern "C" int rca_lm_frame(rca_lm_t* h, const int32_t* first_pair, const int32_
         hipError_t e = hipMemcpyAsync(h->stt, h->h_stt, LM_STATE_DECODE_BYTES, hipMemcpyHostToDevice, st);
         if (e != hipSuccess) rc = fail(RCA_ERR_HIP, "frame memcpy: %s", hipGetErrorString(e));
         for (int i = 0; i < n_steps && rc == RCA_OK; ++i) {
-            rc = lm_enqueue_pass(h, 2, 1, st, nsp_launch);
+            rc = lm_enqueue_pass(h, 2, 1, st, nsp_launch, i > 0);
             if (rc != RCA_OK) break;
-            lm_enqueue_sample(h, h->logits, st);
-            lm_frame_next_kernel<<<1, 1, 0, st>>>(h->stt, i);
+            lm_enqueue_sample(h, h->logits, st, i);
         }
         if (rc == RCA_OK) {
             e = hipMemcpyAsync(h->h_stt->frame_out, h->stt->frame_out, sizeof(int) * LM_FRAME_MAX, hipMemcpyDeviceToHost, st);
