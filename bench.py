@@ -85,6 +85,38 @@ def cpu_baseline_lm_step(cfg, ctx_tokens=64, steps=3):
                        f"context {ctx_tokens}+ tokens; weights regenerated from the device hash in {gen_s:.1f} s")
 
 
+def batch_cli_leg(hours=0.5, seed=0):
+    """The SAME encode through the batch CLI (`audio_to_codes`, the drop-in for codec_bpe.audio_to_codes in encode_audio_gpu_*.sh) on
+    a synthetic corpus of 10-60 s stereo .wav utterances written to a temporary directory: file reading, cross-file window batching,
+    H2D, encode, D2H and .npy writing included -- the deployment-level number next to the kernel-level `value`."""
+    import shutil
+    import tempfile
+    import wave
+    from realtime_codec_agent_amd import audio_to_codes
+    rng = np.random.default_rng(seed)
+    root = tempfile.mkdtemp(prefix="rca_bench_corpus_")
+    try:
+        raw = os.path.join(root, "raw")
+        total, i = 0.0, 0
+        while total < hours * 3600:
+            secs = float(rng.uniform(10, 60))
+            n = int(secs * 16000)
+            t = np.arange(n) / 16000.0
+            sig = np.stack([0.1 * np.sin(2 * np.pi * f * t) + rng.normal(0, 0.02, n) for f in (220.0 + i, 330.0 + i)])
+            d = os.path.join(raw, f"spk{i % 7:02d}")
+            os.makedirs(d, exist_ok=True)
+            with wave.open(os.path.join(d, f"utt{i:04d}.wav"), "wb") as w:
+                w.setnchannels(2); w.setsampwidth(2); w.setframerate(16000)
+                w.writeframes((np.clip(sig.T, -1, 1) * 32767).astype("<i2").tobytes())
+            total += secs
+            i += 1
+        s = audio_to_codes.main(["--audio_path", raw, "--codes_path", os.path.join(root, "codes"), "--stereo"])
+        return dict(value=s["audio_hours_per_hour"], unit="audio-hours/hour", files=i, audio_hours=total / 3600.0, elapsed_s=s["elapsed_s"],
+                    note="audio_to_codes CLI end to end (read .wav, batch windows across files, encode, write .npy), one process")
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def latest_profile_traffic():
     """HBM bytes per launch of the dominant kernel from the newest committed PMC passes (profiles/rNN/traffic.json, written by
     scripts/collect_profiles.py from separate rocprofv3 --pmc runs: FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE).  None when
@@ -133,6 +165,7 @@ def main():
     ap.add_argument("--context-secs", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-duplex", action="store_true")
+    ap.add_argument("--no-cli-leg", action="store_true", help="skip the batch-CLI leg (audio_to_codes on a synthetic corpus of short files)")
     ap.add_argument("--no-trim-leg", action="store_true", help="skip the receptive-field-trimmed batch leg (profiling runs: keeps per-kernel averages to the headline path)")
     ap.add_argument("--duplex-secs", type=float, default=125.0,
                     help="audio seconds of the duplex leg; >= 110 puts two sliding-window trims (80 s context, trim by 20 s) inside the timed window")
@@ -308,6 +341,8 @@ def main():
                     "frac": conv["bytes"] / (conv["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if conv["ms"] > 0 else None},
         },
     }
+    if rank == 0 and world == 1 and not args.no_cli_leg:
+        out["config"]["batch_cli"] = batch_cli_leg()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_encode(cfg, weights, chunk, ctx, 64, C)
         if not args.no_duplex:

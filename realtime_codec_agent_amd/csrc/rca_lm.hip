@@ -2339,6 +2339,15 @@ __device__ __forceinline__ float attn_merge_row(const float* __restrict__ base, 
 // part[((qblock * nkv + g) * n_splits + split) * 32 + row][66] = {m, l, o[64]}, row = token_in_block * G + q_head.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+// Diagnostic build only (-DRCA_ATTN_TIMELINE, scripts/attn_timeline.py): thread 0 of every decode-attention workgroup stamps its phases
+// with the 100 MHz wall clock into a buffer no other code reads.
+#ifdef RCA_ATTN_TIMELINE
+__device__ long* rca_attn_tl = nullptr;
+#define ATL_STAMP(k) do { if (atl && threadIdx.x == 0) atl[k] = (long)wall_clock64(); } while (0)
+#else
+#define ATL_STAMP(k)
+#endif
+
 #define ATTM_VT_PITCH 40     // fp16 per transposed-V row (32 keys + pad): 8-byte fragment reads stay aligned
 #define ATTM_LDS (8 * 32 * 64 * 4 + 2 * 8 * 32 * 4)   // wo (aliases vt) + wm + wl
 template <int G>
@@ -2353,6 +2362,10 @@ __global__ __launch_bounds__(512) void lm_attn_mfma_kernel(const LmDevState* __r
     // handed-off byte stored sc1, vmcnt(0) in every storing wave, workgroup barrier, ONE lane's agent-scope add; the last adder's
     // waves load behind a barrier that lane joins; every load sc1).  Saves the combine launch (1.7 us dispatch + its round trip).
     const bool fused = arrive != nullptr;
+#ifdef RCA_ATTN_TIMELINE
+    long* const atl = (rca_attn_tl && fused) ? rca_attn_tl + ((long)(blockIdx.y * gridDim.x + blockIdx.x) & 1023) * 8 : nullptr;
+#endif
+    ATL_STAMP(0);
     auto part_store = [&](float* p, float v) {
         if (fused) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else *p = v;
@@ -2361,11 +2374,13 @@ __global__ __launch_bounds__(512) void lm_attn_mfma_kernel(const LmDevState* __r
     auto arrive_and_merge = [&](int M_) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial stores have left the CU
         __syncthreads();
+        ATL_STAMP(4);
         if (threadIdx.x == 0) {
             const int old = __hip_atomic_fetch_add(arrive + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = old == (int)gridDim.y - 1;
         }
         __syncthreads();
+        ATL_STAMP(5);
         if (!s_last) return;
         const int w = threadIdx.x >> 6, d = threadIdx.x & 63;       // wave <-> row (token_in_block * G + q head), lane <-> dim
         if (w < M_ * G) {
@@ -2374,6 +2389,8 @@ __global__ __launch_bounds__(512) void lm_attn_mfma_kernel(const LmDevState* __r
             attn_out[(long)m * nh * 64 + head * 64 + d] = attn_merge_row<true>(base, (int)gridDim.y, d);
         }
         if (threadIdx.x == 0) __hip_atomic_store(arrive + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+        __syncthreads();
+        ATL_STAMP(6);
     };
     constexpr int HD = 64;
     constexpr int TPB = 32 / G;   // tokens per query block
@@ -2429,6 +2446,7 @@ __global__ __launch_bounds__(512) void lm_attn_mfma_kernel(const LmDevState* __r
 #pragma unroll
         for (int j = 0; j < 8; ++j) vt[wave][8 * half + 16 * sub + j][col] = v8[j];
     }
+    ATL_STAMP(1);   // V of this wave is in registers (its transposed copy requested)
     // ---- S^T = K Q^T (hi + lo)
     f32x16 sacc;
 #pragma unroll
@@ -2513,6 +2531,7 @@ __global__ __launch_bounds__(512) void lm_attn_mfma_kernel(const LmDevState* __r
             oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl[i], vb, oacc[nt], 0, 0, 0);
         }
     }
+    ATL_STAMP(2);      // S, softmax, P V of this wave
     __syncthreads();   // every wave is done with vt: wo may overwrite it
     if (half == 0) { wm[wave][col] = mx; wl[wave][col] = lsum; }
 #pragma unroll
@@ -2537,8 +2556,21 @@ __global__ __launch_bounds__(512) void lm_attn_mfma_kernel(const LmDevState* __r
         part_store(pout + r * 66 + 2 + d, O);
         if (d == 0) { part_store(pout + r * 66, m2); part_store(pout + r * 66 + 1, L); }
     }
+    ATL_STAMP(3);      // 8 waves merged, partial stores issued
     if (fused) arrive_and_merge(M);
 }
+#ifdef RCA_ATTN_TIMELINE
+extern "C" int rca_debug_attn_timeline(long* out_host, int enable) {   // enable: allocate + arm; else copy the 1024 x 8 stamps out
+    static long* buf = nullptr;
+    if (enable) {
+        if (!buf) { if (hipMalloc((void**)&buf, 1024 * 8 * sizeof(long)) != hipSuccess) return 1; }
+        (void)hipMemset(buf, 0, 1024 * 8 * sizeof(long));
+        return hipMemcpyToSymbol(HIP_SYMBOL(rca_attn_tl), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+    }
+    (void)hipDeviceSynchronize();
+    return buf && hipMemcpy(out_host, buf, 1024 * 8 * sizeof(long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#endif
 // merges the splits of lm_attn_mfma_kernel as its own launch (prefill tiles, and decode steps whose grid exceeds one workgroup per
 // CU): one wave per (token, head)
 template <int G>
