@@ -3177,7 +3177,7 @@ __global__ __launch_bounds__(256, 2) void lm_gemm128_kernel(const LmDevState* __
 // fused epilogue with row-contiguous writes -- residual add, RoPE + KV write (the 64 rows are one head), or SwiGLU +
 // hi/lo split (the 64 rows are 32 interleaved gate/up pairs).
 template <int EPI>
-__global__ __launch_bounds__(256) void lm_gemm128_epilogue_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ part, int nsplit, int N,
+__global__ __launch_bounds__(256) void lm_gemm128_epilogue_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ part, int nsplit, int grp, int N,
                                                                   float* __restrict__ y, int ldy, bf16_t* __restrict__ oh, bf16_t* __restrict__ ol,
                                                                   GemvRope rope) {
     __shared__ float tile[64][33];
@@ -3190,11 +3190,21 @@ __global__ __launch_bounds__(256) void lm_gemm128_epilogue_kernel(const LmDevSta
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) v[rr] = 0.0f;
         const float* p0 = part + ((long)n0 + ty) * LM_MAXM + t0 + tx;
-#pragma unroll 4
-        for (int s = 0; s < nsplit; ++s) {   // eight independent row sums per thread: eight loads in flight per split
-            const float* ps = p0 + (long)s * N * LM_MAXM;
+        // The sum over the k slices is DEFINED in two levels: groups of `grp` consecutive slices are folded first (each from 0), the
+        // group sums are folded in group order (from 0).  A pass stores either every slice (grp > 1 here) or the group sums its
+        // workgroups folded themselves while walking `grp` slices (grp == 1 here: 0 + G == G) -- the same additions either way.
+        for (int s0 = 0; s0 < nsplit; s0 += grp) {
+            float g[8];
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr) v[rr] += ps[(long)rr * 8 * LM_MAXM];
+            for (int rr = 0; rr < 8; ++rr) g[rr] = 0.0f;
+#pragma unroll 4
+            for (int s = s0; s < s0 + grp; ++s) {   // eight independent row sums per thread: eight loads in flight per slice
+                const float* ps = p0 + (long)s * N * LM_MAXM;
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) g[rr] += ps[(long)rr * 8 * LM_MAXM];
+            }
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) v[rr] += g[rr];
         }
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) tile[rr * 8 + ty][tx] = v[rr];
@@ -3295,6 +3305,19 @@ static int g128_splits(int N, int K) {
     while (ns * (N / 128) < 512 && K % (ns * 2 * 32) == 0 && K / (ns * 2) >= 256) ns *= 2;
     return ns;
 }
+// Two-level definition of the sum over the ns slices (lm_gemm128_epilogue_kernel): at most four groups, folded first.  A function of the
+// matrix only, like ns.  It lets a LONG pass store four group sums per output instead of ns partial sums (the narrow projections wrote
+// and re-read 0.9 GB of partials per layer and 1024-token pass: down had 32 slices) without changing a bit of what a short pass
+// computes from all ns.
+static int g128_group(int ns) { return ns / std::min(ns, 4); }
+struct G128Form { int grid_y, nseq, ep_nsplit, ep_grp; };   // ep_nsplit == 0: the kernel's own (fused) epilogue
+static G128Form g128_form(int N, int ns, int tbz, int seq_min) {
+    const int grp = g128_group(ns), ng = ns / grp;
+    if (ns == 1) return {1, 1, 0, 1};
+    if (grp == 1 && seq_min > 0 && (N / 128) * tbz >= seq_min) return {1, ns, 0, 1};            // every workgroup walks all slices (gate/up)
+    if (grp > 1 && seq_min > 0 && (N / 128) * tbz * ng >= seq_min) return {ng, grp, ng, 1};     // workgroups walk a group, group sums stored
+    return {ns, 1, ns, grp};                                                                     // every slice stored
+}
 static bool lm_can_gemm128(const rca_lm* h) {
     const rca_lm_config_t& c = h->cfg;
     const int H = c.hidden, QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, AO = c.n_heads * c.head_dim, F = c.ffn;
@@ -3338,8 +3361,7 @@ static int lm_enqueue_prefill_tile128(rca_lm* h, int M, hipStream_t st, int nsp_
     // (same sums in the same order, no partial sums through HBM, no epilogue launch); RCA_LM_SEQ_MIN_WGS overrides the threshold
     // (0 = never) for A/B runs.
     static const int seq_min = getenv("RCA_LM_SEQ_MIN_WGS") ? atoi(getenv("RCA_LM_SEQ_MIN_WGS")) : 512;
-    auto seq = [&](int N, int ns) { return ns > 1 && seq_min > 0 && (N / 128) * tbz >= seq_min; };
-    const bool o_seq = seq(H, so), gu_seq = seq(2 * F, sg), d_seq = seq(H, sd);
+    const G128Form fo = g128_form(H, so, tbz, seq_min), fg = g128_form(2 * F, sg, tbz, seq_min), fd = g128_form(H, sd, tbz, seq_min);
     float* x = h->x;
     lm_embed_kernel<<<M, 256, 0, st>>>(h->stt, h->embed, h->embed_f32, x, H, c.vocab_size);
     for (int l = 0; l < c.n_layers; ++l) {
@@ -3351,28 +3373,24 @@ static int lm_enqueue_prefill_tile128(rca_lm* h, int M, hipStream_t st, int nsp_
         for (int seg = 0; seg < (L.split_v ? 2 : 1); ++seg) {   // [q; k; v] as one matrix, or [q; k] and v when their formats differ
             const WMat& w = seg ? L.vseg : L.qkv;
             const int Ns = w.N, ss = g128_splits(Ns, H);
-            const bool s_seq = seq(Ns, ss);
+            const G128Form fq = g128_form(Ns, ss, tbz, seq_min);
             rope.row_base = seg ? L.qkv.N : 0;
-            launch_gemm128<GEMM_EPI_ROPE>(h, w, dim3(Ns / 128, s_seq ? 1 : ss, tbz), st, h->xh, h->xl, Ns, H, H / ss, h->qkv, QKV, nullptr, nullptr, rope, s_seq ? ss : 1);
-            if (ss > 1 && !s_seq) lm_gemm128_epilogue_kernel<GEMM_EPI_ROPE><<<dim3(Ns / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, ss, Ns, h->qkv, QKV, nullptr, nullptr, rope);
+            launch_gemm128<GEMM_EPI_ROPE>(h, w, dim3(Ns / 128, fq.grid_y, tbz), st, h->xh, h->xl, Ns, H, H / ss, h->qkv, QKV, nullptr, nullptr, rope, fq.nseq);
+            if (fq.ep_nsplit) lm_gemm128_epilogue_kernel<GEMM_EPI_ROPE><<<dim3(Ns / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, fq.ep_nsplit, fq.ep_grp, Ns, h->qkv, QKV, nullptr, nullptr, rope);
         }
         rope.row_base = 0;
         launch_attention_mfma(h, M, nsp_launch, kc, vc, st, h->xh, h->xl, true);
-        launch_gemm128<GEMM_EPI_RESID>(h, L.o, dim3(H / 128, o_seq ? 1 : so, tbz), st, h->xh, h->xl, H, AO, AO / so, x, H, nullptr, nullptr, norope, o_seq ? so : 1);
-        if (so > 1 && !o_seq) lm_gemm128_epilogue_kernel<GEMM_EPI_RESID><<<dim3(H / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, so, H, x, H, nullptr, nullptr, norope);
+        launch_gemm128<GEMM_EPI_RESID>(h, L.o, dim3(H / 128, fo.grid_y, tbz), st, h->xh, h->xl, H, AO, AO / so, x, H, nullptr, nullptr, norope, fo.nseq);
+        if (fo.ep_nsplit) lm_gemm128_epilogue_kernel<GEMM_EPI_RESID><<<dim3(H / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, fo.ep_nsplit, fo.ep_grp, H, x, H, nullptr, nullptr, norope);
         lm_add_rmsnorm_kernel<<<M, 64, 0, st>>>(h->stt, x, nullptr, nullptr, 0, 0, L.ffn_norm, h->xn, H, c.rms_eps, h->xh, h->xl);
         // SwiGLU epilogue writes the hi/lo split of h straight into the (ffn-wide) split buffers of the down projection:
         // it reads xh/xl [M][H] and writes [M][F] -- distinct regions are needed, so h goes to the second half of hbuf
         bf16_t* hh = reinterpret_cast<bf16_t*>(h->hbuf);
         bf16_t* hl = hh + (long)LM_MAXM * F;
-        if (gu_seq) {   // the token blocks alone fill the chip: every workgroup walks the slices itself (same sums, same order, no partials)
-            launch_gemm128<GEMM_EPI_SWIGLU>(h, L.gu, dim3(2 * F / 128, 1, tbz), st, h->xh, h->xl, 2 * F, H, H / sg, nullptr, F, hh, hl, norope, sg);
-        } else {
-            launch_gemm128<GEMM_EPI_SWIGLU>(h, L.gu, dim3(2 * F / 128, sg, tbz), st, h->xh, h->xl, 2 * F, H, H / sg, nullptr, F, hh, hl, norope, 1);
-            if (sg > 1) lm_gemm128_epilogue_kernel<GEMM_EPI_SWIGLU><<<dim3(2 * F / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sg, 2 * F, nullptr, 0, hh, hl, norope);
-        }
-        launch_gemm128<GEMM_EPI_RESID>(h, L.down, dim3(H / 128, d_seq ? 1 : sd, tbz), st, hh, hl, H, F, F / sd, x, H, nullptr, nullptr, norope, d_seq ? sd : 1);
-        if (sd > 1 && !d_seq) lm_gemm128_epilogue_kernel<GEMM_EPI_RESID><<<dim3(H / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, sd, H, x, H, nullptr, nullptr, norope);
+        launch_gemm128<GEMM_EPI_SWIGLU>(h, L.gu, dim3(2 * F / 128, fg.grid_y, tbz), st, h->xh, h->xl, 2 * F, H, H / sg, nullptr, F, hh, hl, norope, fg.nseq);
+        if (fg.ep_nsplit) lm_gemm128_epilogue_kernel<GEMM_EPI_SWIGLU><<<dim3(2 * F / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, fg.ep_nsplit, fg.ep_grp, 2 * F, nullptr, 0, hh, hl, norope);
+        launch_gemm128<GEMM_EPI_RESID>(h, L.down, dim3(H / 128, fd.grid_y, tbz), st, hh, hl, H, F, F / sd, x, H, nullptr, nullptr, norope, fd.nseq);
+        if (fd.ep_nsplit) lm_gemm128_epilogue_kernel<GEMM_EPI_RESID><<<dim3(H / 64, cdiv(M, 32)), 256, 0, st>>>(h->stt, h->gpart, fd.ep_nsplit, fd.ep_grp, H, x, H, nullptr, nullptr, norope);
     }
     RCA_LAUNCH_CHECK();
     return RCA_OK;
