@@ -1494,6 +1494,7 @@ struct LmLayer {
 };
 
 struct rca_lm {
+    int n_cus = 256;            // compute units of the device (grid shapes that want one workgroup per CU)
     rca_lm_config_t cfg;
     int device = 0;
     hipStream_t stream = nullptr;
@@ -2041,6 +2042,7 @@ static int lm_new(const rca_lm_config_t* cfg, int device, rca_lm** out) {
     rca_lm* h = new rca_lm();
     h->cfg = *cfg;
     h->device = device;
+    if (hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || h->n_cus <= 0) h->n_cus = 256;
     h->layers.resize(cfg->n_layers);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
@@ -2571,6 +2573,26 @@ extern "C" int rca_debug_attn_timeline(long* out_host, int enable) {   // enable
     return buf && hipMemcpy(out_host, buf, 1024 * 8 * sizeof(long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }
 #endif
+#ifdef RCA_ATTN_TIMELINE
+// flash prefill attention: per wave [entry, loop start, loop end, exit] on the 100 MHz wall clock, then shader cycles summed over its
+// blocks for [QK^T + mask/max, exp + sum, P split, PV], block count and the SIMD / CU it ran on (16 longs per wave)
+__device__ long* rca_flash_tl = nullptr;
+extern "C" int rca_debug_flash_timeline(long* out_host, int enable, int n_waves) {
+    static long* buf = nullptr;
+    static int cap = 0;
+    if (enable) {
+        if (!buf || cap < n_waves) { if (buf) (void)hipFree(buf); if (hipMalloc((void**)&buf, (size_t)n_waves * 16 * sizeof(long)) != hipSuccess) return 1; cap = n_waves; }
+        (void)hipMemset(buf, 0, (size_t)cap * 16 * sizeof(long));
+        return hipMemcpyToSymbol(HIP_SYMBOL(rca_flash_tl), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+    }
+    (void)hipDeviceSynchronize();
+    return buf && hipMemcpy(out_host, buf, (size_t)min(cap, n_waves) * 16 * sizeof(long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#define FTL_CLK() ((long)__builtin_readcyclecounter())
+#define FTL_PHASE(k) do { const long t_now = FTL_CLK(); ftl_acc[k] += t_now - ftl_t; ftl_t = t_now; } while (0)
+#else
+#define FTL_PHASE(k)
+#endif
 // merges the splits of lm_attn_mfma_kernel as its own launch (prefill tiles, and decode steps whose grid exceeds one workgroup per
 // CU): one wave per (token, head)
 template <int G>
@@ -2598,65 +2620,120 @@ __global__ __launch_bounds__(64) void lm_attn_mfma_combine_kernel(const LmDevSta
 // ------------------------------------------------------------------ prefill attention, flash shape
 // The decode-shaped kernel above gives every block of 32 query rows one workgroup PER 256 keys and merges the partial results in a
 // second launch: at 6 k tokens of context a 1024-token pass wrote and re-read 0.2 GB of partials per layer and spent 245 us in
-// attention for ~50 us of MFMA work.  Prefill passes (M > 8) run this kernel instead: a WAVE owns 32 query rows (32 / G tokens x
-// the G heads of one kv head) and walks the key blocks of 32 at ABSOLUTE positions 0, 32, 64, ... up to its last visible key with an
-// online softmax -- no partials, no cross-wave merge, no second launch.  Per key block, as in the decode kernel:
-//   S^T = K Q^T   (v_mfma_f32_32x32x16_f16, K straight from the fp16 cache, Q split into fp16 hi + lo once per wave)
-//                 -> lane <-> query row, registers <-> keys: max / sum / rescale are per-lane scalars
-//   O^T += V^T P^T: A = V^T from a per-wave LDS transpose of the block's V, B = P exactly as it sits in the S^T registers
-//                 (hi + lo fp16) -> O^T has dims on registers and the query row on the lane, so the running rescale exp(m - m')
-//                 and the final 1 / l are per-lane multiplies, and a lane stores 4 consecutive dims (16 bytes) at a time.
-// A query row's result depends only on its own position (every row sees the same key blocks in the same order; blocks past its
-// position contribute exact zeros behind alpha = 1), so the bits do not depend on how a prompt is cut into evals or passes -- the
-// property the shadow KV cache rests on (test_mfma_prefill_is_tiling_invariant).  The next block's K / V loads are issued before the
-// current block's arithmetic.
-#define FLASH_WAVES 4
-template <int G>
-__global__ __launch_bounds__(64 * FLASH_WAVES) void lm_attn_flash_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ qkv,
+// attention for ~50 us of MFMA work.  Prefill passes run this kernel instead: a TEAM of three waves owns a tile of 32 query rows
+// (32 / G tokens x the G heads of one kv head); wave w takes the key blocks of 32 at ABSOLUTE positions 32 (3 i + w) up to the tile's
+// last visible key, each wave with its own online softmax in registers, and the three (m, l, O) are merged through LDS once at the
+// end -- no partials in HBM, no second launch, three waves per SIMD whose MFMA and VALU phases overlap.
+// Per key block:
+//   K, V:         global -> registers (one block ahead) -> the wave's two 4 KB LDS images, loaded 8 whole rows per instruction
+//   S^T = K Q^T   (v_mfma_f32_32x32x16_f16; K fragments by ds_read_b128; Q scaled by scale * log2(e) and split into fp16 hi + lo
+//                 once per wave) -> lane <-> query row, registers <-> keys: max / sum / rescale are per-lane scalars, p = 2^(s - m);
+//                 only the blocks that reach past the tile's first row are masked (a second copy of the loop body)
+//   O^T += V^T P^T: V^T fragments by ds_read_b64_tr_b16, which hands a lane 4 consecutive KEYS of its dim; B = P exactly as it sits
+//                 in the S^T registers (fp16 hi + lo, hi rounded toward zero so lo is the rest, one v_fma_mix_f32 each) -> O^T has
+//                 dims on registers and the query row on the lane.
+//   The O^T rescale by 2^(m - m') is skipped when no lane's maximum moved (multiplying by 1.0 changes nothing).
+// A query row's result depends only on its own position (every row sees the same key blocks on the same waves in the same order;
+// blocks past its position contribute exact zeros behind alpha = 1, and the three partial results are merged in wave order), so the
+// bits do not depend on how a prompt is cut into evals or passes -- the property the shadow KV cache rests on
+// (test_mfma_prefill_is_tiling_invariant).
+// Measured at 6.6 k context, per layer and 1024-token pass (profiles/r03/flash_attention_steps.txt): one wave per tile 148 us ->
+// key blocks split over the waves of a workgroup 101 -> coalesced loads through LDS 90 (the direct A-layout loads took 16 bytes from
+// each of 32 cache lines per instruction: 4100 of 4900 cycles per block were spent waiting on the L1) -> one workgroup per CU ~78.
+#define FLASH_WAVES 3        // waves that split the key blocks of one query tile
+#define FLASH_OPITCH 68      // f32 per query row of a wave's O in the merge buffer
+typedef short flash_s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+// TEAMS query tiles per workgroup (a team = FLASH_WAVES waves = one tile).  With 4 teams a workgroup takes more than half of a CU's
+// LDS, so every CU gets exactly one and the dispatcher cannot pile five tiles on one CU and three on another (measured with one tile
+// per workgroup: 414 .. 730 key blocks per CU, the last CU done at 135 us against a median of 101); the four tiles of workgroup j
+// are j, 2 n - 1 - j, 2 n + j and 4 n - 1 - j of the head's 4 n tiles, whose causal lengths add up to the same total for every j.
+template <int G, int TEAMS>
+__global__ __launch_bounds__(64 * FLASH_WAVES * TEAMS, 3) void lm_attn_flash_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ qkv,
                                                                         const f16_t* __restrict__ kc, const f16_t* __restrict__ vc,
                                                                         float* __restrict__ attn_out, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo,
                                                                         int nh, int nkv, float scale, int n_ctx) {
     constexpr int HD = 64;
-    constexpr int TPB = 32 / G;   // tokens per wave
-    __shared__ __attribute__((aligned(16))) _Float16 vt_all[FLASH_WAVES][HD][ATTM_VT_PITCH];
+    constexpr int TPB = 32 / G;   // tokens per tile
+    constexpr int NWAVES = FLASH_WAVES * TEAMS;
+    // the K / V images of the key loop (8 KB per wave) and the merge buffer that follows it share one region (a barrier between the uses)
+    __shared__ __attribute__((aligned(16))) float flash_lds[NWAVES * 32 * FLASH_OPITCH];
+    __shared__ float mrg_m_all[NWAVES][32], mrg_l_all[NWAVES][32];
+    static_assert(8192 <= sizeof(float) * 32 * FLASH_OPITCH, "K / V images fit the merge buffer");
     const int g = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5, col = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    _Float16 (*vt)[ATTM_VT_PITCH] = vt_all[wave];
-    const int qb = blockIdx.y * FLASH_WAVES + wave;
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int team = wave_all / FLASH_WAVES, wave = wave_all % FLASH_WAVES;
+    float (*mrg_o)[32][FLASH_OPITCH] = reinterpret_cast<float (*)[32][FLASH_OPITCH]>(flash_lds) + team * FLASH_WAVES;
+    float (*mrg_m)[32] = mrg_m_all + team * FLASH_WAVES;
+    float (*mrg_l)[32] = mrg_l_all + team * FLASH_WAVES;
+    char* const kbytes = reinterpret_cast<char*>(flash_lds) + wave_all * 8192;   // K image of the current key block: [key][128 bytes]
+    char* const vbytes = kbytes + 4096;                                          // V image
     const int M = stt->m;
-    const int t0 = qb * TPB;
-    if (t0 >= M) return;
+    const int ntiles = (M + TPB - 1) / TPB;
+    int tile = blockIdx.y;
+    if (TEAMS == 4) {
+        const int n4 = gridDim.y, j = blockIdx.y;
+        tile = team == 0 ? j : team == 1 ? 2 * n4 - 1 - j : team == 2 ? 2 * n4 + j : 4 * n4 - 1 - j;
+    } else if (TEAMS == 2) {
+        tile = team == 0 ? (int)blockIdx.y : 2 * (int)gridDim.y - 1 - (int)blockIdx.y;
+    }
+    const bool active = tile < ntiles;   // team-uniform; an idle team still takes part in the workgroup's barriers
+    if (TEAMS == 1 && !active) return;
+    const int t0 = min(tile, ntiles - 1) * TPB;
+#ifdef RCA_ATTN_TIMELINE
+    long* const ftl = rca_flash_tl ? rca_flash_tl + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * NWAVES + wave_all) * 16 : nullptr;
+    long ftl_acc[4] = {0, 0, 0, 0}, ftl_t = 0, ftl_n = 0;
+    const long ftl_entry = (long)wall_clock64();
+#endif
     const int pos0 = stt->n_tokens;
     const int ntok = min(TPB, M - t0);
-    const int tl = col / G, hq = col % G;
+    const int tl = min(col / G, ntok - 1), hq = col % G;   // rows past the pass repeat the last valid token's: they are never stored
     const int ld = (nh + 2 * nkv) * HD;
-    const bool qvalid = tl < ntok;
     const int qpos = pos0 + t0 + tl;
-    const int kmax = min(pos0 + t0 + ntok, n_ctx);   // keys [0, kmax) are visible to the last token of this wave
-    const int nblk = (kmax + 31) >> 5;
-    // ---- K / V of a key block: lane (key = col, half) takes 4 x 16 bytes of its key's row from each cache
+    const int kmax = min(pos0 + t0 + ntok, n_ctx);   // keys [0, kmax) are visible to the last token of this tile (and are all written)
+    const int nblk = active ? (kmax + 31) >> 5 : 0;
+    // ---- K / V of a key block, global -> registers -> LDS.  A load instruction covers 8 whole rows (lane l: key 8 i + l / 8, 16-byte
+    // chunk l % 8 of its 128-byte row): 8 cache lines per instruction.  (Loading the MFMA A layout directly -- lane <-> key, 16 bytes of
+    // each of 32 rows per instruction -- touched 32 lines for 1 KB and made the kernel wait on the L1: 4100 of 4900 cycles per block.)
+    // Images: chunk c of key k sits at chunk c ^ sw(k); K: sw = (k >> 1) & 7, so the 16 lanes of a ds_read_b128 group (lane <-> key) tile
+    // the 64 banks; V: sw = k1 k2 k0 (bits of k), so the 4 rows x 64 bytes of a transposed read do.  A store group is 8 lanes = one row.
     u32x4 kf[4], vf[4];
+    const int ld_key = lane >> 3, ld_chunk = lane & 7;
     auto load_block = [&](int kb) {
-        const long row = ((long)min(32 * kb + col, n_ctx - 1) * nkv + g) * HD + 8 * half;
 #pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {
-            kf[sub] = *reinterpret_cast<const u32x4*>(kc + row + 16 * sub);
-            vf[sub] = *reinterpret_cast<const u32x4*>(vc + row + 16 * sub);
+        for (int i = 0; i < 4; ++i) {
+            const long off = ((long)min(32 * max(kb, 0) + 8 * i + ld_key, kmax - 1) * nkv + g) * HD + 8 * ld_chunk;   // keys past kmax: a written row, p = 0
+            kf[i] = *reinterpret_cast<const u32x4*>(kc + off);
+            vf[i] = *reinterpret_cast<const u32x4*>(vc + off);
         }
     };
-    load_block(0);
-    // ---- Q of this lane's query row, fp16 hi + lo (rows past the pass read the last valid token's: they are never stored)
+    int kw_off[4], vw_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = 8 * i + ld_key;
+        kw_off[i] = k * 128 + ((ld_chunk ^ ((k >> 1) & 7)) << 4);
+        vw_off[i] = k * 128 + ((ld_chunk ^ ((((k >> 1) & 1) << 2) | (((k >> 2) & 1) << 1) | (k & 1))) << 4);
+    }
+    auto stage_block = [&]() {   // the registers' block becomes the current images
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(kbytes + kw_off[i]) = kf[i];
+            *reinterpret_cast<u32x4*>(vbytes + vw_off[i]) = vf[i];
+        }
+    };
+    load_block(min(wave, nblk - 1));
+    // ---- Q of this lane's query row, times scale * log2(e), fp16 hi + lo
     f16x8 qh[4], ql[4];
     {
-        const float* qp = qkv + (long)(t0 + min(tl, ntok - 1)) * ld + (g * G + hq) * HD + 8 * half;
+        const float qs = scale * 1.44269504088896340736f;
+        const float* qp = qkv + (long)(t0 + tl) * ld + (g * G + hq) * HD + 8 * half;
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(qp + 16 * sub), b = *reinterpret_cast<const f32x4*>(qp + 16 * sub + 4);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float q = j < 4 ? a[j] : b[j - 4];
+                const float q = (j < 4 ? a[j] : b[j - 4]) * qs;
                 const _Float16 h16 = (_Float16)q;
                 qh[sub][j] = h16;
                 ql[sub][j] = (_Float16)(q - (float)h16);
@@ -2669,19 +2746,25 @@ __global__ __launch_bounds__(64 * FLASH_WAVES) void lm_attn_flash_kernel(const L
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[nt][r] = 0.0f;
-    for (int kb = 0; kb < nblk; ++kb) {
-        u32x4 kcur[4], vcur[4];
+    // K fragments: lane (key = col, half) reads chunk half + 2 sub (dims 8 half + 16 sub .. + 8) of its key
+    int kr_off[4];
 #pragma unroll
-        for (int sub = 0; sub < 4; ++sub) { kcur[sub] = kf[sub]; vcur[sub] = vf[sub]; }
-        load_block(min(kb + 1, nblk - 1));   // unconditional (the last iteration re-reads its own block): no merge of wait states
-        // ---- this block's V, transposed into the wave's LDS region: vt[dim][key]
+    for (int sub = 0; sub < 4; ++sub) kr_off[sub] = col * 128 + (((half | (sub << 1)) ^ ((col >> 1) & 7)) << 4);
+    // transposed reads: lane 4 q + p of a 16-lane group supplies row (key) q, dims 4 p .. 4 p + 3 of the group's 16 dims
+    int tr_off[2];
+    {
+        const int l16 = lane & 15, q = l16 >> 2, pp = l16 & 3;
+        const int sw = ((q >> 1) << 2) | (half << 1) | (q & 1);   // rows 16 i + 4 half + q (+ 8)
 #pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {
-            const f16x8 v8 = __builtin_bit_cast(f16x8, vcur[sub]);
+        for (int nt = 0; nt < 2; ++nt) tr_off[nt] = (4 * half + q) * 128 + (((4 * nt + 2 * (col >> 4) + (pp >> 1)) ^ sw) << 4) + 8 * (pp & 1);
+    }
+    const int nfull = min((pos0 + t0 + 1) >> 5, nblk);   // blocks [0, nfull) are visible to every row of the tile: no mask
+    auto block = [&](int kb, auto masked_t) {
+        constexpr bool MASKED = decltype(masked_t)::value;
+        u32x4 kcur[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) vt[8 * half + 16 * sub + j][col] = v8[j];
-        }
-        // ---- S^T = K Q^T (hi + lo)
+        for (int sub = 0; sub < 4; ++sub) kcur[sub] = *reinterpret_cast<const u32x4*>(kbytes + kr_off[sub]);
+        // ---- S^T = K Q^T (hi + lo), in log2 units
         f32x16 sacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
@@ -2691,26 +2774,33 @@ __global__ __launch_bounds__(64 * FLASH_WAVES) void lm_attn_flash_kernel(const L
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfr, qh[sub], sacc, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfr, ql[sub], sacc, 0, 0, 0);
         }
-        // ---- online softmax for query row `col`: registers are keys 32 kb + (r & 3) + 8 (r >> 2) + 4 half
+        // ---- online softmax for query row `col`: register r is key 32 kb + 4 half + (r & 3) + 8 (r >> 2)
         float mx = -INFINITY;
+        if (MASKED) {
+            const int lim = qpos - 32 * kb - 4 * half;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float sv = (qvalid && key <= qpos) ? sacc[r] * scale : -INFINITY;
-            sacc[r] = sv;
-            mx = fmaxf(mx, sv);
+            for (int r = 0; r < 16; ++r) {
+                const float sv = ((r & 3) + 8 * (r >> 2) <= lim) ? sacc[r] : -INFINITY;
+                sacc[r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
         }
         {
             float a = mx, b = mx;
             asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
             mx = fmaxf(a, b);
         }
+        FTL_PHASE(0);
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = (m_run == -INFINITY) ? 0.0f : __expf(m_run - m_new);   // m_new >= m_run; a row with nothing visible yet keeps 0
+        const float m_ref = (m_new == -INFINITY) ? 0.0f : m_new;   // a row with nothing visible yet: 2^(-inf - 0) = 0 everywhere
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_ref);
         float lsum = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float e = (sacc[r] == -INFINITY) ? 0.0f : __expf(sacc[r] - m_new);
+            const float e = __builtin_amdgcn_exp2f(sacc[r] - m_ref);
             sacc[r] = e;
             lsum += e;
         }
@@ -2721,86 +2811,161 @@ __global__ __launch_bounds__(64 * FLASH_WAVES) void lm_attn_flash_kernel(const L
         }
         l_run = l_run * alpha + lsum;
         m_run = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {   // wave-uniform
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[nt][r] *= alpha;
-        // P as the B operand of O^T += V^T P^T: registers 8 i .. 8 i + 7 feed MFMA i (hi + lo fp16)
-        f16x8 ph[2], pl[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float pv = sacc[8 * i + j];
-                const _Float16 h16 = (_Float16)pv;
-                ph[i][j] = h16;
-                pl[i][j] = (_Float16)(pv - (float)h16);
-            }
-        // vt is written and read by this wave only
+                for (int r = 0; r < 16; ++r) oacc[nt][r] *= alpha;
+        }
+        FTL_PHASE(1);
+        // V^T fragments: all eight transposed reads go out before the P split below, which hides their latency.  The image was
+        // written at the top of the block by this wave only (LDS operations of a wave complete in order).
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const bool tail = kb == nblk - 1;   // keys of the last block past kmax may hold anything (their p is 0): zero them
+        flash_s16x4 vfr[2][2][2];   // [nt][i][key group]: lane <-> dim 32 nt + col; slot j <-> key 16 i + 4 half + 8 (j >> 2) + (j & 3)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const char* tp = vbytes + tr_off[nt] + 16 * i * 128;
+                vfr[nt][i][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) flash_s16x4*)tp);
+                vfr[nt][i][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) flash_s16x4*)(tp + 8 * 128));
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        // P as the B operand of O^T += V^T P^T: registers 8 i .. 8 i + 7 feed MFMA i (fp16 hi toward zero + lo = the exact rest, rounded)
+        u32x4 ph[2], pl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float p0 = sacc[8 * i + 2 * j], p1 = sacc[8 * i + 2 * j + 1];
+                const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p0, p1));
+                float r0, r1;   // p - (float)hi in one instruction each
+                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h2), "v"(p0));
+                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h2), "v"(p1));
+                ph[i][j] = h2;
+                pl[i][j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+            }
+        FTL_PHASE(2);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const _Float16* vrow = &vt[32 * nt + col][16 * i + 4 * half];   // lane <-> dim; slot j <-> key 16 i + 4 half + 8 (j >> 2) + (j & 3)
-                const f16x4 v0 = *reinterpret_cast<const f16x4*>(vrow);
-                const f16x4 v1 = *reinterpret_cast<const f16x4*>(vrow + 8);
-                f16x8 vb;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int key = 32 * kb + 16 * i + 4 * half + 8 * (j >> 2) + (j & 3);
-                    const _Float16 x = j < 4 ? v0[j] : v1[j - 4];
-                    vb[j] = (tail && key >= kmax) ? (_Float16)0.0f : x;
-                }
-                oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vb, ph[i], oacc[nt], 0, 0, 0);
-                oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vb, pl[i], oacc[nt], 0, 0, 0);
+                typedef short s16x8_t __attribute__((__vector_size__(8 * sizeof(short))));
+                const s16x8_t v01 = __builtin_shufflevector(vfr[nt][i][0], vfr[nt][i][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                const f16x8 vb = __builtin_bit_cast(f16x8, v01);
+                oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vb, __builtin_bit_cast(f16x8, ph[i]), oacc[nt], 0, 0, 0);
+                oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vb, __builtin_bit_cast(f16x8, pl[i]), oacc[nt], 0, 0, 0);
             }
         }
-        // the next iteration overwrites vt: its reads are done (one wave, LDS operations complete in order)
+        // the next block (in registers since the last iteration) replaces the images: this block's reads are done (one wave, LDS
+        // operations complete in order); the block after it starts its way from the caches
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    if (!qvalid) return;
-    // ---- O = O^T / l: this lane holds, for its query row, dims 32 nt + 8 (r >> 2) + 4 half + (r & 3)
-    const float inv = 1.0f / l_run;
-    const long obase = (long)(t0 + tl) * nh * HD + (long)(g * G + hq) * HD;
+        stage_block();
+        load_block(min(kb + 2 * FLASH_WAVES, nblk - 1));   // unconditional (the last iterations re-read a block): no merge of wait states
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    stage_block();                                          // block `wave` (waits for its loads)
+    load_block(min(wave + FLASH_WAVES, nblk - 1));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int kb = wave;
+#ifdef RCA_ATTN_TIMELINE
+    const long ftl_loop0 = (long)wall_clock64();
+    ftl_t = FTL_CLK();
+    for (; kb < nfull; kb += FLASH_WAVES) { block(kb, std::false_type{}); FTL_PHASE(3); ++ftl_n; }
+    for (; kb < nblk; kb += FLASH_WAVES) { block(kb, std::true_type{}); FTL_PHASE(3); ++ftl_n; }
+    const long ftl_loop1 = (long)wall_clock64();
+#else
+    for (; kb < nfull; kb += FLASH_WAVES) block(kb, std::false_type{});
+    for (; kb < nblk; kb += FLASH_WAVES) block(kb, std::true_type{});
+#endif
+    // ---- the four waves' (m, l, O^T): this lane holds, for query row col, dims 32 nt + 8 (r >> 2) + 4 half + (r & 3)
+    __syncthreads();   // every wave is done with its V image
+    if (half == 0) { mrg_m[wave][col] = m_run; mrg_l[wave][col] = l_run; }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const int d0 = 32 * nt + 8 * rq + 4 * half;
-            float o[4];
+        for (int rq = 0; rq < 4; ++rq)
+            *reinterpret_cast<f32x4*>(&mrg_o[wave][col][32 * nt + 8 * rq + 4 * half]) =
+                f32x4{oacc[nt][4 * rq], oacc[nt][4 * rq + 1], oacc[nt][4 * rq + 2], oacc[nt][4 * rq + 3]};
+    __syncthreads();
+#ifdef RCA_ATTN_TIMELINE
+    if (ftl && lane == 0) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        ftl[0] = ftl_entry; ftl[1] = ftl_loop0; ftl[2] = ftl_loop1; ftl[3] = (long)wall_clock64();
+        for (int k = 0; k < 4; ++k) ftl[4 + k] = ftl_acc[k];
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(20)" : "=s"(xcc));   // XCC_ID
+        ftl[8] = ftl_n; ftl[9] = hwid; ftl[10] = nblk; ftl[11] = xcc & 15;
+    }
+#endif
+    // ---- merge in wave order: thread of the team <-> (query row, 8 dims)
+    if (!active) return;
+    for (int idx = threadIdx.x - 64 * FLASH_WAVES * team; idx < 256; idx += 64 * FLASH_WAVES) {
+        const int row = idx >> 3, d0 = 8 * (idx & 7);
+        if (row / G >= ntok) break;
+        float mm = mrg_m[0][row];   // wave 0 holds key 0, which every row sees: finite
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = oacc[nt][4 * rq + j] * inv;
-            if (hi) {   // prefill tiles: the O-projection GEMM reads bf16 hi + lo
-                unsigned ph2[2], pl2[2];
+        for (int w = 1; w < FLASH_WAVES; ++w) mm = fmaxf(mm, mrg_m[w][row]);
+        float lsum = 0.0f, o[8];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const bf16_t h0 = f32_to_bf16_rne(o[2 * j]), h1 = f32_to_bf16_rne(o[2 * j + 1]);
-                    const bf16_t l0 = f32_to_bf16_rne(o[2 * j] - __uint_as_float((unsigned)h0 << 16));
-                    const bf16_t l1 = f32_to_bf16_rne(o[2 * j + 1] - __uint_as_float((unsigned)h1 << 16));
-                    ph2[j] = (unsigned)h0 | ((unsigned)h1 << 16);
-                    pl2[j] = (unsigned)l0 | ((unsigned)l1 << 16);
-                }
-                *reinterpret_cast<uint2*>(hi + obase + d0) = make_uint2(ph2[0], ph2[1]);
-                *reinterpret_cast<uint2*>(lo + obase + d0) = make_uint2(pl2[0], pl2[1]);
-            } else {
-                *reinterpret_cast<float4*>(attn_out + obase + d0) = make_float4(o[0], o[1], o[2], o[3]);
-            }
+        for (int j = 0; j < 8; ++j) o[j] = 0.0f;
+#pragma unroll
+        for (int w = 0; w < FLASH_WAVES; ++w) {
+            const float wgt = __builtin_amdgcn_exp2f(mrg_m[w][row] - mm);   // a wave that saw nothing: 2^-inf = 0
+            lsum += mrg_l[w][row] * wgt;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&mrg_o[w][row][d0]), b = *reinterpret_cast<const f32x4*>(&mrg_o[w][row][d0 + 4]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { o[j] += a[j] * wgt; o[4 + j] += b[j] * wgt; }
         }
+        const float inv = 1.0f / lsum;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] *= inv;
+        const long obase = (long)(t0 + row / G) * nh * HD + (long)(g * G + row % G) * HD + d0;
+        if (hi) {   // prefill tiles: the O-projection GEMM reads bf16 hi + lo
+            unsigned ph2[4], pl2[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16_t h0 = f32_to_bf16_rne(o[2 * j]), h1 = f32_to_bf16_rne(o[2 * j + 1]);
+                const bf16_t l0 = f32_to_bf16_rne(o[2 * j] - __uint_as_float((unsigned)h0 << 16));
+                const bf16_t l1 = f32_to_bf16_rne(o[2 * j + 1] - __uint_as_float((unsigned)h1 << 16));
+                ph2[j] = (unsigned)h0 | ((unsigned)h1 << 16);
+                pl2[j] = (unsigned)l0 | ((unsigned)l1 << 16);
+            }
+            *reinterpret_cast<uint4*>(hi + obase) = make_uint4(ph2[0], ph2[1], ph2[2], ph2[3]);
+            *reinterpret_cast<uint4*>(lo + obase) = make_uint4(pl2[0], pl2[1], pl2[2], pl2[3]);
+        } else {
+            *reinterpret_cast<float4*>(attn_out + obase) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(attn_out + obase + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        }
+    }
+}
+template <int G>
+static void launch_attention_flash_g(rca_lm* h, int M, const f16_t* kc, const f16_t* vc, hipStream_t st, bf16_t* hi, bf16_t* lo) {
+    const rca_lm_config_t& c = h->cfg;
+    const float scale = 1.0f / sqrtf((float)c.head_dim);
+    const int ntiles = cdiv(M * G, 32);
+    // teams per workgroup: 4 (one workgroup per CU) once that still gives every CU of the device a workgroup, else 2, else 1
+    if (c.n_kv_heads * cdiv(ntiles, 4) >= h->n_cus)
+        lm_attn_flash_kernel<G, 4><<<dim3(c.n_kv_heads, cdiv(ntiles, 4)), 64 * FLASH_WAVES * 4, 0, st>>>(h->stt, h->qkv, kc, vc, h->attn, hi, lo, c.n_heads, c.n_kv_heads, scale, c.n_ctx);
+    else if (c.n_kv_heads * cdiv(ntiles, 2) >= h->n_cus)
+        lm_attn_flash_kernel<G, 2><<<dim3(c.n_kv_heads, cdiv(ntiles, 2)), 64 * FLASH_WAVES * 2, 0, st>>>(h->stt, h->qkv, kc, vc, h->attn, hi, lo, c.n_heads, c.n_kv_heads, scale, c.n_ctx);
+    else
+        lm_attn_flash_kernel<G, 1><<<dim3(c.n_kv_heads, ntiles), 64 * FLASH_WAVES, 0, st>>>(h->stt, h->qkv, kc, vc, h->attn, hi, lo, c.n_heads, c.n_kv_heads, scale, c.n_ctx);
 }
 static void launch_attention_flash(rca_lm* h, int M, const f16_t* kc, const f16_t* vc, hipStream_t st, bf16_t* hi, bf16_t* lo) {
-    const rca_lm_config_t& c = h->cfg;
-    const int G = c.n_heads / c.n_kv_heads;
-    const float scale = 1.0f / sqrtf((float)c.head_dim);
-    const dim3 grid(c.n_kv_heads, cdiv(cdiv(M * G, 32), FLASH_WAVES));
-    if (G == 4) lm_attn_flash_kernel<4><<<grid, 64 * FLASH_WAVES, 0, st>>>(h->stt, h->qkv, kc, vc, h->attn, hi, lo, c.n_heads, c.n_kv_heads, scale, c.n_ctx);
-    else if (G == 2) lm_attn_flash_kernel<2><<<grid, 64 * FLASH_WAVES, 0, st>>>(h->stt, h->qkv, kc, vc, h->attn, hi, lo, c.n_heads, c.n_kv_heads, scale, c.n_ctx);
-    else lm_attn_flash_kernel<1><<<grid, 64 * FLASH_WAVES, 0, st>>>(h->stt, h->qkv, kc, vc, h->attn, hi, lo, c.n_heads, c.n_kv_heads, scale, c.n_ctx);
+    const int G = h->cfg.n_heads / h->cfg.n_kv_heads;
+    if (G == 4) launch_attention_flash_g<4>(h, M, kc, vc, st, hi, lo);
+    else if (G == 2) launch_attention_flash_g<2>(h, M, kc, vc, st, hi, lo);
+    else launch_attention_flash_g<1>(h, M, kc, vc, st, hi, lo);
 }
 
 // split attention on MFMA + merge of the splits, for the M tokens of the current pass
