@@ -307,6 +307,42 @@ int rca_lm_step(rca_lm_t* h, const int32_t* ids, int32_t n, int32_t* token);
  * fail with "no logits" until the next eval or step. */
 int rca_lm_frame(rca_lm_t* h, const int32_t* first_pair, const int32_t* user_ids, int32_t n_steps, int32_t audio_id_floor,
                  int32_t* out_tokens, int32_t* n_done);
+/* ONE duplex frame-step as ONE graph replay (north_star: "the per-frame encode -> LM-step -> decode loop is hipGraph-captured";
+ * the loop is RealtimeAgent.process_audio, realtime_agent_v2.py:504-554): encode tail of the user's rolling PCM window
+ * (audio_tokenizer.py:67-103) -> code -> token id (code_token_base + code: the codec tokens sit in the vocabulary in code order,
+ * train_vanilla_latest.py:587-589) -> the chunk's n_steps LM steps exactly as rca_lm_frame runs them (process_audio_input_ids,
+ * :332-372) -> token id -> code appended to the detokenizer's rolling code context (audio_tokenizer.py:113) -> decode tail
+ * (:141-145) -> softmax(last logits)[probe_id] (measure_event_prob, :448-452).  One upload, one replay, one synchronisation.
+ * The host owns both rolling windows and passes them whole; nothing rolls on the device, so a frame that takes the separate
+ * calls instead (warm-up shapes, forced transcription / response, a trim between two steps) needs no repair.
+ * The first frame of a shape runs the same launches eagerly (it sizes the codec workspace); the second captures. */
+typedef struct rca_duplex_frame_args {
+    const float* pcm_window;    /* host [T]: mono PCM window INCLUDING this frame's chunk */
+    const int64_t* code_ctx;    /* host [F_ctx]: the code context BEFORE this frame's codes (may be NULL when F_ctx = 0) */
+    int32_t T;
+    int32_t F_ctx;
+    int32_t n_steps;            /* codes per frame == LM steps (1..8) */
+    int32_t n_samples;          /* PCM samples wanted from the end of decode(code_ctx + this frame's codes) */
+    int32_t code_token_base;    /* token id of code 0 */
+    int32_t audio_id_floor;     /* a sampled token <= this leaves audio mode (<|end_header|>) */
+    int32_t probe_id;           /* token whose probability under the last step's logits is wanted, or -1 */
+    int32_t first_pair[2];      /* [agent, user] pair of the previous frame (the first step's input) */
+} rca_duplex_frame_args_t;
+typedef struct rca_duplex_frame_out {
+    int64_t user_codes[8];      /* the n_steps codes of the user's chunk (always valid) */
+    int32_t tokens[8];          /* sampled agent tokens; entries >= n_done are -1 */
+    int32_t n_done;             /* as rca_lm_frame: < n_steps when step n_done - 1 left audio mode (KV position / draws put back) */
+    int32_t flags;              /* 0: pcm_out_host holds the decode tail.  bit 0: a sampled token is no codec token, bit 1: frame
+                                   cut short -- in both cases pcm_out_host is untouched and the caller decodes on its own path */
+    float probe_prob;           /* -1 when not asked for or the frame was cut short */
+} rca_duplex_frame_out_t;
+int rca_duplex_frame(rca_lm_t* lm, rca_codec_t* codec, const rca_duplex_frame_args_t* args, rca_duplex_frame_out_t* out,
+                     float* pcm_out_host);
+/* what rca_duplex_frame needs from a codec handle whose tail calls it captures: a signature of every address a captured tail
+ * call bakes in, a hand-over of the handle's stream ordering to the capturing stream, the codebook size */
+int rca_codec_workspace_sig(rca_codec_t* h, uint64_t* sig);
+int rca_codec_stream_handoff(rca_codec_t* h, void* stream);
+int rca_codec_codebook_size(const rca_codec_t* h, int32_t* n);
 /* softmax(logits)[token] of the last position, reduced on the device
  * (measure_event_prob, realtime_agent_v2.py:448-452) */
 int rca_lm_token_probs(rca_lm_t* h, const int32_t* token_ids, int32_t n, float* probs_out);

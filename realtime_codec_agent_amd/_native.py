@@ -164,6 +164,31 @@ class SamplerParamsC(C.Structure):
     ]
 
 
+class DuplexFrameArgsC(C.Structure):
+    _fields_ = [
+        ("pcm_window", C.c_void_p),
+        ("code_ctx", C.c_void_p),
+        ("T", C.c_int32),
+        ("F_ctx", C.c_int32),
+        ("n_steps", C.c_int32),
+        ("n_samples", C.c_int32),
+        ("code_token_base", C.c_int32),
+        ("audio_id_floor", C.c_int32),
+        ("probe_id", C.c_int32),
+        ("first_pair", C.c_int32 * 2),
+    ]
+
+
+class DuplexFrameOutC(C.Structure):
+    _fields_ = [
+        ("user_codes", C.c_int64 * 8),
+        ("tokens", C.c_int32 * 8),
+        ("n_done", C.c_int32),
+        ("flags", C.c_int32),
+        ("probe_prob", C.c_float),
+    ]
+
+
 def sources() -> List[str]:
     return [os.path.join(CSRC_DIR, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC_DIR, s))]
 
@@ -235,6 +260,7 @@ ABI_SYMBOLS = [
     "rca_lm_sync", "rca_lm_set_graphs", "rca_lm_mask_head_rows", "rca_lm_set_mfma_prefill", "rca_lm_set_logits_all",
     "rca_lm_persist_codec_embeddings", "rca_lm_create_shared", "rca_lm_eval_async", "rca_lm_copy_kv", "rca_lm_swap_kv",
     "rca_lm_set_low_priority", "rca_lm_frame", "rca_lm_weight_format", "rca_lm_set_attn_fuse",
+    "rca_duplex_frame", "rca_codec_workspace_sig", "rca_codec_stream_handoff", "rca_codec_codebook_size",
 ]
 
 

@@ -178,6 +178,41 @@ class AudioTokenizer:
         preroll_left = max(0, preroll_samples - n_samples + pcm.shape[-1])
         return (self.sampling_rate, pcm[0, 0] if self.num_channels == 1 else pcm[0]), end_hanging, preroll_left
 
+    # ------------------------------------------------------------------ one-replay duplex frame (rca_duplex_frame)
+    def duplex_plan(self, audio: AudioArg, preroll_samples: int = 0) -> Optional[dict]:
+        """What tokenize_audio(audio) followed by detokenize_audio(<as many codes>, preroll_samples) would hand to the codec, WITHOUT
+        touching the rolling state: the PCM window after the push, the code context the new codes will be appended to, the samples
+        owed.  None unless both windows are in steady state (full: one call shape, one captured graph), the stream is mono and the
+        codec object is the HIP one -- the caller then makes the two separate calls.  duplex_commit_pcm / duplex_commit_codes apply
+        the state changes of the two calls once the fused frame has run."""
+        model = self.codec_model
+        if not (self.streaming_tail and self.num_channels == 1 and hasattr(model, "hip")):
+            return None
+        chunk = self._prep_audio_for_tokenization(audio).reshape(1, -1)
+        n_new = chunk.shape[-1]
+        n_codes = int(n_new / self.sampling_rate * self.framerate * self.num_channels)
+        if n_codes < 1 or n_codes > 8:
+            return None
+        window = np.concatenate((self._pcm.data, chunk), axis=-1)[..., -max(n_new, self._pcm.limit):]
+        have = len(self._codes.text)
+        F = min(have + n_codes, max(n_codes, self._codes.limit))
+        n_samples = int(n_codes / (self.framerate * self.num_channels) * self.sampling_rate) + preroll_samples
+        if window.shape[-1] != self.context_samples or F != self.context_frames or n_samples > F * model.hip.hop:
+            return None
+        ctx = self._codes.text[have + n_codes - F:]
+        code_ctx = chars_to_codes(ctx, self.num_codebooks, self.codebook_size, unicode_offset=self.unicode_offset)[0]
+        return {"window": np.ascontiguousarray(window), "n_codes": n_codes, "code_ctx": np.ascontiguousarray(code_ctx, dtype=np.int64),
+                "n_samples": n_samples, "preroll": preroll_samples}
+
+    def duplex_commit_pcm(self, plan: dict) -> None:
+        """tokenize_audio's state change: the pushed window."""
+        self._pcm.data = plan["window"]
+
+    def duplex_commit_codes(self, plan: dict, audio_codes_str: str, pcm: np.ndarray) -> Tuple[Tuple[int, np.ndarray], str, int]:
+        """detokenize_audio's state change and return value, given the decode tail the fused frame produced."""
+        self._codes.push(audio_codes_str)
+        return (self.sampling_rate, pcm), "", plan["preroll"]
+
     @torch.inference_mode()
     def get_codec_embeddings(self) -> torch.Tensor:
         q = self.codec_model.quantizer

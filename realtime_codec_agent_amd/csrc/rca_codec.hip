@@ -2557,6 +2557,28 @@ extern "C" int rca_codec_decode_tail(rca_codec_t* h, const int64_t* codes_host, 
     return stream_call(h, 1, B, F, n_samples, codes_host, (size_t)B * F * 8, pcm_host, (size_t)B * n_samples * 4);
 }
 
+// Support for a caller that captures the tail calls into a graph of its own (rca_duplex_frame): a signature of everything a captured
+// tail call bakes in (workspace addresses, variant), and a hand-over of the handle's stream ordering to the caller's stream so that
+// the capture records no wait on an event from outside it.
+extern "C" int rca_codec_workspace_sig(rca_codec_t* h, uint64_t* sig) {
+    if (!h || !sig) return fail(RCA_ERR_ARG, "null");
+    *sig = workspace_signature(h) * 1099511628211ull + (unsigned long long)h->variant;
+    return RCA_OK;
+}
+extern "C" int rca_codec_stream_handoff(rca_codec_t* h, void* stream) {
+    if (!h) return fail(RCA_ERR_ARG, "null");
+    RCA_HIP(hipSetDevice(h->device));
+    if (h->last_stream_valid && h->last_stream != (hipStream_t)stream) RCA_HIP(hipStreamSynchronize(h->last_stream));
+    h->last_stream = (hipStream_t)stream;
+    h->last_stream_valid = true;
+    return RCA_OK;
+}
+extern "C" int rca_codec_codebook_size(const rca_codec_t* h, int32_t* n) {
+    if (!h || !n) return fail(RCA_ERR_ARG, "null");
+    *n = h->cfg.codebook_size;
+    return RCA_OK;
+}
+
 extern "C" int rca_codec_set_stream_graphs(rca_codec_t* h, int32_t enable) {
     if (!h) return fail(RCA_ERR_ARG, "null");
     h->stream_graphs = enable != 0;

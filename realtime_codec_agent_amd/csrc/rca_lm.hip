@@ -1540,7 +1540,11 @@ struct rca_lm {
     rca_lm* weights_of = nullptr;
     int borrowers = 0;
     bool zombie = false;
+    struct DuplexState* duplex = nullptr;   // rca_duplex_frame: buffers + graphs of the one-replay frame
 };
+struct DuplexState;
+static void duplex_destroy(DuplexState* d);
+static void duplex_drop_graphs(DuplexState* d);
 
 static int lm_alloc(void** p, size_t bytes) {
     hipError_t e = hipMalloc(p, bytes);
@@ -1575,6 +1579,7 @@ static void lm_drop_graph_set(rca_lm::GraphSet& gs) {
 }
 static void lm_drop_graphs(rca_lm* h) {
     for (auto& gs : h->gset) lm_drop_graph_set(gs);
+    duplex_drop_graphs(h->duplex);
 }
 // the graph set captured over the KV cache that is installed now (evicting the older set if neither matches)
 static rca_lm::GraphSet& lm_graph_set(rca_lm* h) {
@@ -1595,6 +1600,8 @@ extern "C" int rca_lm_destroy(rca_lm_t* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     lm_drop_graphs(h);
+    duplex_destroy(h->duplex);
+    h->duplex = nullptr;
     for (void* p : {(void*)h->kc, (void*)h->vc, (void*)h->x, (void*)h->xn, (void*)h->qkv, (void*)h->attn, (void*)h->hbuf,
                     (void*)h->att_part, (void*)h->logits, (void*)h->probs_dev, (void*)h->probe_ids_dev, (void*)h->att_arrive, (void*)h->xh, (void*)h->xl,
                     (void*)h->gpart, (void*)h->stt, (void*)h->samp, (void*)h->swork})
@@ -3922,6 +3929,226 @@ extern "C" int rca_lm_frame(rca_lm_t* h, const int32_t* first_pair, const int32_
     if (done < n_steps) {   // the device drew n_steps times: put its counter where the step-by-step loop would be
         RCA_HIP(hipMemcpy(&h->stt->rng_counter, &h->rng_host, 8, hipMemcpyHostToDevice));
     }
+    return RCA_OK;
+}
+
+// ---- one duplex frame as ONE graph (process_audio, realtime_agent_v2.py:504-554): encode tail of the user's PCM window -> code ->
+// token id (affine: the codec tokens were added to the vocabulary in code order, train_vanilla_latest.py:587-589) -> the chunk's
+// n_steps LM steps with device-side feedback (rca_lm_frame) -> token id -> code, appended to the detokenizer's code context ->
+// decode tail -> softmax(last logits)[probe] (measure_event_prob, :448-452).  One upload, one replay, one synchronisation.  The host
+// stays the owner of both rolling windows (it passes them in whole), so a frame that cannot take this path -- or is cut short --
+// simply goes through the separate calls with nothing to repair on the device.
+struct DuplexDev {            // device-side scratch of the duplex frame (one allocation)
+    long long user_codes[LM_FRAME_MAX];
+    float probe_prob;
+    int flags;
+    int probe_id;
+    int pad;
+};
+struct DuplexPin {            // pinned mirror: inputs first (uploaded), outputs behind
+    int probe_id;
+    int pad0[3];
+    long long user_codes[LM_FRAME_MAX];   // user_codes, probe_prob, flags: one copy of DuplexDev's head
+    float probe_prob;
+    int flags;
+    int frame_out[LM_FRAME_MAX];
+};
+__global__ void duplex_codes_to_ids_kernel(const long long* __restrict__ codes, int n, int base, LmDevState* stt, int* flags) {
+    if (threadIdx.x == 0) *flags = 0;
+    if ((int)threadIdx.x < n) stt->ids[LM_FRAME_USER0 + threadIdx.x] = base + (int)codes[threadIdx.x];
+}
+// frame_out -> codes behind the context codes; a token that is not a codec token (the frame left audio mode, or a padding row of the
+// vocabulary was drawn) becomes code 0 and raises flag bit 0: the PCM of this replay is then not used
+__global__ void duplex_tokens_to_codes_kernel(const LmDevState* __restrict__ stt, int n, int base, int n_codes, long long* __restrict__ dst,
+                                              int* flags) {
+    if ((int)threadIdx.x < n) {
+        const int c = stt->frame_out[threadIdx.x] - base;
+        const bool ok = c >= 0 && c < n_codes;
+        dst[threadIdx.x] = ok ? c : 0;
+        if (!ok) atomicOr(flags, 1);
+    }
+}
+struct DuplexGraphKey {
+    int T, F_ctx, n_steps, n_samples, probe, bucket, base;
+    const void* kc;
+    unsigned long long codec_sig;
+    const void* codec;
+    bool operator==(const DuplexGraphKey& o) const {
+        return T == o.T && F_ctx == o.F_ctx && n_steps == o.n_steps && n_samples == o.n_samples && probe == o.probe && bucket == o.bucket &&
+               base == o.base && kc == o.kc && codec_sig == o.codec_sig && codec == o.codec;
+    }
+};
+struct DuplexState {
+    float* pcm_in = nullptr; size_t pcm_in_cap = 0;       // device: the PCM window
+    long long* code_win = nullptr; size_t code_win_cap = 0;   // device: context codes + this frame's
+    float* pcm_out = nullptr; size_t pcm_out_cap = 0;     // device: decode tail
+    DuplexDev* dev = nullptr;
+    char* pin = nullptr; size_t pin_cap = 0;              // pinned: [DuplexPin | pcm window | code ctx | pcm out]
+    struct Entry { DuplexGraphKey key; hipGraphExec_t exec = nullptr; int seen = 0; };
+    std::vector<Entry> graphs;
+    const void* logits_at_capture = nullptr;
+};
+static void duplex_drop_graphs(DuplexState* d) {
+    if (!d) return;
+    for (auto& e : d->graphs)
+        if (e.exec) (void)hipGraphExecDestroy(e.exec);
+    d->graphs.clear();
+}
+static void duplex_destroy(DuplexState* d) {
+    if (!d) return;
+    duplex_drop_graphs(d);
+    for (void* p : {(void*)d->pcm_in, (void*)d->code_win, (void*)d->pcm_out, (void*)d->dev})
+        if (p) (void)hipFree(p);
+    if (d->pin) (void)hipHostFree(d->pin);
+    delete d;
+}
+template <class T>
+static int duplex_grow(T** p, size_t* cap, size_t n) {
+    if (n <= *cap) return RCA_OK;
+    if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+    int rc = lm_alloc((void**)p, n * sizeof(T));
+    if (rc == RCA_OK) *cap = n;
+    return rc;
+}
+
+extern "C" int rca_duplex_frame(rca_lm_t* h, rca_codec_t* codec, const rca_duplex_frame_args_t* a, rca_duplex_frame_out_t* out,
+                                float* pcm_out_host) {
+    if (!h || !codec || !a || !out || !pcm_out_host || !a->pcm_window || (a->F_ctx > 0 && !a->code_ctx)) return fail(RCA_ERR_ARG, "duplex_frame: null argument");
+    const int n = a->n_steps;
+    if (n < 1 || n > LM_FRAME_MAX) return fail(RCA_ERR_ARG, "duplex_frame: %d steps (1..%d)", n, LM_FRAME_MAX);
+    if (a->T < 1 || a->F_ctx < 0 || a->n_samples < 1) return fail(RCA_ERR_ARG, "duplex_frame: bad shape (T=%d F_ctx=%d n_samples=%d)", a->T, a->F_ctx, a->n_samples);
+    if (!h->sampler_set) return fail(RCA_ERR_STATE, "sampler not initialised");
+    if (h->cfg.logits_all) return fail(RCA_ERR_STATE, "duplex_frame: not on a logits_all handle");
+    if (h->n_tokens + 2 * n > h->cfg.n_ctx) return fail(RCA_ERR_STATE, "context overflow: %d + %d > n_ctx %d", h->n_tokens, 2 * n, h->cfg.n_ctx);
+    int32_t n_codes = 0;
+    int rc;
+    if ((rc = rca_codec_codebook_size(codec, &n_codes)) != RCA_OK) return rc;
+    if (a->code_token_base < 0 || (long)a->code_token_base + n_codes > h->cfg.vocab_size) return fail(RCA_ERR_ARG, "duplex_frame: codes [%d, %d + %d) fall outside the vocabulary", a->code_token_base, a->code_token_base, n_codes);
+    for (int i = 0; i < 2; ++i)
+        if (a->first_pair[i] < 0 || a->first_pair[i] >= h->cfg.vocab_size) return fail(RCA_ERR_ARG, "duplex_frame: token id %d outside the vocabulary", a->first_pair[i]);
+    if (a->probe_id >= h->cfg.vocab_size) return fail(RCA_ERR_ARG, "duplex_frame: probe id %d outside the vocabulary", a->probe_id);
+    for (int i = 0; i < a->F_ctx; ++i)
+        if (a->code_ctx[i] < 0 || a->code_ctx[i] >= n_codes) return fail(RCA_ERR_ARG, "decode: code out of range [0, %d)", n_codes);
+    { const int src = lm_settle(h); if (src != RCA_OK) return src; }
+    RCA_HIP(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    if (!h->duplex) h->duplex = new DuplexState();
+    DuplexState* d = h->duplex;
+    const int F = a->F_ctx + n;
+    const size_t pin_pcm = sizeof(DuplexPin), pin_codes = pin_pcm + (((size_t)a->T * 4 + 255) & ~(size_t)255),
+                 pin_out = pin_codes + (((size_t)a->F_ctx * 8 + 255) & ~(size_t)255), pin_total = pin_out + (size_t)a->n_samples * 4;
+    // growing a buffer invalidates the graphs captured over it
+    if ((size_t)a->T > d->pcm_in_cap || (size_t)F > d->code_win_cap || (size_t)a->n_samples > d->pcm_out_cap || pin_total > d->pin_cap || !d->dev) {
+        RCA_HIP(hipStreamSynchronize(st));
+        duplex_drop_graphs(d);
+        if ((rc = duplex_grow(&d->pcm_in, &d->pcm_in_cap, (size_t)a->T)) != RCA_OK) return rc;
+        if ((rc = duplex_grow(&d->code_win, &d->code_win_cap, (size_t)F + 8)) != RCA_OK) return rc;
+        if ((rc = duplex_grow(&d->pcm_out, &d->pcm_out_cap, (size_t)a->n_samples)) != RCA_OK) return rc;
+        if (!d->dev && (rc = lm_alloc((void**)&d->dev, sizeof(DuplexDev))) != RCA_OK) return rc;
+        if (pin_total > d->pin_cap) {
+            if (d->pin) (void)hipHostFree(d->pin);
+            d->pin = nullptr; d->pin_cap = 0;
+            RCA_HIP(hipHostMalloc((void**)&d->pin, pin_total + (pin_total >> 2), hipHostMallocDefault));
+            d->pin_cap = pin_total + (pin_total >> 2);
+        }
+    }
+    if (d->logits_at_capture != (const void*)h->logits) { duplex_drop_graphs(d); d->logits_at_capture = h->logits; }
+    DuplexPin* pin = reinterpret_cast<DuplexPin*>(d->pin);
+    // stage the inputs
+    h->h_stt->n_tokens = h->n_tokens;
+    h->h_stt->m = 2;
+    h->h_stt->ids[0] = a->first_pair[0];
+    h->h_stt->ids[1] = a->first_pair[1];
+    for (int i = 0; i < n; ++i) h->h_stt->ids[LM_FRAME_USER0 + i] = 0;
+    pin->probe_id = a->probe_id >= 0 ? a->probe_id : 0;
+    memcpy(d->pin + pin_pcm, a->pcm_window, (size_t)a->T * 4);
+    if (a->F_ctx) memcpy(d->pin + pin_codes, a->code_ctx, (size_t)a->F_ctx * 8);
+    int bucket = 0;
+    const int need = lm_splits_needed(h, 2 * n);
+    while (bucket + 1 < LM_GRAPH_BUCKETS && (4 << bucket) < need) ++bucket;
+    const int nsp_launch = bucket + 1 == LM_GRAPH_BUCKETS ? h->n_splits : std::min(h->n_splits, 4 << bucket);
+    uint64_t csig = 0;
+    if ((rc = rca_codec_workspace_sig(codec, &csig)) != RCA_OK) return rc;
+    DuplexGraphKey key{a->T, a->F_ctx, n, a->n_samples, a->probe_id >= 0 ? 1 : 0, bucket, a->code_token_base, (const void*)h->kc, csig, (const void*)codec};
+    DuplexState::Entry* ent = nullptr;
+    for (auto& e : d->graphs)
+        if (e.key == key) ent = &e;
+    if (!ent) {
+        if (d->graphs.size() >= 32) { RCA_HIP(hipStreamSynchronize(st)); duplex_drop_graphs(d); }   // stale shapes / caches: start over
+        d->graphs.push_back(DuplexState::Entry{key, nullptr, 0});
+        ent = &d->graphs.back();
+    }
+    auto enqueue = [&]() -> int {
+        hipError_t e = hipMemcpyAsync(h->stt, h->h_stt, LM_STATE_DECODE_BYTES, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(d->pcm_in, d->pin + pin_pcm, (size_t)a->T * 4, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && a->F_ctx) e = hipMemcpyAsync(d->code_win, d->pin + pin_codes, (size_t)a->F_ctx * 8, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(&d->dev->probe_id, &pin->probe_id, 4, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return fail(RCA_ERR_HIP, "duplex h2d: %s", hipGetErrorString(e));
+        int r = rca_codec_encode_tail_dev(codec, d->pcm_in, 1, a->T, n, (int64_t*)d->dev->user_codes, st);
+        if (r != RCA_OK) return r;
+        duplex_codes_to_ids_kernel<<<1, 64, 0, st>>>(d->dev->user_codes, n, a->code_token_base, h->stt, &d->dev->flags);
+        for (int i = 0; i < n; ++i) {
+            if ((r = lm_enqueue_pass(h, 2, 1, st, nsp_launch, i > 0)) != RCA_OK) return r;
+            lm_enqueue_sample(h, h->logits, st, i);
+        }
+        duplex_tokens_to_codes_kernel<<<1, 64, 0, st>>>(h->stt, n, a->code_token_base, n_codes, d->code_win + a->F_ctx, &d->dev->flags);
+        if ((r = rca_codec_decode_tail_dev(codec, (const int64_t*)d->code_win, 1, F, a->n_samples, d->pcm_out, st)) != RCA_OK) return r;
+        if (a->probe_id >= 0) {
+            lm_softmax_slices_kernel<<<PROBS_SLICES, 1024, 0, st>>>(h->logits, h->cfg.vocab_size, h->probs_dev + 64);
+            lm_token_probs_kernel<<<1, 64, 0, st>>>(h->logits, h->cfg.vocab_size, h->probs_dev + 64, &d->dev->probe_id, 1, &d->dev->probe_prob);
+        }
+        RCA_LAUNCH_CHECK();
+        e = hipMemcpyAsync(pin->frame_out, h->stt->frame_out, sizeof(int) * LM_FRAME_MAX, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(pin->user_codes, d->dev->user_codes, sizeof(long long) * LM_FRAME_MAX + 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(d->pin + pin_out, d->pcm_out, (size_t)a->n_samples * 4, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) return fail(RCA_ERR_HIP, "duplex d2h: %s", hipGetErrorString(e));
+        return RCA_OK;
+    };
+    // the codec's ordering moves to this stream (nothing of it is in flight elsewhere once this returns)
+    if ((rc = rca_codec_stream_handoff(codec, st)) != RCA_OK) return rc;
+    const bool want_graph = h->graphs_enabled && ent->seen >= 1;
+    if (want_graph && !ent->exec) {
+        // the eager frame before this one sized every workspace buffer of this shape: nothing allocates under capture
+        hipGraph_t g = nullptr;
+        RCA_HIP(hipStreamSynchronize(st));
+        RCA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        rc = enqueue();
+        hipError_t e2 = hipStreamEndCapture(st, &g);
+        if (rc != RCA_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (e2 != hipSuccess) return fail(RCA_ERR_HIP, "duplex capture: %s", hipGetErrorString(e2));
+        e2 = hipGraphInstantiate(&ent->exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e2 != hipSuccess) { ent->exec = nullptr; return fail(RCA_ERR_HIP, "duplex graph instantiate: %s", hipGetErrorString(e2)); }
+        // a workspace that moved under the eager run (first call of a shape) would have changed the signature: checked by the key
+    }
+    if (want_graph) {
+        RCA_HIP(hipGraphLaunch(ent->exec, st));
+    } else if ((rc = enqueue()) != RCA_OK) {
+        return rc;
+    }
+    ++ent->seen;
+    RCA_HIP(hipStreamSynchronize(st));
+    // the eager run may have (re)allocated codec workspace: a graph captured later must be keyed by the signature after it
+    if (!want_graph) {
+        uint64_t csig2 = 0;
+        if ((rc = rca_codec_workspace_sig(codec, &csig2)) != RCA_OK) return rc;
+        ent->key.codec_sig = csig2;
+    }
+    int done = n;
+    for (int i = 0; i < n; ++i) {
+        out->tokens[i] = pin->frame_out[i];
+        out->user_codes[i] = pin->user_codes[i];
+        if (out->tokens[i] <= a->audio_id_floor) { done = i + 1; break; }
+    }
+    for (int i = done; i < n; ++i) { out->tokens[i] = -1; out->user_codes[i] = pin->user_codes[i]; }
+    out->n_done = done;
+    out->flags = pin->flags | (done < n ? 2 : 0);
+    out->probe_prob = (a->probe_id >= 0 && done == n) ? pin->probe_prob : -1.0f;
+    if (out->flags == 0) memcpy(pcm_out_host, d->pin + pin_out, (size_t)a->n_samples * 4);
+    h->n_tokens += 2 * done;
+    h->logits_rows = done < n ? 0 : 1;
+    h->rng_host += (unsigned long long)done;
+    if (done < n) RCA_HIP(hipMemcpy(&h->stt->rng_counter, &h->rng_host, 8, hipMemcpyHostToDevice));
     return RCA_OK;
 }
 

@@ -447,6 +447,34 @@ class LlamaForAlternatingCodeChannels:
         self._logits_valid = False
         return toks
 
+    def duplex_frame(self, codec_handle, pcm_window: np.ndarray, code_ctx: np.ndarray, n_steps: int, n_samples: int,
+                     code_token_base: int, audio_id_floor: int, probe_id: int, first_pair: Sequence[int]) -> dict:
+        """One whole duplex frame (encode tail -> the chunk's LM steps -> decode tail -> P(probe)) as ONE graph replay
+        (rca_duplex_frame; RealtimeAgent.process_audio, realtime_agent_v2.py:504-554).  `codec_handle` is the HipCodec whose tail
+        calls are captured.  Returns user_codes [n_steps], tokens (as frame(): shorter when a step left audio mode), pcm
+        [n_samples] or None when the decode of this replay must not be used, probe_prob or None."""
+        first_pair = [int(t) for t in first_pair]
+        if len(first_pair) != 2:
+            raise ValueError("duplex_frame() starts from the last [agent, user] pair")
+        pcm_window = np.ascontiguousarray(pcm_window, dtype=np.float32).reshape(-1)
+        code_ctx = np.ascontiguousarray(code_ctx, dtype=np.int64).reshape(-1)
+        n0 = self.n_tokens
+        a = N.DuplexFrameArgsC(pcm_window=pcm_window.ctypes.data, code_ctx=code_ctx.ctypes.data if code_ctx.size else None,
+                               T=pcm_window.size, F_ctx=code_ctx.size, n_steps=int(n_steps), n_samples=int(n_samples),
+                               code_token_base=int(code_token_base), audio_id_floor=int(audio_id_floor), probe_id=int(probe_id))
+        a.first_pair[0], a.first_pair[1] = first_pair
+        out = N.DuplexFrameOutC()
+        pcm = np.empty(int(n_samples), dtype=np.float32)
+        N.check(self._lib.rca_duplex_frame(self._h, codec_handle._h, C.byref(a), C.byref(out), C.c_void_p(pcm.ctypes.data)), "rca_duplex_frame")
+        codes = [int(c) for c in out.user_codes[:n_steps]]
+        toks = [int(t) for t in out.tokens[:out.n_done]]
+        user_ids = [int(code_token_base) + c for c in codes]
+        evaluated = first_pair + [t for pair in zip(toks[:-1], user_ids) for t in pair]
+        self._input_ids[n0:n0 + len(evaluated)] = evaluated
+        self._logits_valid = False
+        return {"user_codes": codes, "tokens": toks, "pcm": pcm if out.flags == 0 else None,
+                "probe_prob": float(out.probe_prob) if out.probe_prob >= 0.0 else None}
+
     def generate(self, tokens: Sequence[int], reset: bool = True, stopping_criteria=None) -> Generator[int, Optional[Sequence[int]], None]:
         """llamacpp_utils.py:97-181.  The agent always calls next(generate(ids, reset=False)) and drops the
         generator, so the first yield is the fused step; continuing the generator keeps sampling."""

@@ -178,19 +178,70 @@ def test_trim_through_shadow_cache_equals_reference_recompute(mfma_prefill):
 
 
 def test_frame_graph_session_equals_step_by_step_session():
-    """N1 (north_star: the per-frame loop is hipGraph-captured): the same sampled session with one graph replay per chunk
-    (llm.frame) and with one replay per step -- identical token streams, audio and final logits, trims included."""
+    """N1 (north_star: the per-frame loop is hipGraph-captured): the same sampled session (a) with the WHOLE frame -- encode tail, code ->
+    id, the chunk's LM steps, id -> code, decode tail, P(<|end_audio|>) -- as one graph replay (rca_duplex_frame), (b) with one replay
+    per LM chunk (llm.frame) between the separate codec calls, (c) with one replay per step -- identical token streams, audio, event
+    statistics and final logits, trims included."""
     runs = []
-    for frame_graph in (True, False):
+    for duplex_graph, frame_graph in ((True, True), (False, True), (False, False)):
         agent, res = make_agent(chunk=0.08, max_context_secs=1.2, trim_by_secs=0.4)
         agent.use_frame_graph = frame_graph
-        sig = rich_signal(1280 * 50, 35)
+        agent.use_duplex_graph = duplex_graph
+        sig = rich_signal(1280 * 70, 35)
         outs = [agent.process_audio(sig[s:s + 1280]) for s in range(0, len(sig), 1280)]
         res.llm.eval(agent.input_ids[-2:])
-        runs.append((list(agent.input_ids), np.concatenate(outs), res.llm._scores[-1].copy()))
+        runs.append((list(agent.input_ids), np.concatenate(outs), res.llm._scores[-1].copy(), list(agent.stats.event_prob.values),
+                     res.audio_tokenizer.detokenize_context, res.audio_tokenizer.tokenize_context.copy()))
         assert agent.frame_graph_active == frame_graph
-    assert runs[0][0] == runs[1][0]
-    assert np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+        # both codec windows are full after 2 s (25 frames): every later frame that stays on the steady-state path is one replay
+        print("one-replay frames:", agent.duplex_graph_frames)
+        assert (agent.duplex_graph_frames >= 30) if duplex_graph else (agent.duplex_graph_frames == 0)
+    for other in runs[1:]:
+        assert runs[0][0] == other[0]
+        assert np.array_equal(runs[0][1], other[1]) and np.array_equal(runs[0][2], other[2])
+        assert runs[0][3] == other[3] and runs[0][4] == other[4] and np.array_equal(runs[0][5], other[5])
+
+
+def test_duplex_frame_call_equals_the_separate_calls():
+    """rca_duplex_frame against the calls it fuses, on two handles over the same weights: codes of the user's window, sampled tokens,
+    decode tail and the probe probability are the ones encode_tail -> frame -> decode_tail -> token_probs give, eagerly (first call
+    of a shape) and replayed (later calls), and also when a step leaves audio mode inside the frame."""
+    agent, res = make_agent(chunk=0.08)
+    llm, at = res.llm, res.audio_tokenizer
+    hip = at.codec_model.hip
+    twin = llm.make_kv_shadow(low_priority=False)
+    for m in (llm, twin):          # the same sampler, both draw counters at 0
+        m.init_sampler_for_generate(top_k=100, top_p=1.0, min_p=0.0, temp=1.0, seed=11)
+    base, floor = agent._code_token_base, agent.end_header_token_id
+    rng = np.random.default_rng(5)
+    prompt = [int(t) for t in rng.integers(base, base + at.codebook_size, size=40)]
+    for m in (llm, twin):
+        m.reset()
+        m.eval(prompt[:-2])
+    sig = rich_signal(32000 + 1280 * 6, 17)
+    ctx = rng.integers(0, at.codebook_size, size=96).astype(np.int64)
+    pair = prompt[-2:]
+    for k in range(6):
+        window = sig[1280 * (k + 1):1280 * (k + 1) + 32000]
+        out = llm.duplex_frame(hip, window, ctx, 4, 1280 + 160, base, floor, agent.end_audio_token_id, pair)
+        codes = hip.encode_tail(window[None], 4)[0]
+        toks = twin.frame(pair, [base + int(c) for c in codes], floor)
+        assert out["user_codes"] == [int(c) for c in codes] and out["tokens"] == toks
+        assert len(toks) == 4
+        new_codes = np.array([t - base for t in toks], dtype=np.int64)
+        pcm = hip.decode_tail(np.concatenate([ctx, new_codes])[None], 1280 + 160)[0]
+        assert np.array_equal(out["pcm"], pcm)
+        assert out["probe_prob"] == float(twin.token_probs([agent.end_audio_token_id])[0])
+        assert llm.n_tokens == twin.n_tokens
+        ctx = np.concatenate([ctx, new_codes])[-96:]
+        pair = [toks[-1], base + int(codes[-1])]
+    # a floor above every token id: the first step "leaves audio mode" -> cut short, no PCM, state as after one step
+    out = llm.duplex_frame(hip, sig[:32000], ctx, 4, 1280 + 160, base, llm.n_vocab(), -1, pair)
+    toks = twin.frame(pair, [base + int(c) for c in hip.encode_tail(sig[None, :32000], 4)[0]], twin.n_vocab())
+    assert out["tokens"] == toks and len(toks) == 1 and out["pcm"] is None and out["probe_prob"] is None
+    assert llm.n_tokens == twin.n_tokens
+    assert llm.step(pair) == twin.step(pair)       # the draw counters were put back alike
+    twin.close()
 
 
 def test_full_size_duplex_session_equals_the_oracle_session():
