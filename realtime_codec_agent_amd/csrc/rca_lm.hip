@@ -3984,9 +3984,16 @@ struct DuplexState {
     float* pcm_out = nullptr; size_t pcm_out_cap = 0;     // device: decode tail
     DuplexDev* dev = nullptr;
     char* pin = nullptr; size_t pin_cap = 0;              // pinned: [DuplexPin | pcm window | code ctx | pcm out]
-    struct Entry { DuplexGraphKey key; hipGraphExec_t exec = nullptr; int seen = 0; };
+    struct Entry { DuplexGraphKey key; hipGraphExec_t exec = nullptr; };
     std::vector<Entry> graphs;
+    // call shapes whose codec workspace an eager frame has already sized (a capture must not allocate): one eager frame per SHAPE,
+    // not per context bucket
+    struct Warm { int T, F_ctx, n_steps, n_samples; const void* codec; unsigned long long codec_sig; };
+    std::vector<Warm> warm;
     const void* logits_at_capture = nullptr;
+    hipStream_t side = nullptr;      // the encode tail runs beside the first LM step (which does not need this chunk's codes)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool fork = true;
 };
 static void duplex_drop_graphs(DuplexState* d) {
     if (!d) return;
@@ -4000,6 +4007,9 @@ static void duplex_destroy(DuplexState* d) {
     for (void* p : {(void*)d->pcm_in, (void*)d->code_win, (void*)d->pcm_out, (void*)d->dev})
         if (p) (void)hipFree(p);
     if (d->pin) (void)hipHostFree(d->pin);
+    if (d->side) (void)hipStreamDestroy(d->side);
+    if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
+    if (d->ev_join) (void)hipEventDestroy(d->ev_join);
     delete d;
 }
 template <class T>
@@ -4032,7 +4042,14 @@ extern "C" int rca_duplex_frame(rca_lm_t* h, rca_codec_t* codec, const rca_duple
     { const int src = lm_settle(h); if (src != RCA_OK) return src; }
     RCA_HIP(hipSetDevice(h->device));
     hipStream_t st = h->stream;
-    if (!h->duplex) h->duplex = new DuplexState();
+    if (!h->duplex) {
+        h->duplex = new DuplexState();
+        const char* nf = getenv("RCA_DUPLEX_FORK");
+        h->duplex->fork = !(nf && nf[0] == '0');
+        RCA_HIP(hipStreamCreateWithFlags(&h->duplex->side, hipStreamNonBlocking));
+        RCA_HIP(hipEventCreateWithFlags(&h->duplex->ev_fork, hipEventDisableTiming));
+        RCA_HIP(hipEventCreateWithFlags(&h->duplex->ev_join, hipEventDisableTiming));
+    }
     DuplexState* d = h->duplex;
     const int F = a->F_ctx + n;
     const size_t pin_pcm = sizeof(DuplexPin), pin_codes = pin_pcm + (((size_t)a->T * 4 + 255) & ~(size_t)255),
@@ -4075,20 +4092,40 @@ extern "C" int rca_duplex_frame(rca_lm_t* h, rca_codec_t* codec, const rca_duple
         if (e.key == key) ent = &e;
     if (!ent) {
         if (d->graphs.size() >= 32) { RCA_HIP(hipStreamSynchronize(st)); duplex_drop_graphs(d); }   // stale shapes / caches: start over
-        d->graphs.push_back(DuplexState::Entry{key, nullptr, 0});
+        d->graphs.push_back(DuplexState::Entry{key, nullptr});
         ent = &d->graphs.back();
     }
+    bool warmed = false;
+    for (auto& w : d->warm)
+        warmed = warmed || (w.T == a->T && w.F_ctx == a->F_ctx && w.n_steps == n && w.n_samples == a->n_samples && w.codec == (const void*)codec && w.codec_sig == csig);
     auto enqueue = [&]() -> int {
         hipError_t e = hipMemcpyAsync(h->stt, h->h_stt, LM_STATE_DECODE_BYTES, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemcpyAsync(d->pcm_in, d->pin + pin_pcm, (size_t)a->T * 4, hipMemcpyHostToDevice, st);
         if (e == hipSuccess && a->F_ctx) e = hipMemcpyAsync(d->code_win, d->pin + pin_codes, (size_t)a->F_ctx * 8, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemcpyAsync(&d->dev->probe_id, &pin->probe_id, 4, hipMemcpyHostToDevice, st);
         if (e != hipSuccess) return fail(RCA_ERR_HIP, "duplex h2d: %s", hipGetErrorString(e));
-        int r = rca_codec_encode_tail_dev(codec, d->pcm_in, 1, a->T, n, (int64_t*)d->dev->user_codes, st);
+        // Step 0 evaluates the PREVIOUS frame's pair: this chunk's codes are first needed by the sampler tail of step 0, which makes
+        // [token just sampled, user's code 0] the next pair.  The encode tail therefore runs on a side branch beside step 0's layers
+        // (a dozen latency-bound launches of a few workgroups each) and joins in front of step 0's sampler.
+        hipStream_t se = d->fork ? d->side : st;
+        if (d->fork) {
+            e = hipEventRecord(d->ev_fork, st);
+            if (e == hipSuccess) e = hipStreamWaitEvent(se, d->ev_fork, 0);
+            if (e != hipSuccess) return fail(RCA_ERR_HIP, "duplex fork: %s", hipGetErrorString(e));
+        }
+        int r = rca_codec_encode_tail_dev(codec, d->pcm_in, 1, a->T, n, (int64_t*)d->dev->user_codes, se);
         if (r != RCA_OK) return r;
-        duplex_codes_to_ids_kernel<<<1, 64, 0, st>>>(d->dev->user_codes, n, a->code_token_base, h->stt, &d->dev->flags);
+        duplex_codes_to_ids_kernel<<<1, 64, 0, se>>>(d->dev->user_codes, n, a->code_token_base, h->stt, &d->dev->flags);
+        if (d->fork) {
+            e = hipEventRecord(d->ev_join, se);
+            if (e != hipSuccess) return fail(RCA_ERR_HIP, "duplex join: %s", hipGetErrorString(e));
+        }
         for (int i = 0; i < n; ++i) {
             if ((r = lm_enqueue_pass(h, 2, 1, st, nsp_launch, i > 0)) != RCA_OK) return r;
+            if (i == 0 && d->fork) {
+                e = hipStreamWaitEvent(st, d->ev_join, 0);
+                if (e != hipSuccess) return fail(RCA_ERR_HIP, "duplex join: %s", hipGetErrorString(e));
+            }
             lm_enqueue_sample(h, h->logits, st, i);
         }
         duplex_tokens_to_codes_kernel<<<1, 64, 0, st>>>(h->stt, n, a->code_token_base, n_codes, d->code_win + a->F_ctx, &d->dev->flags);
@@ -4105,8 +4142,8 @@ extern "C" int rca_duplex_frame(rca_lm_t* h, rca_codec_t* codec, const rca_duple
         return RCA_OK;
     };
     // the codec's ordering moves to this stream (nothing of it is in flight elsewhere once this returns)
-    if ((rc = rca_codec_stream_handoff(codec, st)) != RCA_OK) return rc;
-    const bool want_graph = h->graphs_enabled && ent->seen >= 1;
+    if ((rc = rca_codec_stream_handoff(codec, d->fork ? d->side : st)) != RCA_OK) return rc;
+    const bool want_graph = h->graphs_enabled && warmed;
     if (want_graph && !ent->exec) {
         // the eager frame before this one sized every workspace buffer of this shape: nothing allocates under capture
         hipGraph_t g = nullptr;
@@ -4126,12 +4163,13 @@ extern "C" int rca_duplex_frame(rca_lm_t* h, rca_codec_t* codec, const rca_duple
     } else if ((rc = enqueue()) != RCA_OK) {
         return rc;
     }
-    ++ent->seen;
     RCA_HIP(hipStreamSynchronize(st));
-    // the eager run may have (re)allocated codec workspace: a graph captured later must be keyed by the signature after it
-    if (!want_graph) {
+    // the eager run may have (re)allocated codec workspace: graphs are keyed by the signature after it
+    if (!warmed) {
         uint64_t csig2 = 0;
         if ((rc = rca_codec_workspace_sig(codec, &csig2)) != RCA_OK) return rc;
+        if (d->warm.size() >= 16) d->warm.clear();
+        d->warm.push_back(DuplexState::Warm{a->T, a->F_ctx, n, a->n_samples, (const void*)codec, csig2});
         ent->key.codec_sig = csig2;
     }
     int done = n;

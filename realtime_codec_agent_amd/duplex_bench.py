@@ -29,7 +29,7 @@ def session_resources_kwargs(seed: int = 0, n_ctx: int = 16384, weight_format=No
 
 
 def run_duplex_bench(dev=None, secs: float = 125.0, chunk_size_secs: float = 0.08, n_ctx: int = 16384, lm_steps_probe: int = 64,
-                     max_context_secs: float = 80.0, trim_by_secs: float = 20.0, weight_format=None) -> dict:
+                     max_context_secs: float = 80.0, trim_by_secs: float = 20.0, weight_format=None, duplex_graph: bool = True) -> dict:
     import torch
     from .llm import LMConfig
     from .realtime_agent_config import RealtimeAgentConfig
@@ -43,6 +43,7 @@ def run_duplex_bench(dev=None, secs: float = 125.0, chunk_size_secs: float = 0.0
                                  max_context_secs=max_context_secs, trim_by_secs=trim_by_secs,
                                  force_trans_after_inactivity_secs=0.0, force_response_after_inactivity_secs=0.0)
     agent = RealtimeAgent(resources=res, config=config)
+    agent.use_duplex_graph = duplex_graph       # False: one replay per LM chunk between the separate codec calls (the round-2 path)
     load_s = time.perf_counter() - t0
     n = int(secs * 16000)
     sig = synth_signal(n, 0)
@@ -51,6 +52,7 @@ def run_duplex_bench(dev=None, secs: float = 125.0, chunk_size_secs: float = 0.0
     for s in range(0, 10 * cs, cs):
         agent.process_audio(sig[s:s + cs])
     agent.profilers.reset()
+    one_replay0 = agent.duplex_graph_frames
     t1 = time.perf_counter()
     nchunks = 0
     trims = []                                  # (audio second, frame latency ms, context tokens after the trim)
@@ -96,6 +98,7 @@ def run_duplex_bench(dev=None, secs: float = 125.0, chunk_size_secs: float = 0.0
         "trims_in_timed_window": trims,
         "kv_shadow": bool(getattr(agent, "kv_shadow_active", False)),
         "frame_graph": bool(getattr(agent, "frame_graph_active", False)),
+        "one_replay_frames": agent.duplex_graph_frames - one_replay0,   # frames that ran as ONE graph replay (rca_duplex_frame)
         "stage_p50_ms": {k: v.get("p50") for k, v in summ.items()},
         "frames": nchunks,
         "lm_step_ms": lm_ms,
