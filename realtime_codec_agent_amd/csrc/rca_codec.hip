@@ -300,7 +300,7 @@ struct ConvBOff {
 #define RCA_ABL_BREAD(x) (x)
 #endif
 template <int KS, int S, int CIC, int WM, int WN, int FUSE, int TR>
-__global__ __launch_bounds__(64 * RCA_CONV_WPB, ((KS == 8 && CIC == 2) || (KS == 16 && CIC == 1)) ? 3 : RCA_CONV_OCC) void conv1d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+__global__ __launch_bounds__(64 * RCA_CONV_WPB, (((KS == 8 && CIC == 2) || (KS == 16 && CIC == 1)) && WM * WN < 8) ? 3 : RCA_CONV_OCC) void conv1d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           int Cin, int Lin, int Cout, int Lout, long Ncols, int nchunks,
                                                           int pre, float slope, FuseIn fin, TrInfo tr) {
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, ((KS == 8 && CIC == 2) || (KS ==
         for (int wm = 0; wm < WM; ++wm) pn[wm] = w_ptr(wm, cn);
         // the B fragments of (half) a chunk are requested up front; the MFMAs then consume them in order
         // behind counted lgkmcnt waits, so the matrix pipe is not re-stalled on LDS latency every k step
-        constexpr int NB = (KPC * WN > 32) ? ((KPC % 4 == 0) ? 4 : 2) : 1;  // register budget for the fragment prefetch
+        constexpr int NB = (KPC * WN > 32) ? ((KPC % 4 == 0) ? 4 : 2) : (KPC * WN == 32 && WN == 4) ? 2 : 1;  // register budget for the fragment prefetch
         constexpr int PB = KPC / NB;
         static_assert(KPC % NB == 0, "batching");
 #pragma unroll
@@ -1893,9 +1893,23 @@ static int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B,
     const FuseIn none{};
     const TrInfo notr{};
     if (fuse) {
+        // The fused first layer (K = 128: an 8-chunk loop of ~20 us between ~9 us of prologue + epilogue) runs 64 x 128 wave tiles on
+        // 2-channel chunks: the prologue is paid once per 128 columns and the loop is 16 chunks of the same 32 MFMAs (249 VGPRs, no
+        // spills; the packed weights are the same array, Kpad does not change).  719 -> 664 us per launch of the 256-window step,
+        // bit-identical.  RCA_FUSE_WIDE=0 brings the 64 x 64 tiles back (A/B).
+        static const bool wide = []() { const char* e = getenv("RCA_FUSE_WIDE"); return !(e && e[0] == '0'); }();
+        if constexpr (KS == 4 && S == 2) {
+            if (wide && waves_big >= BIG_MIN && Lout >= 131 && L.cin % 2 == 0) {
+                launch_conv_cfg<4, 2, 2, 2, 4, 1, 0>(L, L.wp, L.cin / 2, x, y, Lin, Lout, Ncols, slope, *fuse, notr, st, act);
+                RCA_LAUNCH_CHECK();
+                return RCA_OK;
+            }
+        }
         if (waves_big >= BIG_MIN) launch_conv_cfg<KS, S, CIC, 2, 2, 1, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, *fuse, notr, st, act);
         else launch_conv_cfg<KS, S, CIC, 1, 1, 1, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, *fuse, notr, st, act);
     } else {
+        // (64 x 128 tiles on the k8s4 layer, <8, 4, 2, 2, 4>: 252 VGPRs, no spills, 1048 vs 1041 us -- its prologue is 7 % of a wave's
+        //  life, not 30 %: not kept)
         if (waves_big >= BIG_MIN) launch_conv_cfg<KS, S, CIC, 2, 2, 0, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, none, notr, st, act);
         else if (waves_big >= MID_MIN) launch_conv_cfg<KS, S, CIC, 1, 2, 0, 0>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, none, notr, st, act);
         // the stride-1 k = 3 layers have a short reduction per column tile: 64 x 32 wave tiles (half the staging per MFMA of 32 x 32)
