@@ -167,6 +167,7 @@ def main():
     ap.add_argument("--no-duplex", action="store_true")
     ap.add_argument("--no-cli-leg", action="store_true", help="skip the batch-CLI leg (audio_to_codes on a synthetic corpus of short files)")
     ap.add_argument("--no-trim-leg", action="store_true", help="skip the receptive-field-trimmed batch leg (profiling runs: keeps per-kernel averages to the headline path)")
+    ap.add_argument("--no-bf16-leg", action="store_true", help="skip the opt-in bf16-MFMA encoder legs (rca_codec_set_mfma_mode)")
     ap.add_argument("--duplex-secs", type=float, default=125.0,
                     help="audio seconds of the duplex leg; >= 110 puts two sliding-window trims (80 s context, trim by 20 s) inside the timed window")
     ap.add_argument("--variant", type=int, default=1)
@@ -275,6 +276,37 @@ def main():
         trim_identical = bool(torch.equal(codes, codes_full))
         assert trim_identical, "window-trimmed batch encode produced different codes"
 
+    # Opt-in arithmetic legs (reported beside the headline, never as `value`): the same steps with the encoder's conv layers on the
+    # bf16 matrix instruction -- operands split into bf16 hi + lo (mode 3) or rounded to bf16 like the reference's bf16 autocast
+    # (mode 1, audio_tokenizer.py:24,78-82).  Not bit-exact: the fraction of code ids equal to the f32 path is measured here.
+    bf16_legs = None
+    if not args.no_bf16_leg:
+        bf16_legs = {}
+        codes_f32 = codes.clone()
+        for mode, name in ((3, "bf16_hi_lo_split"), (1, "bf16_rounded")):
+            hip.set_mfma_mode(mode)
+            for i in range(args.warmup):
+                step(i)
+            torch.cuda.synchronize(dev)
+            if dist is not None:
+                dist.barrier()
+            t0 = time.perf_counter()
+            for i in range(args.warmup, total_steps):
+                step(i)
+            torch.cuda.synchronize(dev)
+            if dist is not None:
+                dist.barrier()
+            el = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            eq = float((codes == codes_f32).double().mean().item())
+            bf16_legs[name] = {"value": world * args.steps * chunks_per_step * chunk / cfg.sample_rate / el, "unit": "audio-hours/hour",
+                               "ms_per_step": 1e3 * el / args.steps, "code_ids_equal_to_f32_path": eq, "mfma_mode": mode}
+        hip.set_mfma_mode(0)
+        codes.copy_(codes_f32)
+
     prof = {k: hip.profile_read(k) for k in (0, 1, 2, 3)}
     audio_secs = args.steps * chunks_per_step * chunk / cfg.sample_rate  # per rank, stereo seconds
     value = world * audio_secs / elapsed
@@ -310,6 +342,7 @@ def main():
             "codebook": f"{cfg.codebook_size}x{cfg.codebook_dim}",
             "encoder_gflop_per_window": cfg.encoder_flops_per_sample() * ctx / 1e9,
             "sharding": "chunk ranges per rank, no collective (replicas only)",
+            "bf16_mfma_opt_in": bf16_legs,
             "receptive_field_trimmed": None if args.no_trim_leg else {
                 "value": world * audio_secs / elapsed_trim, "unit": "audio-hours/hour", "ms_per_step": 1e3 * elapsed_trim / args.steps,
                 "codes_identical_to_full_windows": trim_identical,

@@ -153,6 +153,12 @@ int rca_codec_decode_tail_dev(rca_codec_t* h, const int64_t* codes_dev, int32_t 
 int rca_codec_encode_tail(rca_codec_t* h, const float* pcm_host, int32_t B, int32_t T, int32_t n_keep, int64_t* codes_host);
 int rca_codec_decode_tail(rca_codec_t* h, const int64_t* codes_host, int32_t B, int32_t F, int32_t n_samples, float* pcm_host);
 int rca_codec_set_stream_graphs(rca_codec_t* h, int32_t enable);
+/* Opt-in arithmetic of the encoder's MFMA conv layers (never the default; the default, 0, is the f32 matrix instruction whose
+ * results equal the oracle's fma chains bit for bit).  3: bf16 matrix instruction on operands split into bf16 hi + lo (three
+ * products per step, ~2^-16 relative); 1: operands rounded to bf16, one product -- the arithmetic class of the reference's own GPU
+ * path, bf16 autocast (audio_tokenizer.py:24,78-82).  Neither is bit-exact: ids can differ from mode 0 near ties (bench.py reports
+ * the measured fraction).  Decoder and streaming-tail kernels are not affected. */
+int rca_codec_set_mfma_mode(rca_codec_t* h, int32_t mode);
 /* whole frames a kept code / a kept sample can see to its left */
 int rca_codec_receptive_field(const rca_codec_t* h, int32_t* enc_left_frames, int32_t* dec_left_frames);
 /* Batch windows (rca_codec_encode_windows_dev / _chunk_range_dev): when enabled, each window is cut down to the

@@ -94,6 +94,10 @@ class HipCodec:
                 "rca_codec_decode_tail")
         return pcm
 
+    def set_mfma_mode(self, mode: int) -> None:
+        """Encoder conv arithmetic: 0 = f32 matrix instruction (bit-exact, default), 3 = bf16 hi + lo split, 1 = bf16 (opt-in, not bit-exact)."""
+        N.check(self._lib.rca_codec_set_mfma_mode(self._h, int(mode)), "rca_codec_set_mfma_mode")
+
     def set_stream_graphs(self, enable: bool) -> None:
         N.check(self._lib.rca_codec_set_stream_graphs(self._h, int(bool(enable))), "rca_codec_set_stream_graphs")
 

@@ -299,7 +299,31 @@ struct ConvBOff {
 #else
 #define RCA_ABL_BREAD(x) (x)
 #endif
-template <int KS, int S, int CIC, int WM, int WN, int FUSE, int TR>
+// BF (opt-in, rca_codec_set_mfma_mode; never the default): the same kernel with the products on v_mfma_f32_32x32x16_bf16 instead of
+// v_mfma_f32_32x32x2_f32.  Staging, LDS window, weight fragments and B reads are unchanged -- a lane already holds the operand of
+// k = 2 kp + half for every k pair kp, and an MFMA may pair its 16 k slots with any 16 k as long as A and B agree -- so eight k pairs
+// become ONE bf16 step: slot (half, j) <-> k = 2 (8 g + j) + half.  BF = 3: both operands split into bf16 hi + bf16 lo in registers,
+// three MFMAs per step (hi hi + hi lo + lo hi: ~2^-16 relative, the prefill GEMM's scheme); BF = 1: both operands rounded to bf16,
+// one MFMA (what the reference's bf16 autocast does, audio_tokenizer.py:24,78-82).  The matrix pipe's internal summation order is
+// not documented, so neither is bit-exact against the f32 fma chain: code ids near a tie can differ (measured and reported).
+typedef __bf16 conv_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 conv_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned conv_pack_bf16x2(float a, float b) {   // v_cvt_pk_bf16_f32: round to nearest even
+    const conv_bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+template <int BF>
+__device__ __forceinline__ void conv_split8(const float (&w)[8], uint4& hi, uint4& lo) {
+    unsigned ph[4], pl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ph[j] = conv_pack_bf16x2(w[2 * j], w[2 * j + 1]);
+        pl[j] = BF == 3 ? conv_pack_bf16x2(w[2 * j] - __uint_as_float(ph[j] << 16), w[2 * j + 1] - __uint_as_float(ph[j] & 0xffff0000u)) : 0u;
+    }
+    hi = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+    lo = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+}
+template <int KS, int S, int CIC, int WM, int WN, int FUSE, int TR, int BF = 0>
 __global__ __launch_bounds__(64 * RCA_CONV_WPB, (((KS == 8 && CIC == 2) || (KS == 16 && CIC == 1)) && WM * WN < 8) ? 3 : RCA_CONV_OCC) void conv1d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           int Cin, int Lin, int Cout, int Lout, long Ncols, int nchunks,
@@ -617,7 +641,7 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, (((KS == 8 && CIC == 2) || (KS =
     // measured per layer (same box, pipelined vs batched block): k16s8 950 vs 962 us, k8s4 1150 vs 1130, k10s5 1102 vs 1087, fused k4s2
     // 799 vs 788, k3 225 vs 220 -> the pipeline is used for the k = 16 layer only (all within a few per cent: the block is not
     // what bounds these layers)
-    constexpr bool PIPE = RCA_CONV_PIPE && !TR && KS == 16;
+    constexpr bool PIPE = RCA_CONV_PIPE && !TR && KS == 16 && BF == 0;
     constexpr int RD = KPC >= 8 ? 4 : 2;
     float bhead[RD][WN];
     auto read_head = [&](int buf) __attribute__((always_inline)) {
@@ -674,6 +698,55 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, (((KS == 8 && CIC == 2) || (KS =
         }
     };
 
+    // BF != 0: the chunk on the bf16 matrix instruction, eight k pairs per step (see the note above the kernel)
+    auto compute_b = [&](int buf, int cn, auto edge_tag) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        const float* xb = xs + buf * BUF;
+        constexpr int NG = (KPC + 7) / 8;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            uint4 bh[WN], bl[WN];
+#pragma unroll
+            for (int wn = 0; wn < WN; ++wn) {
+                float bv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int kp = g * 8 + i;
+                    bv[i] = kp < KPC ? xb[b_off(kp < KPC ? kp : 0) + wn * 32] : 0.0f;
+                    if (EDGE && kp < KPC && ((zmask[wn] >> kp) & 1u)) bv[i] = 0.0f;
+                }
+                conv_split8<BF>(bv, bh[wn], bl[wn]);
+            }
+#pragma unroll
+            for (int wm = 0; wm < WM; ++wm) {
+                float aw[8];
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const int q = 2 * g + qq;
+                    const float4 q4 = q < QPC ? a[wm][q < QPC ? q : 0] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    aw[4 * qq + 0] = q4.x; aw[4 * qq + 1] = q4.y; aw[4 * qq + 2] = q4.z; aw[4 * qq + 3] = q4.w;
+                }
+                uint4 ah, al;
+                conv_split8<BF>(aw, ah, al);
+                const conv_bf16x8 ahv = __builtin_bit_cast(conv_bf16x8, ah), alv = __builtin_bit_cast(conv_bf16x8, al);
+#pragma unroll
+                for (int wn = 0; wn < WN; ++wn) {
+                    const conv_bf16x8 bhv = __builtin_bit_cast(conv_bf16x8, bh[wn]);
+                    acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahv, bhv, acc[wm][wn], 0, 0, 0);
+                    if (BF == 3) {
+                        acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahv, __builtin_bit_cast(conv_bf16x8, bl[wn]), acc[wm][wn], 0, 0, 0);
+                        acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alv, bhv, acc[wm][wn], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const int q = 2 * g + qq;
+                    if (q < QPC) a[wm][q] = w_load(wm, cn, q);
+                }
+            }
+        }
+    };
+
     if (FUSE) stage_load(0);
     stage_write(0);
     __builtin_amdgcn_wave_barrier();
@@ -699,7 +772,8 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, (((KS == 8 && CIC == 2) || (KS =
         __builtin_amdgcn_sched_barrier(0);
         RCA_TL_STAMP(tb);
         __builtin_amdgcn_s_setprio(RCA_CONV_EPRIO);
-        if constexpr (PIPE) compute_p(0, c1, edge_tag);
+        if constexpr (BF != 0) compute_b(0, c1, edge_tag);
+        else if constexpr (PIPE) compute_p(0, c1, edge_tag);
         else compute_t(0, c1, edge_tag);
         __builtin_amdgcn_s_setprio(RCA_CONV_PRIO ? 3 : 2);  // staging phases run at raised priority (measured +2.4 %)
         __builtin_amdgcn_sched_barrier(0);
@@ -717,7 +791,8 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, (((KS == 8 && CIC == 2) || (KS =
         stage_load(c2);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(RCA_CONV_EPRIO);
-        if constexpr (PIPE) compute_p(1, c2, edge_tag);
+        if constexpr (BF != 0) compute_b(1, c2, edge_tag);
+        else if constexpr (PIPE) compute_p(1, c2, edge_tag);
         else compute_t(1, c2, edge_tag);
         __builtin_amdgcn_s_setprio(RCA_CONV_PRIO ? 3 : 2);
         __builtin_amdgcn_sched_barrier(0);
@@ -1553,6 +1628,7 @@ struct rca_codec {
     hipStream_t stream = nullptr;
     int hop = 1;
     int variant = 1;
+    int mfma_mode = 0;          // 0: f32 matrix instruction (bit-exact, default); 1 / 3: bf16 matrix instruction, rounded / hi + lo split (opt-in)
     bool lat_mode = false;      // streaming tail: LDS-staged scalar-chain kernels (set per call)
     // receptive-field margins (whole frames) left of a kept frame / sample, derived from the layer geometry
     int enc_left_frames = 0, dec_left_frames = 0;
@@ -1858,7 +1934,7 @@ extern "C" int rca_codec_sync(rca_codec_t* h) {
     return RCA_OK;
 }
 
-template <int KS, int S, int CIC, int WM, int WN, int FUSE, int TR>
+template <int KS, int S, int CIC, int WM, int WN, int FUSE, int TR, int BF = 0>
 static void launch_conv_cfg(const ConvLayer& L, const float* wp, int nchunks, const float* x, float* y, int Lin, int Lc, long Ncols,
                             float slope, const FuseIn& fin, const TrInfo& tr, hipStream_t st, int act) {
     constexpr int NT = RCA_CONV_WPB * WN * 32, MT = WM * 32;
@@ -1867,16 +1943,32 @@ static void launch_conv_cfg(const ConvLayer& L, const float* wp, int nchunks, co
     // 1-D grid: column tiles padded to a multiple of 8 (one per XCD), times the channel tiles (times the phases)
     const long col_tiles = (cdiv(Ncols, NT) + 7) / 8 * 8;
     dim3 grid((unsigned)(col_tiles * cdiv(L.cout, MT) * (TR ? tr.s : 1)));
-    conv1d_mfma_kernel<KS, S, CIC, WM, WN, FUSE, TR><<<grid, 64 * RCA_CONV_WPB, lds, st>>>(x, wp, L.bp, y, L.cin, Lin, L.cout, Lc, Ncols, nchunks, act, slope, fin, tr);
+    conv1d_mfma_kernel<KS, S, CIC, WM, WN, FUSE, TR, BF><<<grid, 64 * RCA_CONV_WPB, lds, st>>>(x, wp, L.bp, y, L.cin, Lin, L.cout, Lc, Ncols, nchunks, act, slope, fin, tr);
 }
 
 template <int KS, int S, int CIC>
 // act: bit 0 = LeakyReLU on the input while staging (the layer's pre-activation), bit 1 = LeakyReLU on the output before the
 // store (the NEXT layer's pre-activation, applied once by the producer: same values, see run_encoder)
 static int launch_conv_mfma(const ConvLayer& L, const float* x, float* y, int B, int Lin, int Lout, float slope, hipStream_t st,
-                            const FuseIn* fuse = nullptr, int act = -1) {
+                            const FuseIn* fuse = nullptr, int act = -1, int bf = 0) {
     if (act < 0) act = L.pre;
     const long Ncols = (long)B * Lout;
+    if (bf) {   // opt-in bf16 matrix path (rca_codec_set_mfma_mode): 64 x 64 tiles for large launches, 32 x 32 below
+        const FuseIn none_b{};
+        const TrInfo notr_b{};
+        const bool big = (long)cdiv(Ncols, 64) * cdiv(L.cout, 64) >= 2048;
+#define RCA_BF_LAUNCH(FU, BFM) do { \
+            if (big) launch_conv_cfg<KS, S, CIC, 2, 2, FU, 0, BFM>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, FU ? *fuse : none_b, notr_b, st, act); \
+            else launch_conv_cfg<KS, S, CIC, 1, 1, FU, 0, BFM>(L, L.wp, L.nchunks, x, y, Lin, Lout, Ncols, slope, FU ? *fuse : none_b, notr_b, st, act); } while (0)
+        if constexpr (KS == 4 || KS == 8 || KS == 16) {
+            if (fuse) { if (bf == 3) RCA_BF_LAUNCH(1, 3); else RCA_BF_LAUNCH(1, 1); RCA_LAUNCH_CHECK(); return RCA_OK; }
+        }
+        if (fuse) return fail(RCA_ERR_ARG, "internal: fused first layer of this shape has no bf16 instantiation");
+        if (bf == 3) RCA_BF_LAUNCH(0, 3); else RCA_BF_LAUNCH(0, 1);
+#undef RCA_BF_LAUNCH
+        RCA_LAUNCH_CHECK();
+        return RCA_OK;
+    }
     // wave tile 64 channels x 64 columns (two waves per SIMD, most reuse per staged element) while that yields at least ~4
     // rounds of workgroups on the chip's 512 slots; below that the last, partly filled round costs more than the reuse
     // gains and smaller wave tiles win (more workgroups, 3-4 waves per SIMD).  Measured on the k16s8 layer of the 256-window
@@ -2052,11 +2144,11 @@ static int run_conv(rca_codec* h, const ConvLayer& L, const float* x, float* y, 
         if (h->variant == 2 && try_conv_ws(L, x, y, B, Lin, Lout, slope, st, nullptr)) { RCA_LAUNCH_CHECK(); return RCA_OK; }
         const int act = ((L.pre && !in_activated) ? 1 : 0) | (want_post ? 2 : 0);
         if (post_done) *post_done = want_post;
-        if (L.k == 4 && L.s == 2) return launch_conv_mfma<4, 2, 4>(L, x, y, B, Lin, Lout, slope, st, nullptr, act);
-        if (L.k == 8 && L.s == 4) return launch_conv_mfma<8, 4, RCA_CIC_K8>(L, x, y, B, Lin, Lout, slope, st, nullptr, act);
-        if (L.k == 10 && L.s == 5) return launch_conv_mfma<10, 5, 4>(L, x, y, B, Lin, Lout, slope, st, nullptr, act);
-        if (L.k == 16 && L.s == 8) return launch_conv_mfma<16, 8, RCA_CIC_K16>(L, x, y, B, Lin, Lout, slope, st, nullptr, act);
-        if (L.k == 3 && L.s == 1) return launch_conv_mfma<3, 1, 8>(L, x, y, B, Lin, Lout, slope, st, nullptr, act);
+        if (L.k == 4 && L.s == 2) return launch_conv_mfma<4, 2, 4>(L, x, y, B, Lin, Lout, slope, st, nullptr, act, h->mfma_mode);
+        if (L.k == 8 && L.s == 4) return launch_conv_mfma<8, 4, RCA_CIC_K8>(L, x, y, B, Lin, Lout, slope, st, nullptr, act, h->mfma_mode);
+        if (L.k == 10 && L.s == 5) return launch_conv_mfma<10, 5, 4>(L, x, y, B, Lin, Lout, slope, st, nullptr, act, h->mfma_mode);
+        if (L.k == 16 && L.s == 8) return launch_conv_mfma<16, 8, RCA_CIC_K16>(L, x, y, B, Lin, Lout, slope, st, nullptr, act, h->mfma_mode);
+        if (L.k == 3 && L.s == 1) return launch_conv_mfma<3, 1, 8>(L, x, y, B, Lin, Lout, slope, st, nullptr, act, h->mfma_mode);
     }
     if (in_activated) return fail(RCA_ERR_ARG, "internal: activated input handed to a kernel without that mode");
     const long total = (long)B * L.cout * Lout;
@@ -2113,9 +2205,9 @@ static int run_encoder(rca_codec* h, RowSrc src, int B, hipStream_t st, float** 
             prev_post = handoff(2, Lout);
             const int act = (E1.pre ? 1 : 0) | (prev_post ? 2 : 0);
             if (h->variant == 2 && try_conv_ws(E1, nullptr, y, B, L, Lout, slope, st, &fin)) { rc = RCA_OK; RCA_LAUNCH_CHECK(); }
-            else if (E1.k == 4) rc = launch_conv_mfma<4, 2, 4>(E1, nullptr, y, B, L, Lout, slope, st, &fin, act);
-            else if (E1.k == 8) rc = launch_conv_mfma<8, 4, RCA_CIC_K8>(E1, nullptr, y, B, L, Lout, slope, st, &fin, act);
-            else rc = launch_conv_mfma<16, 8, RCA_CIC_K16>(E1, nullptr, y, B, L, Lout, slope, st, &fin, act);
+            else if (E1.k == 4) rc = launch_conv_mfma<4, 2, 4>(E1, nullptr, y, B, L, Lout, slope, st, &fin, act, h->mfma_mode);
+            else if (E1.k == 8) rc = launch_conv_mfma<8, 4, RCA_CIC_K8>(E1, nullptr, y, B, L, Lout, slope, st, &fin, act, h->mfma_mode);
+            else rc = launch_conv_mfma<16, 8, RCA_CIC_K16>(E1, nullptr, y, B, L, Lout, slope, st, &fin, act, h->mfma_mode);
         }
         if (rc != RCA_OK) return rc;
         L = Lout;
@@ -2576,7 +2668,7 @@ extern "C" int rca_codec_decode_tail(rca_codec_t* h, const int64_t* codes_host, 
 // the capture records no wait on an event from outside it.
 extern "C" int rca_codec_workspace_sig(rca_codec_t* h, uint64_t* sig) {
     if (!h || !sig) return fail(RCA_ERR_ARG, "null");
-    *sig = workspace_signature(h) * 1099511628211ull + (unsigned long long)h->variant;
+    *sig = (workspace_signature(h) * 1099511628211ull + (unsigned long long)h->variant) * 1099511628211ull + (unsigned long long)h->mfma_mode;
     return RCA_OK;
 }
 extern "C" int rca_codec_stream_handoff(rca_codec_t* h, void* stream) {
@@ -2590,6 +2682,19 @@ extern "C" int rca_codec_stream_handoff(rca_codec_t* h, void* stream) {
 extern "C" int rca_codec_codebook_size(const rca_codec_t* h, int32_t* n) {
     if (!h || !n) return fail(RCA_ERR_ARG, "null");
     *n = h->cfg.codebook_size;
+    return RCA_OK;
+}
+
+extern "C" int rca_codec_set_mfma_mode(rca_codec_t* h, int32_t mode) {
+    if (!h) return fail(RCA_ERR_ARG, "null");
+    if (mode != 0 && mode != 1 && mode != 3) return fail(RCA_ERR_ARG, "mfma mode %d (0 = f32 exact, 1 = bf16, 3 = bf16 hi + lo split)", mode);
+    if (mode != h->mfma_mode) {
+        RCA_HIP(hipSetDevice(h->device));
+        RCA_HIP(hipStreamSynchronize(h->stream));
+        for (auto& kv : h->sgraphs)      // captured tail calls hold the kernels of the old mode
+            if (kv.second.exec) { (void)hipGraphExecDestroy(kv.second.exec); kv.second.exec = nullptr; }
+    }
+    h->mfma_mode = mode;
     return RCA_OK;
 }
 

@@ -388,3 +388,28 @@ def test_batch_cli_cross_file_pipeline_equals_per_file_loop(tmp_path):
             bad = [k for k in ta if ta[k] != tb[k]]
             assert not bad, bad
             assert s1["codes"] == s2["codes"] > 0
+
+
+def test_bf16_mfma_modes_track_the_f32_path():
+    """Opt-in arithmetic (rca_codec_set_mfma_mode; never the default): the encoder's conv layers on the bf16 matrix instruction.  Mode 3
+    (operands split into bf16 hi + lo, three products per step) must reproduce the f32 path's last encoder activation to ~1e-4 of its
+    scale and almost all code ids; mode 1 (operands rounded to bf16, the arithmetic class of the reference's bf16 autocast) to ~2e-2.
+    Mode 0 afterwards is bit-exact again (the oracle-checked path is untouched)."""
+    from realtime_codec_agent_amd.codec import HipCodec
+    from realtime_codec_agent_amd.codec_model import CodecConfig, init_codec_weights
+    cfg = CodecConfig()
+    hip = HipCodec(cfg, init_codec_weights(cfg, seed=0), device=0)
+    B, T = 48, 32000
+    pcm = np.stack([rich_signal(T, 100 + b) for b in range(B)]).astype(np.float32)
+    last = len(cfg.strides) + 1          # conv_out
+    ref_codes, ref_tap = hip.encode(pcm), hip.encode_tap(pcm, last)
+    scale = float(np.abs(ref_tap).max())
+    for mode, tol, min_equal in ((3, 2e-4, 0.97), (1, 5e-2, 0.05)):
+        hip.set_mfma_mode(mode)
+        codes, tap = hip.encode(pcm), hip.encode_tap(pcm, last)
+        err = float(np.abs(tap - ref_tap).max()) / scale
+        equal = float((codes == ref_codes).mean())
+        print(f"mfma mode {mode}: max |diff| / max |act| = {err:.2e}, code ids equal = {equal:.4f}")
+        assert err < tol and equal >= min_equal
+    hip.set_mfma_mode(0)
+    assert np.array_equal(hip.encode(pcm), ref_codes) and np.array_equal(hip.encode_tap(pcm, last), ref_tap)
