@@ -821,6 +821,9 @@ __global__ __launch_bounds__(64 * RCA_CONV_WPB, (((KS == 8 && CIC == 2) || (KS =
     const long orow = TR ? tr.Lout : Lout;
     const bool full_rows = co0 + MT <= Cout;
     float* const yw = y + ((long)b_base * Cout + co0) * orow;
+    // (16-byte stores after a 4 x 4 transpose inside each quad of lanes -- two quad_perm butterflies, a quarter of the store
+    //  instructions -- were built and measured in round 3: bit-identical, slower on every layer (fused k4s2 689 vs 648 us, k8s4 1040
+    //  vs 1026): the 64 extra moves + selects per tile cost more next to the neighbour's MFMA stream than the stores they replace.)
 #pragma unroll
     for (int wn = 0; wn < WN; ++wn) {
         const int dn = 1 - lead + wn * 32 + (lane & 31);
