@@ -2543,10 +2543,12 @@ __global__ __launch_bounds__(512) void lm_attn_mfma_kernel(const LmDevState* __r
     ATL_STAMP(2);      // S, softmax, P V of this wave
     __syncthreads();   // every wave is done with vt: wo may overwrite it
     if (half == 0) { wm[wave][col] = mx; wl[wave][col] = lsum; }
+    // (a decode step has at most 8 live query rows -- registers 0..3 of the accumulators: the other 24 rows are never merged)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) wo[wave][(r & 3) + 8 * (r >> 2) + 4 * half][32 * nt + col] = oacc[nt][r];
+        for (int r = 0; r < 16; ++r)
+            if (r < 4 || !fused) wo[wave][(r & 3) + 8 * (r >> 2) + 4 * half][32 * nt + col] = oacc[nt][r];
     __syncthreads();
     // ---- merge the 8 waves, write the split partial (a decode step has M * G <= 8 live rows of the 32: the others are skipped)
     const int live_rows = fused ? M * G : 32;
