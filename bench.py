@@ -110,7 +110,10 @@ def batch_cli_leg(hours=0.5, seed=0):
                 w.writeframes((np.clip(sig.T, -1, 1) * 32767).astype("<i2").tobytes())
             total += secs
             i += 1
-        s = audio_to_codes.main(["--audio_path", raw, "--codes_path", os.path.join(root, "codes"), "--stereo"])
+        # the CLI prints its own JSON summary: keep it off stdout, which carries exactly ONE line (the bench contract)
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):
+            s = audio_to_codes.main(["--audio_path", raw, "--codes_path", os.path.join(root, "codes"), "--stereo"])
         return dict(value=s["audio_hours_per_hour"], unit="audio-hours/hour", files=i, audio_hours=total / 3600.0, elapsed_s=s["elapsed_s"],
                     note="audio_to_codes CLI end to end (read .wav, batch windows across files, encode, write .npy), one process")
     finally:
