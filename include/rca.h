@@ -243,7 +243,9 @@ typedef struct {
 } rca_lm_config_t;
 
 typedef struct {
-    int32_t top_k;   /* 1..256 (llama.cpp's <=0 = whole vocabulary is refused by rca_lm_sampler_init unless temp <= 0) */
+    int32_t top_k;   /* 1..256 ranked candidates, or <= 0 = llama.cpp's "whole vocabulary" (llamacpp_utils.py:39-77 passes top_k straight
+                        through): min_p -> temp -> softmax -> draw over every token by the Gumbel-max rule, top_p >= 1 only.  top_k > 256
+                        and top_k <= 0 with top_p < 1 are refused by rca_lm_sampler_init (never clamped); temp <= 0 is greedy whatever top_k */
     float top_p;     /* 1.0 = off */
     float min_p;     /* 0.0 = off */
     float temp;      /* <=0: greedy */

@@ -243,6 +243,8 @@ def _slib():
         _lib.oracle_sample.restype = C.c_int
         _lib.oracle_expf.restype = C.c_float
         _lib.oracle_expf.argtypes = [C.c_float]
+        _lib.oracle_logf.restype = C.c_float
+        _lib.oracle_logf.argtypes = [C.c_float]
     return _lib
 
 
@@ -258,3 +260,7 @@ def sample(logits: np.ndarray, top_k: int, top_p: float, min_p: float, temp: flo
 
 def expf(x: float) -> float:
     return float(_slib().oracle_expf(C.c_float(x)))
+
+
+def logf(x: float) -> float:
+    return float(_slib().oracle_logf(C.c_float(x)))

@@ -9,6 +9,11 @@
  * discrete_distribution) cannot be reproduced from the reference; the reference holds no sampled
  * golden tokens.  This file pins THIS build's sampler definition: exact top-k by (logit desc,
  * index asc), polynomial exp in fma, counter-based splitmix64 RNG, inverse-CDF draw.
+ * top_k <= 0 is llama.cpp's "whole vocabulary" (its top-k sampler is then a no-op): with top_p >= 1 the draw from
+ * softmax(logits / temp) over every token that passes min_p is made by the Gumbel-max rule -- argmax of
+ * (v_i - max) / temp + g_i with g_i = -log(-log(u_i)), u_i from the counter RNG keyed by (seed, draw, token) -- which has
+ * exactly that distribution and needs no sort of 259 k candidates; polynomial log in fma so that device and host agree
+ * bit for bit.  top_k <= 0 with top_p < 1 is not defined here (the device refuses it).
  */
 #include <math.h>
 #include <stdint.h>
@@ -27,6 +32,34 @@ float oracle_expf(float x) {
     p = fmaf(p, r, 1.0f);
     p = fmaf(p, r, 1.0f);
     return ldexpf(p, (int)n);
+}
+
+/* natural log of a positive normal float: cephes' logf polynomial written as explicit fmas */
+float oracle_logf(float x) {
+    union { float f; uint32_t u; } b;
+    b.f = x;
+    int e = (int)(b.u >> 23) - 127;
+    b.u = (b.u & 0x007FFFFFu) | 0x3F800000u;
+    float m = b.f;
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    const float f = m - 1.0f;
+    const float z = f * f;
+    float y = 7.0376836292e-2f;
+    y = fmaf(y, f, -1.1514610310e-1f);
+    y = fmaf(y, f, 1.1676998740e-1f);
+    y = fmaf(y, f, -1.2420140846e-1f);
+    y = fmaf(y, f, 1.4249322787e-1f);
+    y = fmaf(y, f, -1.6668057665e-1f);
+    y = fmaf(y, f, 2.0000714765e-1f);
+    y = fmaf(y, f, -2.4999993993e-1f);
+    y = fmaf(y, f, 3.3333331174e-1f);
+    y = y * f * z;
+    const float fe = (float)e;
+    y = fmaf(fe, -2.12194440e-4f, y);
+    y = fmaf(z, -0.5f, y);
+    float r = f + y;
+    r = fmaf(fe, 0.693359375f, r);
+    return r;
 }
 
 uint64_t oracle_splitmix(uint64_t seed, uint64_t ctr) {
@@ -55,8 +88,27 @@ int oracle_sample(const float* logits, int V, int top_k, float top_p, float min_
             if (bias_ids[b] == i) v = v + bias_vals[b];
         c[i].v = v; c[i].idx = i;
     }
-    qsort(c, (size_t)V, sizeof(cand_t), cmp_cand);
     const int greedy = temp <= 0.0f;
+    if (!greedy && top_k <= 0) {   /* whole vocabulary: Gumbel-max over every token that passes min_p */
+        if (top_p < 1.0f) { free(c); return -1; }
+        float mx = c[0].v;
+        for (int i = 1; i < V; ++i) if (c[i].v > mx) mx = c[i].v;
+        const float inv_t = 1.0f / temp;
+        const uint64_t draw = oracle_splitmix((uint64_t)seed, counter);
+        int best = -1; float best_key = 0.0f;
+        for (int i = 0; i < V; ++i) {
+            const float d = c[i].v - mx;
+            if (min_p > 0.0f && !(oracle_expf(d) >= min_p)) continue;
+            const uint64_t z = oracle_splitmix(draw, (uint64_t)i);
+            const float u = (float)(uint32_t)(((z >> 41) << 1) | 1u) * 5.9604644775390625e-08f;   /* odd / 2^24: strictly inside (0, 1) */
+            const float g = -oracle_logf(-oracle_logf(u));
+            const float key = fmaf(d, inv_t, g);
+            if (best < 0 || key > best_key) { best = i; best_key = key; }   /* ties: lowest index */
+        }
+        free(c);
+        return best;
+    }
+    qsort(c, (size_t)V, sizeof(cand_t), cmp_cand);
     int k = greedy ? 1 : top_k;
     if (k <= 0 || k > 256) k = 256;
     if (k > V) k = V;

@@ -899,6 +899,31 @@ __device__ __forceinline__ unsigned long long splitmix(unsigned long long seed, 
     z ^= z >> 31;
     return z;
 }
+// natural log of a positive normal float: cephes' logf polynomial as explicit fmas (the oracle's oracle_logf, bit for bit)
+__device__ __forceinline__ float rca_logf(float x) {
+    unsigned u = __float_as_uint(x);
+    int e = (int)(u >> 23) - 127;
+    float m = __uint_as_float((u & 0x007FFFFFu) | 0x3F800000u);
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    const float f = m - 1.0f;
+    const float z = f * f;
+    float y = 7.0376836292e-2f;
+    y = __builtin_fmaf(y, f, -1.1514610310e-1f);
+    y = __builtin_fmaf(y, f, 1.1676998740e-1f);
+    y = __builtin_fmaf(y, f, -1.2420140846e-1f);
+    y = __builtin_fmaf(y, f, 1.4249322787e-1f);
+    y = __builtin_fmaf(y, f, -1.6668057665e-1f);
+    y = __builtin_fmaf(y, f, 2.0000714765e-1f);
+    y = __builtin_fmaf(y, f, -2.4999993993e-1f);
+    y = __builtin_fmaf(y, f, 3.3333331174e-1f);
+    y = y * f * z;
+    const float fe = (float)e;
+    y = __builtin_fmaf(fe, -2.12194440e-4f, y);
+    y = __builtin_fmaf(z, -0.5f, y);
+    float r = f + y;
+    r = __builtin_fmaf(fe, 0.693359375f, r);
+    return r;
+}
 __device__ __forceinline__ unsigned long long sample_key(float v, unsigned idx) {
     unsigned u = __float_as_uint(v);
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -1152,6 +1177,91 @@ __global__ __launch_bounds__(1024) void samp_final_kernel(const float* __restric
     for (int b = tid; b < SAMP_BINS; b += 1024) w->hist[b] = 0u;
     if (tid == 0) { w->ncand = 0u; w->overflow = 0u; }
     if (tail.frame_i >= 0) {   // lm_embed_kernel for the next pair (m = 2)
+        const int id1 = stt->ids[LM_FRAME_USER0 + tail.frame_i];
+        for (int e = tid; e < 2 * tail.H; e += 1024) {
+            const int m = e / tail.H, hh = e - m * tail.H;
+            int id = m == 0 ? s_tok : id1;
+            id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+            tail.x[e] = tail.f32tab ? reinterpret_cast<const float*>(tail.table)[(long)id * tail.H + hh]
+                                    : __uint_as_float((unsigned)reinterpret_cast<const bf16_t*>(tail.table)[(long)id * tail.H + hh] << 16);
+        }
+    }
+}
+
+// ---- top_k <= 0: llama.cpp's "whole vocabulary" (its top-k sampler is then a no-op; llamacpp_utils.py:39-77 passes top_k straight
+// through).  With top_p >= 1 the chain is min_p -> temp -> softmax -> draw over every token, and that draw is made by the Gumbel-max
+// rule: token = argmax_i (v_i - max) / temp + g_i over the tokens that pass min_p, g_i = -log(-log(u_i)), u_i from the counter RNG
+// keyed by (seed, draw, token).  Same distribution, no sort of 259 k candidates, one pass; ties go to the lowest index.  Three launches
+// like the top-k sampler: slice maxima, slice winners, merge + the sampler tail.  (top_k <= 0 with top_p < 1 is refused at init.)
+#define SAMPF_SLICES 64
+__global__ __launch_bounds__(1024) void samp_full_max_kernel(const float* __restrict__ logits, int V, const SamplerDev* __restrict__ sp,
+                                                             SampWork* __restrict__ w) {
+    __shared__ float red[16];
+    const int per = (V + SAMPF_SLICES - 1) / SAMPF_SLICES;
+    const int i0 = blockIdx.x * per, i1 = min(V, i0 + per);
+    float mx = -INFINITY;
+    for (int i = i0 + threadIdx.x; i < i1; i += 1024) mx = fmaxf(mx, samp_value(logits, sp, i));
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = red[0];
+        for (int k = 1; k < 16; ++k) m = fmaxf(m, red[k]);
+        reinterpret_cast<float*>(w->hist)[blockIdx.x] = m;     // the histogram area is free in this mode (and re-zeroed by the merge)
+    }
+}
+__global__ __launch_bounds__(1024) void samp_full_pick_kernel(const float* __restrict__ logits, int V, const SamplerDev* __restrict__ sp,
+                                                              const LmDevState* __restrict__ stt, SampWork* __restrict__ w) {
+    __shared__ unsigned long long red[16];
+    const float* smax = reinterpret_cast<const float*>(w->hist);
+    float mx = smax[0];
+    for (int k = 1; k < SAMPF_SLICES; ++k) mx = fmaxf(mx, smax[k]);
+    const float inv_t = 1.0f / sp->temp, min_p = sp->min_p;
+    const unsigned long long draw = splitmix(sp->seed, stt->rng_counter);
+    const int per = (V + SAMPF_SLICES - 1) / SAMPF_SLICES;
+    const int i0 = blockIdx.x * per, i1 = min(V, i0 + per);
+    unsigned long long best = 0ull;   // below every real key (a real key has bit 63 or bits of ~u set... see sample_key: never 0 with idx < 2^32 - 1)
+    for (int i = i0 + threadIdx.x; i < i1; i += 1024) {
+        const float d = samp_value(logits, sp, i) - mx;
+        if (min_p > 0.0f && !(rca_expf(d) >= min_p)) continue;
+        const unsigned long long z = splitmix(draw, (unsigned long long)i);
+        const float u = (float)(unsigned)(((z >> 41) << 1) | 1ull) * 5.9604644775390625e-08f;
+        const float g = -rca_logf(-rca_logf(u));
+        const unsigned long long key = sample_key(__builtin_fmaf(d, inv_t, g), (unsigned)i);
+        best = key > best ? key : best;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off);
+        best = o > best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = red[0];
+        for (int k = 1; k < 16; ++k) b = red[k] > b ? red[k] : b;
+        w->cand[blockIdx.x] = b;
+    }
+}
+__global__ __launch_bounds__(1024) void samp_full_final_kernel(int V, LmDevState* __restrict__ stt, SampWork* __restrict__ w, SampTail tail) {
+    __shared__ int s_tok;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        unsigned long long b = w->cand[0];
+        for (int k = 1; k < SAMPF_SLICES; ++k) b = w->cand[k] > b ? w->cand[k] : b;
+        const int tok = (int)(0xFFFFFFFFu - (unsigned)(b & 0xFFFFFFFFull));
+        stt->rng_counter += 1ull;
+        stt->out_token = tok;
+        if (tail.frame_i >= 0) {
+            stt->frame_out[tail.frame_i] = tok;
+            stt->n_tokens += 2;
+            stt->ids[0] = tok;
+            stt->ids[1] = stt->ids[LM_FRAME_USER0 + tail.frame_i];
+        }
+        s_tok = tok;
+    }
+    __syncthreads();
+    for (int b = tid; b < SAMPF_SLICES; b += 1024) w->hist[b] = 0u;   // the top-k sampler expects a zeroed histogram
+    if (tail.frame_i >= 0) {   // lm_embed_kernel for the next pair (m = 2), as in samp_final_kernel
         const int id1 = stt->ids[LM_FRAME_USER0 + tail.frame_i];
         for (int e = tid; e < 2 * tail.H; e += 1024) {
             const int m = e / tail.H, hh = e - m * tail.H;
@@ -1522,6 +1632,7 @@ struct rca_lm {
     LmDevState* h_stt = nullptr;   // pinned host staging (ids, n_tokens, m in; out_token back)
     int n_tokens = 0;           // host mirror (llama_cpp.Llama.n_tokens)
     bool sampler_set = false;
+    bool samp_full = false;     // top_k <= 0: the whole-vocabulary (Gumbel-max) sampler launches instead of the top-k ones
     // captured steady-state steps (n = 1, 2)
     // decode-step graphs per (tokens 1..2, context bucket): bucket b launches min(n_splits, 4 << b) attention splits
     // Two sets: the handle's KV cache can be exchanged with a twin's (rca_lm_swap_kv) and the cache address is baked into the
@@ -3758,8 +3869,11 @@ extern "C" int rca_lm_sampler_init(rca_lm_t* h, const rca_sampler_params_t* p) {
     if (p->n_bias < 0 || p->n_bias > 8) return fail(RCA_ERR_ARG, "at most 8 logit-bias entries");
     // llama.cpp reads top_k <= 0 as "whole vocabulary"; the device sampler ranks at most SAMP_MAXK candidates, so anything it
     // cannot honour is refused instead of being clamped silently (greedy, temp <= 0, needs one candidate whatever top_k says)
-    if (p->temp > 0.0f && (p->top_k <= 0 || p->top_k > SAMP_MAXK))
-        return fail(RCA_ERR_ARG, "sampler: top_k %d unsupported (1..%d; top_k <= 0 = whole vocabulary is not implemented)", p->top_k, SAMP_MAXK);
+    if (p->temp > 0.0f && p->top_k > SAMP_MAXK)
+        return fail(RCA_ERR_ARG, "sampler: top_k %d unsupported (1..%d, or <= 0 = whole vocabulary)", p->top_k, SAMP_MAXK);
+    if (p->temp > 0.0f && p->top_k <= 0 && p->top_p < 1.0f)
+        return fail(RCA_ERR_ARG, "sampler: top_k %d (whole vocabulary) with top_p %g < 1 is not implemented (top_p >= 1 is; min_p and temp apply)", p->top_k, (double)p->top_p);
+    const bool full = p->temp > 0.0f && p->top_k <= 0;
     RCA_HIP(hipSetDevice(h->device));
     SamplerDev s;
     memset(&s, 0, sizeof(s));
@@ -3772,6 +3886,8 @@ extern "C" int rca_lm_sampler_init(rca_lm_t* h, const rca_sampler_params_t* p) {
     RCA_HIP(hipMemcpy(&h->stt->rng_counter, &zero, 8, hipMemcpyHostToDevice));
     h->rng_host = 0;
     h->sampler_set = true;
+    if (full != h->samp_full) lm_drop_graphs(h);   // the captured steps hold the other sampler's launches
+    h->samp_full = full;
     return RCA_OK;
 }
 
@@ -3779,6 +3895,12 @@ extern "C" int rca_lm_sampler_init(rca_lm_t* h, const rca_sampler_params_t* p) {
 static void lm_enqueue_sample(rca_lm* h, const float* lg, hipStream_t st, int frame_i = -1) {
     const int V = h->cfg.vocab_size;
     const SampTail tail{frame_i, h->embed, h->embed_f32, h->x, h->cfg.hidden};
+    if (h->samp_full) {   // top_k <= 0: whole vocabulary (Gumbel-max)
+        samp_full_max_kernel<<<SAMPF_SLICES, 1024, 0, st>>>(lg, V, h->samp, h->swork);
+        samp_full_pick_kernel<<<SAMPF_SLICES, 1024, 0, st>>>(lg, V, h->samp, h->stt, h->swork);
+        samp_full_final_kernel<<<1, 1024, 0, st>>>(V, h->stt, h->swork, tail);
+        return;
+    }
     samp_hist_kernel<<<128, 256, 0, st>>>(lg, V, h->samp, h->swork);
     samp_gather_kernel<<<128, 256, 0, st>>>(lg, V, h->samp, h->swork);
     samp_final_kernel<<<1, 1024, 0, st>>>(lg, V, h->samp, h->stt, h->swork, tail);

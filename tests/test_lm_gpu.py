@@ -152,6 +152,49 @@ def test_sampler_matches_restatement_and_graph_equals_eager():
     assert g2 != g and g2 == int(np.argsort(-llm._scores[-1], kind="stable")[1])
 
 
+@pytest.mark.parametrize("min_p,temp", [(0.0, 1.0), (0.02, 0.7)])
+def test_whole_vocabulary_sampler_matches_restatement(min_p, temp):
+    """llama.cpp's top_k <= 0 = whole vocabulary (llamacpp_utils.py:39-77 passes top_k straight through): the device draws by the
+    Gumbel-max rule over every token that passes min_p -- token for token the C restatement's choice, eagerly, as graph replays and
+    inside a frame graph; switching between the top-k and the whole-vocabulary sampler on one handle keeps both right."""
+    llm, w, ids = make_llm("llama3")
+    params = dict(top_k=0, top_p=1.0, min_p=min_p, temp=temp, seed=23)
+    seqs = []
+    for use_graph in (True, False):
+        llm.set_graphs(use_graph)
+        llm.reset()
+        llm.init_sampler_for_generate(**params)
+        llm.eval(ids[:9].tolist())
+        toks, out = ids[9:11].tolist(), []
+        for step in range(24):
+            t = llm.step(toks)
+            want = lm_ref.sample(llm._scores[-1], 0, 1.0, min_p, temp, 23, step)
+            assert t == want, (step, t, want)
+            out.append(t)
+            toks = [t, int(ids[9 + (step % 20)])]
+        seqs.append(out)
+    assert seqs[0] == seqs[1] and len(set(seqs[0])) > 6
+    # the frame graph: 4 steps with the sampled token fed back on the device == the same 4 single steps
+    llm.set_graphs(True)
+    llm.reset(); llm.init_sampler_for_generate(**params); llm.eval(ids[:9].tolist())
+    user = [int(ids[9 + i]) for i in range(4)]
+    got = llm.frame(ids[9:11].tolist(), user, -1)
+    assert got == [seqs[0][0]] + got[1:] and len(got) == 4
+    llm.reset(); llm.init_sampler_for_generate(**params); llm.eval(ids[:9].tolist())
+    toks, single = ids[9:11].tolist(), []
+    for i in range(4):
+        t = llm.step(toks)
+        single.append(t)
+        toks = [t, user[i]]
+    assert got == single
+    # back to top-k on the same handle (the graphs of the other sampler were dropped), then whole vocabulary again
+    llm.reset(); llm.init_sampler_for_generate(top_k=20, top_p=1.0, min_p=0.0, temp=1.0, seed=42); llm.eval(ids[:9].tolist())
+    t = llm.step(ids[9:11].tolist())
+    assert t == lm_ref.sample(llm._scores[-1], 20, 1.0, 0.0, 1.0, 42, 0)
+    llm.reset(); llm.init_sampler_for_generate(**params); llm.eval(ids[:9].tolist())
+    assert llm.step(ids[9:11].tolist()) == seqs[0][0]
+
+
 def test_logits_all_and_get_logprobs():
     llm, w, ids = make_llm("llama3", logits_all=True)
     ref = lm_ref.LMRef(tiny_cfg("llama3"), w, kv_dtype=torch.float16)
@@ -194,13 +237,14 @@ def test_step_graphs_survive_a_logits_all_excursion():
 
 
 def test_sampler_and_token_ids_are_validated():
-    """llama.cpp reads top_k <= 0 as 'whole vocabulary'; the device sampler cannot, so it refuses instead of clamping.  Token ids
-    outside the vocabulary are an error, not a clamped embedding row."""
+    """top_k outside what the device sampler implements is refused, never clamped: more than 256 ranked candidates, and llama.cpp's
+    'whole vocabulary' (top_k <= 0) combined with top_p < 1 (top_k <= 0 with top_p >= 1 is implemented, next test).  Token ids outside the
+    vocabulary are an error, not a clamped embedding row."""
     from realtime_codec_agent_amd._native import RcaError
     llm, w, ids = make_llm("default")
-    for bad in (0, -1, 257):
+    for bad in (dict(top_k=257, top_p=1.0), dict(top_k=0, top_p=0.9), dict(top_k=-1, top_p=0.5)):
         with pytest.raises(RcaError):
-            llm.init_sampler_for_generate(top_k=bad, top_p=1.0, min_p=0.0, temp=1.0, seed=1)
+            llm.init_sampler_for_generate(min_p=0.0, temp=1.0, seed=1, **bad)
     llm.init_sampler_for_generate(top_k=0, top_p=1.0, min_p=0.0, temp=0.0, seed=1)      # greedy ignores top_k
     llm.init_sampler_for_generate(top_k=256, top_p=1.0, min_p=0.0, temp=1.0, seed=1)
     llm.eval(ids[:4].tolist())
