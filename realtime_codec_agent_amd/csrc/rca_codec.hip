@@ -1268,6 +1268,7 @@ __global__ __launch_bounds__(64 * NW) void conv1d_lds_kernel(const float* __rest
 // ws[kk][CP] like the input: four 16-byte reads per four channels (eight steps).
 template <int S, int NW>
 __global__ __launch_bounds__(64 * NW) void convtr1d_lds_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ wt,
                                                                const float* __restrict__ bias, float* __restrict__ y, int Cin,
                                                                int Lin, int Cout, int NC, int NTI, float slope, int pre) {
     extern __shared__ __attribute__((aligned(16))) float lds_sm[];
@@ -1295,6 +1296,18 @@ __global__ __launch_bounds__(64 * NW) void convtr1d_lds_kernel(const float* __re
         if (pre) v = lrelu(v, slope);
         xs[j * CP + ci] = v;
     }
+    if (wt && (Cin & 3) == 0) {
+        // tap-major copy w_lat[co][k][ci] (packed at load): the NW x K rows of this workgroup are one contiguous run in memory and
+        // land in LDS as 16-byte stores (the [ci][co][k] original costs a 16-byte load per 64-byte line and four scalar LDS stores)
+        const int c4 = Cin >> 2;
+#pragma unroll 8
+        for (int e = tid; e < NW * K * c4; e += NT) {
+            const int row = e / c4, q = e - row * c4;      // row = wv * K + kk
+            const int wv = row / K, kk = row - wv * K;
+            const int co = min(co0 + wv, Cout - 1);
+            *reinterpret_cast<f32x4*>(ws + (long)row * CP + 4 * q) = *reinterpret_cast<const f32x4*>(wt + ((long)co * K + kk) * Cin + 4 * q);
+        }
+    } else {
     constexpr int VW = (K % 4 == 0) ? 4 : 2;      // the K = 2S taps of one (ci, co) are contiguous: 16- or 8-byte loads
     constexpr int KV = K / VW;
     typedef float fvw __attribute__((ext_vector_type(VW)));
@@ -1307,6 +1320,7 @@ __global__ __launch_bounds__(64 * NW) void convtr1d_lds_kernel(const float* __re
         const fvw v = *reinterpret_cast<const fvw*>(w + ((long)ci * Cout + co) * K + kq);
 #pragma unroll
         for (int q = 0; q < VW; ++q) ws[((long)wv * K + kq + q) * CP + ci] = v[q];
+    }
     }
     __syncthreads();
     const int co = co0 + wave;
@@ -1596,6 +1610,7 @@ struct ConvLayer {
     float* wp2 = nullptr;   // packing for the warp-specialised kernel (larger K chunks)
     int nchunks2 = 0;
     float* wp_tr = nullptr; // transposed conv: per-phase packing [phase][co_tile][kquad][lane][4]
+    float* w_lat = nullptr; // transposed conv, latency kernel: tap-major rows [co][k][ci] (a workgroup's weights are one contiguous run)
     int nchunks_tr = 0;
 };
 
@@ -1738,6 +1753,14 @@ static int pack_weights_tr(const float* w_host, ConvLayer& L) {
                     }
     RCA_HIP(hipMalloc((void**)&L.wp_tr, p.size() * sizeof(float)));
     RCA_HIP(hipMemcpy(L.wp_tr, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
+    {   // w[ci][co][k] -> w_lat[co][k][ci]: convtr1d_lds_kernel reads the rows of its output channels with contiguous 16-byte loads
+        std::vector<float> t((size_t)L.cin * L.cout * L.k);
+        for (int ci = 0; ci < L.cin; ++ci)
+            for (int co = 0; co < L.cout; ++co)
+                for (int kk = 0; kk < L.k; ++kk) t[((size_t)co * L.k + kk) * L.cin + ci] = w_host[((size_t)ci * L.cout + co) * L.k + kk];
+        RCA_HIP(hipMalloc((void**)&L.w_lat, t.size() * sizeof(float)));
+        RCA_HIP(hipMemcpy(L.w_lat, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     L.nchunks_tr = nchunks;
     return RCA_OK;
 }
@@ -1785,6 +1808,7 @@ extern "C" int rca_codec_destroy(rca_codec_t* h) {
             if (L.wp) (void)hipFree(L.wp);
             if (L.wp2) (void)hipFree(L.wp2);
             if (L.wp_tr) (void)hipFree(L.wp_tr);
+            if (L.w_lat) (void)hipFree(L.w_lat);
         }
     for (float* p : {h->q_in_w, h->q_in_b, h->cb, h->hc, h->cbp})
         if (p) (void)hipFree(p);
@@ -2074,7 +2098,7 @@ static void launch_convtr_lds(const ConvLayer& L, const float* x, float* y, int 
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, RCA_LDS_BUDGET); attr_done = true; }
     dim3 grid(cdiv((long)Lin * S, NC), cdiv(L.cout, NW), B);
-    kern<<<grid, 64 * NW, lds, st>>>(x, L.w, L.b, y, L.cin, Lin, L.cout, NC, NTI, slope, L.pre);
+    kern<<<grid, 64 * NW, lds, st>>>(x, L.w, L.w_lat, L.b, y, L.cin, Lin, L.cout, NC, NTI, slope, L.pre);
 }
 static bool try_conv_lds(rca_codec* h, const ConvLayer& L, const float* x, long xbs, int Lvalid, float* y, int B, int Lin, int clamp_out, hipStream_t st) {
     const float slope = h->cfg.leaky_slope;
