@@ -59,6 +59,37 @@ print(f"source_hash={source_hash()}  (sha256/16 over {', '.join(__import__('prof
 for sub in ("bench", "lm", "lm_6k", "lm_q8", "lm_q4k"):
     if os.path.isdir(f"{d}/{sub}"):
         stats(sub)
+
+
+def conv_layer_table():
+    """Per layer of the default codec's encoder at the bench's 256 windows of 2.0 s (the step bench.py times): algorithmic FLOP =
+    2 Cin KS Cout per output column (the fused first layer also carries conv_in's 2 * 7 * 32 per input sample)."""
+    f = newest(f"{d}/bench/*/*kernel_stats.csv")
+    if not f:
+        return
+    B, T = 256, 32000
+    layers = [("fused conv_in + k4s2", "conv1d_mfma_kernel<4, 2,", 2.0 * 32 * 4 * 64 * B * (T // 2) + 2.0 * 7 * 32 * B * T),
+              ("k8s4", "conv1d_mfma_kernel<8, 4,", 2.0 * 64 * 8 * 128 * B * (T // 8)),
+              ("k10s5", "conv1d_mfma_kernel<10, 5,", 2.0 * 128 * 10 * 256 * B * (T // 40)),
+              ("k16s8", "conv1d_mfma_kernel<16, 8,", 2.0 * 256 * 16 * 512 * B * (T // 320)),
+              ("k3 (conv_out)", "conv1d_mfma_kernel<3, 1,", 2.0 * 512 * 3 * 256 * B * (T // 320))]
+    rows = list(csv.DictReader(open(f)))
+    print("== conv layers of the 256-window step (bench run, the instantiation with the most calls per layer): us per launch, algorithmic GFLOP, TFLOP/s, fraction of the 157.3 TFLOP/s f32-MFMA peak")
+    tot_us = tot_fl = 0.0
+    for name, pat, fl in layers:
+        cand = [r for r in rows if pat in r["Name"]]
+        if not cand:
+            continue
+        r = max(cand, key=lambda r: int(r["Calls"]))
+        us = float(r["AverageNs"]) / 1e3
+        tot_us += us
+        tot_fl += fl
+        print(f"{name:22s} {short(r['Name'])[:44]:44s} {us:9.1f} us {fl / 1e9:8.1f} GFLOP {fl / us / 1e6:7.1f} TFLOP/s  {fl / us / 1e6 / 157.3:5.3f}")
+    if tot_us:
+        print(f"{'sum':22s} {'':44s} {tot_us:9.1f} us {tot_fl / 1e9:8.1f} GFLOP {tot_fl / tot_us / 1e6:7.1f} TFLOP/s  {tot_fl / tot_us / 1e6 / 157.3:5.3f}")
+
+
+conv_layer_table()
 sq = pmc("pmc_sq")
 if sq:
     print("== pmc_sq: per-dispatch averages (profiled run; SQ_* are per-XCD sums, quad-cycles for WAVE/WAIT)")
