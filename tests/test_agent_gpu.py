@@ -247,7 +247,7 @@ def test_duplex_frame_call_equals_the_separate_calls():
 def test_full_size_duplex_session_equals_the_oracle_session():
     """BASELINE config [3] at full size against the oracle, not only inside bench.py: the default codec (131072 x 16 codebook, hop 320) and
     the Llama-3.2-1B-dims LM (V = 259 344, hash-generated weights, text rows of lm_head zeroed like a trained codec LM in audio mode) run
-    2 s of duplex audio through the SAME RealtimeAgent twice -- over the HIP objects (frame graph, streaming codec tails, graph steps) and
+    2.7 s of duplex audio through the SAME RealtimeAgent twice -- over the HIP objects (frame graph, streaming codec tails, graph steps) and
     over the CPU oracle objects (C codec oracle + LMRef + C sampler), greedy sampling.  Token stream, KV position and emitted PCM must
     be equal (ids exactly, PCM bit for bit); the last logits within the 1B decode tolerance."""
     from types import SimpleNamespace
@@ -283,7 +283,7 @@ def test_full_size_duplex_session_equals_the_oracle_session():
     a_hip = RealtimeAgent(resources=hip, config=RealtimeAgentConfig(**cfg))
     a_ora = RealtimeAgent(resources=ora, config=RealtimeAgentConfig(**cfg))
     assert a_hip.input_ids == a_ora.input_ids                  # header incl. the 3 s enrollment encoded by both codecs
-    sig = rich_signal(1280 * 25, 33)
+    sig = rich_signal(1280 * 34, 33)      # 34 frames: from the 25th on both codec windows are full and the HIP side runs ONE replay per frame
     for s in range(0, len(sig), 1280):
         o_hip = a_hip.process_audio(sig[s:s + 1280])
         o_ora = a_ora.process_audio(sig[s:s + 1280])
@@ -294,4 +294,6 @@ def test_full_size_duplex_session_equals_the_oracle_session():
     print(f"full-size session: {len(a_hip.input_ids)} tokens, last-step logits HIP vs oracle max|d| = {d:.2e}")
     assert d < 1.5e-3
     assert a_hip.frame_graph_active and not getattr(a_ora, "frame_graph_active", False)   # one graph replay per chunk on the HIP side
+    print("one-replay frames at full size:", a_hip.duplex_graph_frames)
+    assert a_hip.duplex_graph_frames >= 8 and a_ora.duplex_graph_frames == 0               # ... and per FRAME once the windows are full
     assert len(set(a_hip.input_ids[a_hip.context_start_pos + 8::2])) > 10
