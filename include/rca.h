@@ -351,6 +351,10 @@ int rca_duplex_frame(rca_lm_t* lm, rca_codec_t* codec, const rca_duplex_frame_ar
 int rca_codec_workspace_sig(rca_codec_t* h, uint64_t* sig);
 int rca_codec_stream_handoff(rca_codec_t* h, void* stream);
 int rca_codec_codebook_size(const rca_codec_t* h, int32_t* n);
+/* rca_lm_step + rca_lm_token_probs of the position it evaluated, as ONE replay and one synchronisation: the agent's speculative
+ * <|end_audio|> step (get_probable_event_speaker, realtime_agent_v2.py:455-466: eval, sample, softmax(logits)[agent speaker, user
+ * speaker], then n_tokens -= 1).  Same token and the same probabilities as the two separate calls. */
+int rca_lm_step_probe(rca_lm_t* h, const int32_t* ids, int32_t n, const int32_t* probe_ids, int32_t n_probe, int32_t* token, float* probs_out);
 /* softmax(logits)[token] of the last position, reduced on the device
  * (measure_event_prob, realtime_agent_v2.py:448-452) */
 int rca_lm_token_probs(rca_lm_t* h, const int32_t* token_ids, int32_t n, float* probs_out);

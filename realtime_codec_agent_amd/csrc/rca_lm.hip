@@ -1630,6 +1630,7 @@ struct rca_lm {
     SamplerDev* samp = nullptr; // device
     SampWork* swork = nullptr;  // device: sampler histogram + candidate list
     LmDevState* h_stt = nullptr;   // pinned host staging (ids, n_tokens, m in; out_token back)
+    int* h_probe = nullptr;        // pinned: [0, 64) probe ids in, [64, 128) their probabilities back (rca_lm_step_probe)
     int n_tokens = 0;           // host mirror (llama_cpp.Llama.n_tokens)
     bool sampler_set = false;
     bool samp_full = false;     // top_k <= 0: the whole-vocabulary (Gumbel-max) sampler launches instead of the top-k ones
@@ -1638,6 +1639,7 @@ struct rca_lm {
     // Two sets: the handle's KV cache can be exchanged with a twin's (rca_lm_swap_kv) and the cache address is baked into the
     // captured kernel nodes, so a set remembers the cache it was captured over (at most two caches ever rotate through a handle).
     struct GraphSet { const f16_t* kc = nullptr; hipGraphExec_t g[3][LM_GRAPH_BUCKETS] = {}; hipGraphExec_t fg[LM_FRAME_MAX + 1][LM_GRAPH_BUCKETS] = {};
+                      hipGraphExec_t gp[3][LM_GRAPH_BUCKETS] = {}; int gp_nprobe[3][LM_GRAPH_BUCKETS] = {};   // step + token probabilities (rca_lm_step_probe)
                       unsigned long long last_use = 0; };
     GraphSet gset[2];
     unsigned long long gset_clock = 0;
@@ -1681,8 +1683,10 @@ static void lm_free_weights(rca_lm* h) {
 // whenever one of those is reallocated (or the handle goes away) every captured graph has to go with it.
 static void lm_drop_graph_set(rca_lm::GraphSet& gs) {
     for (int i = 0; i < 3; ++i)
-        for (int b = 0; b < LM_GRAPH_BUCKETS; ++b)
+        for (int b = 0; b < LM_GRAPH_BUCKETS; ++b) {
             if (gs.g[i][b]) { (void)hipGraphExecDestroy(gs.g[i][b]); gs.g[i][b] = nullptr; }
+            if (gs.gp[i][b]) { (void)hipGraphExecDestroy(gs.gp[i][b]); gs.gp[i][b] = nullptr; }
+        }
     for (int i = 0; i <= LM_FRAME_MAX; ++i)
         for (int b = 0; b < LM_GRAPH_BUCKETS; ++b)
             if (gs.fg[i][b]) { (void)hipGraphExecDestroy(gs.fg[i][b]); gs.fg[i][b] = nullptr; }
@@ -1721,6 +1725,7 @@ extern "C" int rca_lm_destroy(rca_lm_t* h) {
     h->x = h->xn = h->qkv = h->attn = h->hbuf = h->att_part = h->logits = h->probs_dev = h->gpart = nullptr;
     h->probe_ids_dev = nullptr; h->att_arrive = nullptr; h->xh = h->xl = nullptr; h->stt = nullptr; h->samp = nullptr; h->swork = nullptr;
     if (h->h_stt) { (void)hipHostFree(h->h_stt); h->h_stt = nullptr; }
+    if (h->h_probe) { (void)hipHostFree(h->h_probe); h->h_probe = nullptr; }
     if (h->stream) { (void)hipStreamDestroy(h->stream); h->stream = nullptr; }
     if (h->weights_of) {            // borrower: the weights belong to someone else
         rca_lm* owner = h->weights_of;
@@ -3928,38 +3933,55 @@ extern "C" int rca_lm_sample(rca_lm_t* h, int32_t* token) {
 
 // eval(ids[0..n)) + sample with no host round trip in between.  For n <= 2 and a plain (not
 // logits_all) handle the whole step is one hipGraph replay.
-extern "C" int rca_lm_step(rca_lm_t* h, const int32_t* ids, int32_t n, int32_t* token) {
+// eval + sample (+ optionally softmax(logits)[probe ids] of the evaluated position) as one replay and one synchronisation
+static int lm_step_impl(rca_lm_t* h, const int32_t* ids, int32_t n, const int32_t* probe_ids, int32_t n_probe, int32_t* token, float* probs_out) {
     if (!h || !ids || !token || n < 1) return fail(RCA_ERR_ARG, "step: bad argument");
+    if (n_probe < 0 || n_probe > 8 || (n_probe > 0 && (!probe_ids || !probs_out))) return fail(RCA_ERR_ARG, "step: 0..8 probe ids");
     { const int src = lm_settle(h); if (src != RCA_OK) return src; }
     if (!h->sampler_set) return fail(RCA_ERR_STATE, "sampler not initialised");
     if (h->n_tokens + n > h->cfg.n_ctx) return fail(RCA_ERR_STATE, "context overflow: %d + %d > n_ctx %d", h->n_tokens, n, h->cfg.n_ctx);
     for (int i = 0; i < n; ++i)
         if (ids[i] < 0 || ids[i] >= h->cfg.vocab_size) return fail(RCA_ERR_ARG, "step: token id %d at index %d is outside the vocabulary [0, %d)", ids[i], i, h->cfg.vocab_size);
+    for (int i = 0; i < n_probe; ++i)
+        if (probe_ids[i] < 0 || probe_ids[i] >= h->cfg.vocab_size) return fail(RCA_ERR_ARG, "step: probe id %d is outside the vocabulary", probe_ids[i]);
     RCA_HIP(hipSetDevice(h->device));
     hipStream_t st = h->stream;
     int rc;
     if (n > 2 || h->cfg.logits_all || !h->graphs_enabled) {
         if ((rc = rca_lm_eval(h, ids, n)) != RCA_OK) return rc;
-        return rca_lm_sample(h, token);
+        if ((rc = rca_lm_sample(h, token)) != RCA_OK) return rc;
+        return n_probe ? rca_lm_token_probs(h, probe_ids, n_probe, probs_out) : RCA_OK;
     }
     // stage inputs in pinned memory; the graph's first node copies them to the device
     h->h_stt->n_tokens = h->n_tokens;
     h->h_stt->m = n;
     for (int i = 0; i < n; ++i) h->h_stt->ids[i] = ids[i];
+    if (n_probe) {
+        if (!h->h_probe) { RCA_HIP(hipHostMalloc((void**)&h->h_probe, 64 * 4 + 64 * 4, hipHostMallocDefault)); }
+        for (int i = 0; i < n_probe; ++i) h->h_probe[i] = probe_ids[i];
+    }
     int bucket = 0;
     const int need = lm_splits_needed(h, n);
     while (bucket + 1 < LM_GRAPH_BUCKETS && (4 << bucket) < need) ++bucket;
     const int nsp_launch = bucket + 1 == LM_GRAPH_BUCKETS ? h->n_splits : std::min(h->n_splits, 4 << bucket);
-    hipGraphExec_t& gexec = lm_graph_set(h).g[n][bucket];
+    rca_lm::GraphSet& gs = lm_graph_set(h);
+    hipGraphExec_t& gexec = n_probe ? gs.gp[n][bucket] : gs.g[n][bucket];
+    if (n_probe && gexec && gs.gp_nprobe[n][bucket] != n_probe) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
     if (!gexec) {
         hipGraph_t g = nullptr;
         RCA_HIP(hipStreamSynchronize(st));
         RCA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         hipError_t e = hipMemcpyAsync(h->stt, h->h_stt, LM_STATE_DECODE_BYTES, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && n_probe) e = hipMemcpyAsync(h->probe_ids_dev, h->h_probe, n_probe * 4, hipMemcpyHostToDevice, st);
         rc = e == hipSuccess ? lm_enqueue_pass(h, n, 1, st, nsp_launch) : fail(RCA_ERR_HIP, "capture memcpy: %s", hipGetErrorString(e));
         if (rc == RCA_OK) {
             lm_enqueue_sample(h, h->logits, st);
+            if (n_probe) {   // rca_lm_token_probs' two launches, over the logits this step just wrote
+                lm_softmax_slices_kernel<<<PROBS_SLICES, 1024, 0, st>>>(h->logits, h->cfg.vocab_size, h->probs_dev + 64);
+                lm_token_probs_kernel<<<1, 64, 0, st>>>(h->logits, h->cfg.vocab_size, h->probs_dev + 64, h->probe_ids_dev, n_probe, h->probs_dev);
+            }
             e = hipMemcpyAsync(&h->h_stt->out_token, &h->stt->out_token, 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && n_probe) e = hipMemcpyAsync(h->h_probe + 64, h->probs_dev, n_probe * 4, hipMemcpyDeviceToHost, st);
             if (e != hipSuccess) rc = fail(RCA_ERR_HIP, "capture d2h: %s", hipGetErrorString(e));
         }
         hipError_t e2 = hipStreamEndCapture(st, &g);
@@ -3968,6 +3990,7 @@ extern "C" int rca_lm_step(rca_lm_t* h, const int32_t* ids, int32_t n, int32_t* 
         e2 = hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
         if (e2 != hipSuccess) { gexec = nullptr; return fail(RCA_ERR_HIP, "graph instantiate: %s", hipGetErrorString(e2)); }
+        if (n_probe) gs.gp_nprobe[n][bucket] = n_probe;
     }
     RCA_HIP(hipGraphLaunch(gexec, st));
     RCA_HIP(hipStreamSynchronize(st));
@@ -3975,7 +3998,19 @@ extern "C" int rca_lm_step(rca_lm_t* h, const int32_t* ids, int32_t n, int32_t* 
     h->logits_rows = 1;
     h->rng_host += 1;
     *token = h->h_stt->out_token;
+    for (int i = 0; i < n_probe; ++i) probs_out[i] = reinterpret_cast<const float*>(h->h_probe + 64)[i];
     return RCA_OK;
+}
+// eval(ids[0..n)) + sample with no host round trip in between.  For n <= 2 and a plain (not
+// logits_all) handle the whole step is one hipGraph replay.
+extern "C" int rca_lm_step(rca_lm_t* h, const int32_t* ids, int32_t n, int32_t* token) {
+    return lm_step_impl(h, ids, n, nullptr, 0, token, nullptr);
+}
+// rca_lm_step + rca_lm_token_probs of the position just evaluated, as ONE replay and one synchronisation: the agent's speculative
+// <|end_audio|> step (get_probable_event_speaker, realtime_agent_v2.py:455-466: eval, sample, softmax(logits)[agent / user speaker])
+extern "C" int rca_lm_step_probe(rca_lm_t* h, const int32_t* ids, int32_t n, const int32_t* probe_ids, int32_t n_probe, int32_t* token, float* probs_out) {
+    if (n_probe < 1) return fail(RCA_ERR_ARG, "step_probe: 1..8 probe ids");
+    return lm_step_impl(h, ids, n, probe_ids, n_probe, token, probs_out);
 }
 
 // One frame of the duplex loop as ONE graph (process_audio_input_ids, realtime_agent_v2.py:332-372, while every sampled token is an

@@ -427,6 +427,20 @@ class LlamaForAlternatingCodeChannels:
         self._logits_valid = False
         return tok.value
 
+    def step_probe(self, tokens: Sequence[int], probe_ids: Sequence[int]):
+        """step(tokens) and token_probs(probe_ids) of the position it evaluated in ONE C-ABI call (one replay, one synchronisation):
+        the agent's speculative <|end_audio|> step (realtime_agent_v2.py:455-466).  Returns (token, probabilities)."""
+        tokens, probe_ids = list(tokens), list(probe_ids)
+        n0 = self.n_tokens
+        arr = (C.c_int32 * len(tokens))(*tokens)
+        pid = (C.c_int32 * len(probe_ids))(*probe_ids)
+        out = (C.c_float * len(probe_ids))()
+        tok = C.c_int32()
+        N.check(self._lib.rca_lm_step_probe(self._h, arr, len(tokens), pid, len(probe_ids), C.byref(tok), out), "rca_lm_step_probe")
+        self._input_ids[n0:n0 + len(tokens)] = tokens
+        self._logits_valid = False
+        return tok.value, np.array(out[:], dtype=np.float32)
+
     def frame(self, first_pair: Sequence[int], user_ids: Sequence[int], audio_id_floor: int) -> List[int]:
         """One chunk of process_audio_input_ids (realtime_agent_v2.py:332-372) as ONE graph replay: len(user_ids) S=2 steps with
         the sampled agent token fed back on the device.  Returns the sampled tokens; the list is shorter than user_ids when a

@@ -195,6 +195,32 @@ def test_whole_vocabulary_sampler_matches_restatement(min_p, temp):
     assert llm.step(ids[9:11].tolist()) == seqs[0][0]
 
 
+def test_step_probe_equals_step_plus_token_probs():
+    """rca_lm_step_probe (the agent's speculative <|end_audio|> step as one replay): same token, same probabilities, same state as
+    step() followed by token_probs(), replayed and eager, across a graph-bucket boundary, and the rollback afterwards works."""
+    llm, w, ids = make_llm("llama3")
+    twin, _, _ = make_llm("llama3")
+    params = dict(top_k=20, top_p=1.0, min_p=0.0, temp=1.0, seed=3)
+    for use_graph in (True, False):
+        for m in (llm, twin):
+            m.set_graphs(use_graph)
+            m.reset()
+            m.init_sampler_for_generate(**params)
+            m.eval(ids[:9].tolist())
+        toks = ids[9:11].tolist()
+        for step in range(12):
+            probe = [int(ids[step]), int(ids[step + 3]), 5]
+            t, p = llm.step_probe(toks[:1 + step % 2], probe)
+            t2 = twin.step(toks[:1 + step % 2])
+            p2 = twin.token_probs(probe)
+            assert t == t2 and np.array_equal(p, p2) and llm.n_tokens == twin.n_tokens
+            if step % 3 == 0:                       # the agent rolls the speculative token back
+                llm.n_tokens -= 1
+                twin.n_tokens -= 1
+            toks = [t, int(ids[9 + step])]
+        assert np.array_equal(llm._scores[-1], twin._scores[-1])
+
+
 def test_logits_all_and_get_logprobs():
     llm, w, ids = make_llm("llama3", logits_all=True)
     ref = lm_ref.LMRef(tiny_cfg("llama3"), w, kv_dtype=torch.float16)
