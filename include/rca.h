@@ -346,6 +346,9 @@ typedef struct rca_duplex_frame_out {
 } rca_duplex_frame_out_t;
 int rca_duplex_frame(rca_lm_t* lm, rca_codec_t* codec, const rca_duplex_frame_args_t* args, rca_duplex_frame_out_t* out,
                      float* pcm_out_host);
+/* Optional: make rca_duplex_frame's one-time allocations for a call shape (pinned staging, device buffers, side stream) ahead of the
+ * first frame -- a session calls it at reset() (realtime_agent_v2.py:127-161) so that no frame pays for a pinned allocation. */
+int rca_duplex_prepare(rca_lm_t* lm, int32_t T, int32_t F_ctx, int32_t n_steps, int32_t n_samples);
 /* what rca_duplex_frame needs from a codec handle whose tail calls it captures: a signature of every address a captured tail
  * call bakes in, a hand-over of the handle's stream ordering to the capturing stream, the codebook size */
 int rca_codec_workspace_sig(rca_codec_t* h, uint64_t* sig);

@@ -2154,6 +2154,8 @@ static int lm_common_init(rca_lm* h, const rca_tensor_t* ts, int nt, const rca_l
     RCA_HIP(hipMemsetAsync(h->swork, 0, sizeof(SampWork), h->stream));
     RCA_HIP(hipHostMalloc((void**)&h->h_stt, sizeof(LmDevState), hipHostMallocDefault));
     memset(h->h_stt, 0, sizeof(LmDevState));
+    RCA_HIP(hipHostMalloc((void**)&h->h_probe, 128 * 4, hipHostMallocDefault));   // at creation: a pinned allocation inside a frame costs milliseconds
+    memset(h->h_probe, 0, 128 * 4);
     RCA_HIP(hipStreamSynchronize(h->stream));
     return RCA_OK;
 }
@@ -3957,7 +3959,6 @@ static int lm_step_impl(rca_lm_t* h, const int32_t* ids, int32_t n, const int32_
     h->h_stt->m = n;
     for (int i = 0; i < n; ++i) h->h_stt->ids[i] = ids[i];
     if (n_probe) {
-        if (!h->h_probe) { RCA_HIP(hipHostMalloc((void**)&h->h_probe, 64 * 4 + 64 * 4, hipHostMallocDefault)); }
         for (int i = 0; i < n_probe; ++i) h->h_probe[i] = probe_ids[i];
     }
     int bucket = 0;
@@ -4180,6 +4181,47 @@ static int duplex_grow(T** p, size_t* cap, size_t n) {
     return rc;
 }
 
+// buffers, side stream and events of the duplex frame for a call shape (growing a buffer invalidates the graphs captured over it)
+static int duplex_reserve(rca_lm* h, int T, int F_ctx, int n, int n_samples) {
+    int rc;
+    hipStream_t st = h->stream;
+    if (!h->duplex) {
+        h->duplex = new DuplexState();
+        const char* nf = getenv("RCA_DUPLEX_FORK");
+        h->duplex->fork = !(nf && nf[0] == '0');
+        RCA_HIP(hipStreamCreateWithFlags(&h->duplex->side, hipStreamNonBlocking));
+        RCA_HIP(hipEventCreateWithFlags(&h->duplex->ev_fork, hipEventDisableTiming));
+        RCA_HIP(hipEventCreateWithFlags(&h->duplex->ev_join, hipEventDisableTiming));
+    }
+    DuplexState* d = h->duplex;
+    const int F = F_ctx + n;
+    const size_t pin_pcm = sizeof(DuplexPin), pin_codes = pin_pcm + (((size_t)T * 4 + 255) & ~(size_t)255),
+                 pin_out = pin_codes + (((size_t)F_ctx * 8 + 255) & ~(size_t)255), pin_total = pin_out + (size_t)n_samples * 4;
+    if ((size_t)T > d->pcm_in_cap || (size_t)F > d->code_win_cap || (size_t)n_samples > d->pcm_out_cap || pin_total > d->pin_cap || !d->dev) {
+        RCA_HIP(hipStreamSynchronize(st));
+        duplex_drop_graphs(d);
+        if ((rc = duplex_grow(&d->pcm_in, &d->pcm_in_cap, (size_t)T)) != RCA_OK) return rc;
+        if ((rc = duplex_grow(&d->code_win, &d->code_win_cap, (size_t)F + 8)) != RCA_OK) return rc;
+        if ((rc = duplex_grow(&d->pcm_out, &d->pcm_out_cap, (size_t)n_samples)) != RCA_OK) return rc;
+        if (!d->dev && (rc = lm_alloc((void**)&d->dev, sizeof(DuplexDev))) != RCA_OK) return rc;
+        if (pin_total > d->pin_cap) {
+            if (d->pin) (void)hipHostFree(d->pin);
+            d->pin = nullptr; d->pin_cap = 0;
+            RCA_HIP(hipHostMalloc((void**)&d->pin, pin_total + (pin_total >> 2), hipHostMallocDefault));
+            d->pin_cap = pin_total + (pin_total >> 2);
+        }
+    }
+    return RCA_OK;
+}
+// The one-time allocations of rca_duplex_frame for a call shape (pinned staging, device buffers, side stream), so that a session can make
+// them at reset() instead of inside its first one-replay frame (a pinned allocation costs milliseconds).  Optional.
+extern "C" int rca_duplex_prepare(rca_lm_t* h, int32_t T, int32_t F_ctx, int32_t n_steps, int32_t n_samples) {
+    if (!h || T < 1 || F_ctx < 0 || n_steps < 1 || n_steps > LM_FRAME_MAX || n_samples < 1) return fail(RCA_ERR_ARG, "duplex_prepare: bad shape");
+    { const int src = lm_settle(h); if (src != RCA_OK) return src; }
+    RCA_HIP(hipSetDevice(h->device));
+    return duplex_reserve(h, T, F_ctx, n_steps, n_samples);
+}
+
 extern "C" int rca_duplex_frame(rca_lm_t* h, rca_codec_t* codec, const rca_duplex_frame_args_t* a, rca_duplex_frame_out_t* out,
                                 float* pcm_out_host) {
     if (!h || !codec || !a || !out || !pcm_out_host || !a->pcm_window || (a->F_ctx > 0 && !a->code_ctx)) return fail(RCA_ERR_ARG, "duplex_frame: null argument");
@@ -4201,33 +4243,11 @@ extern "C" int rca_duplex_frame(rca_lm_t* h, rca_codec_t* codec, const rca_duple
     { const int src = lm_settle(h); if (src != RCA_OK) return src; }
     RCA_HIP(hipSetDevice(h->device));
     hipStream_t st = h->stream;
-    if (!h->duplex) {
-        h->duplex = new DuplexState();
-        const char* nf = getenv("RCA_DUPLEX_FORK");
-        h->duplex->fork = !(nf && nf[0] == '0');
-        RCA_HIP(hipStreamCreateWithFlags(&h->duplex->side, hipStreamNonBlocking));
-        RCA_HIP(hipEventCreateWithFlags(&h->duplex->ev_fork, hipEventDisableTiming));
-        RCA_HIP(hipEventCreateWithFlags(&h->duplex->ev_join, hipEventDisableTiming));
-    }
+    if ((rc = duplex_reserve(h, a->T, a->F_ctx, n, a->n_samples)) != RCA_OK) return rc;
     DuplexState* d = h->duplex;
     const int F = a->F_ctx + n;
     const size_t pin_pcm = sizeof(DuplexPin), pin_codes = pin_pcm + (((size_t)a->T * 4 + 255) & ~(size_t)255),
-                 pin_out = pin_codes + (((size_t)a->F_ctx * 8 + 255) & ~(size_t)255), pin_total = pin_out + (size_t)a->n_samples * 4;
-    // growing a buffer invalidates the graphs captured over it
-    if ((size_t)a->T > d->pcm_in_cap || (size_t)F > d->code_win_cap || (size_t)a->n_samples > d->pcm_out_cap || pin_total > d->pin_cap || !d->dev) {
-        RCA_HIP(hipStreamSynchronize(st));
-        duplex_drop_graphs(d);
-        if ((rc = duplex_grow(&d->pcm_in, &d->pcm_in_cap, (size_t)a->T)) != RCA_OK) return rc;
-        if ((rc = duplex_grow(&d->code_win, &d->code_win_cap, (size_t)F + 8)) != RCA_OK) return rc;
-        if ((rc = duplex_grow(&d->pcm_out, &d->pcm_out_cap, (size_t)a->n_samples)) != RCA_OK) return rc;
-        if (!d->dev && (rc = lm_alloc((void**)&d->dev, sizeof(DuplexDev))) != RCA_OK) return rc;
-        if (pin_total > d->pin_cap) {
-            if (d->pin) (void)hipHostFree(d->pin);
-            d->pin = nullptr; d->pin_cap = 0;
-            RCA_HIP(hipHostMalloc((void**)&d->pin, pin_total + (pin_total >> 2), hipHostMallocDefault));
-            d->pin_cap = pin_total + (pin_total >> 2);
-        }
-    }
+                 pin_out = pin_codes + (((size_t)a->F_ctx * 8 + 255) & ~(size_t)255);
     if (d->logits_at_capture != (const void*)h->logits) { duplex_drop_graphs(d); d->logits_at_capture = h->logits; }
     DuplexPin* pin = reinterpret_cast<DuplexPin*>(d->pin);
     // stage the inputs

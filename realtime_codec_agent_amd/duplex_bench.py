@@ -36,6 +36,8 @@ def run_duplex_bench(dev=None, secs: float = 125.0, chunk_size_secs: float = 0.0
     from .realtime_agent_resources import RealtimeAgentResources
     from .realtime_agent_v2 import RealtimeAgent
 
+    import gc
+    gc.collect()          # an earlier leg's handles (a 3 GB model, its KV caches) must not be torn down inside this leg's timed frames
     cfg = LMConfig.llama_3_2_1b()
     t0 = time.perf_counter()
     res = RealtimeAgentResources(**session_resources_kwargs(0, n_ctx, weight_format))
@@ -52,6 +54,7 @@ def run_duplex_bench(dev=None, secs: float = 125.0, chunk_size_secs: float = 0.0
     for s in range(0, 10 * cs, cs):
         agent.process_audio(sig[s:s + cs])
     agent.profilers.reset()
+    gc.collect()
     one_replay0 = agent.duplex_graph_frames
     t1 = time.perf_counter()
     nchunks = 0

@@ -461,6 +461,10 @@ class LlamaForAlternatingCodeChannels:
         self._logits_valid = False
         return toks
 
+    def duplex_prepare(self, T: int, F_ctx: int, n_steps: int, n_samples: int) -> None:
+        """duplex_frame's one-time allocations for a call shape, ahead of the first frame (rca_duplex_prepare)."""
+        N.check(self._lib.rca_duplex_prepare(self._h, int(T), int(F_ctx), int(n_steps), int(n_samples)), "rca_duplex_prepare")
+
     def duplex_frame(self, codec_handle, pcm_window: np.ndarray, code_ctx: np.ndarray, n_steps: int, n_samples: int,
                      code_token_base: int, audio_id_floor: int, probe_id: int, first_pair: Sequence[int]) -> dict:
         """One whole duplex frame (encode tail -> the chunk's LM steps -> decode tail -> P(probe)) as ONE graph replay
