@@ -183,29 +183,21 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU (python bench.py --gpus N does it itself)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    # rehearsal hooks (not used by the driver): several ranks on ONE card over gloo exercise the N > 1 code path
-    # on a 1-GPU box -- RCA_BENCH_DEVICE pins every rank to that device, RCA_BENCH_BACKEND picks the backend
+    # rehearsal hooks (not used by the driver): several ranks on ONE card exercise the N > 1 code path on a 1-GPU box --
+    # RCA_BENCH_DEVICE pins every rank to that device, RCA_BENCH_BACKEND=gloo skips the RCCL attempt
     if os.environ.get("RCA_BENCH_DEVICE") is not None:
         local_rank = int(os.environ["RCA_BENCH_DEVICE"])
-    backend = os.environ.get("RCA_BENCH_BACKEND", "nccl")
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-    else:
-        torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # The data path has no collective: the control plane (barrier, max of one float, gather of the duplex summaries) rides on RCCL
+    # when every rank can bring it up and on gloo over CPU tensors otherwise -- same process, no re-exec; the line says which.
+    from realtime_codec_agent_amd.dist_utils import ControlPlane
+    cp = ControlPlane(prefer=os.environ.get("RCA_BENCH_BACKEND", "nccl"), device_index=local_rank)
 
     from realtime_codec_agent_amd import _native
     if _native.needs_build() and rank == 0:
         _native.build()
-    if dist is not None:
-        dist.barrier()
+    cp.barrier()
     from realtime_codec_agent_amd.codec import HipCodec
     from realtime_codec_agent_amd.codec_model import CodecConfig, init_codec_weights
 
@@ -235,23 +227,18 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
+    cp.barrier()
     torch.cuda.synchronize(dev)
     hip.profile(True)
     t0 = time.perf_counter()
     for i in range(args.warmup, total_steps):
         step(i)
     torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
+    cp.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     hip.profile(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = cp.max(elapsed)
 
     # SURVEY 8f-1 leg (reported beside the headline, never as `value`): the same steps with every window cut down
     # to the receptive field of its kept frames -- identical codes (checked), ~10x less encoder work
@@ -262,20 +249,15 @@ def main():
         for i in range(args.warmup):
             step(i)
         torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
+        cp.barrier()
         t0 = time.perf_counter()
         for i in range(args.warmup, total_steps):
             step(i)
         torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
+        cp.barrier()
         elapsed_trim = time.perf_counter() - t0
         hip.set_window_trim(False)
-        if dist is not None:
-            t = torch.tensor([elapsed_trim], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed_trim = float(t.item())
+        elapsed_trim = cp.max(elapsed_trim)
         trim_identical = bool(torch.equal(codes, codes_full))
         assert trim_identical, "window-trimmed batch encode produced different codes"
 
@@ -291,19 +273,14 @@ def main():
             for i in range(args.warmup):
                 step(i)
             torch.cuda.synchronize(dev)
-            if dist is not None:
-                dist.barrier()
+            cp.barrier()
             t0 = time.perf_counter()
             for i in range(args.warmup, total_steps):
                 step(i)
             torch.cuda.synchronize(dev)
-            if dist is not None:
-                dist.barrier()
+            cp.barrier()
             el = time.perf_counter() - t0
-            if dist is not None:
-                t = torch.tensor([el], device=dev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                el = float(t.item())
+            el = cp.max(el)
             eq = float((codes == codes_f32).double().mean().item())
             bf16_legs[name] = {"value": world * args.steps * chunks_per_step * chunk / cfg.sample_rate / el, "unit": "audio-hours/hour",
                                "ms_per_step": 1e3 * el / args.steps, "code_ids_equal_to_f32_path": eq, "mfma_mode": mode}
@@ -345,6 +322,7 @@ def main():
             "codebook": f"{cfg.codebook_size}x{cfg.codebook_dim}",
             "encoder_gflop_per_window": cfg.encoder_flops_per_sample() * ctx / 1e9,
             "sharding": "chunk ranges per rank, no collective (replicas only)",
+            "control_plane": cp.describe(),
             "bf16_mfma_opt_in": bf16_legs,
             "receptive_field_trimmed": None if args.no_trim_leg else {
                 "value": world * audio_secs / elapsed_trim, "unit": "audio-hours/hour", "ms_per_step": 1e3 * elapsed_trim / args.steps,
@@ -388,10 +366,9 @@ def main():
         # one independent duplex session per GPU (BASELINE configs[3]/[4]; no exchange between sessions)
         from realtime_codec_agent_amd.duplex_bench import run_duplex_bench
         mine = run_duplex_bench(dev, secs=args.duplex_secs if world == 1 else min(args.duplex_secs, 10.0))
-        if dist is not None:
-            allr = [None] * world
-            dist.all_gather_object(allr, {k: mine[k] for k in ("xRT", "p50_frame_step_ms", "p95_frame_step_ms", "p99_frame_step_ms", "max_frame_step_ms",
-                                                                "frames_over_budget", "lm_step_ms")})
+        if cp.active:
+            allr = cp.all_gather_object({k: mine[k] for k in ("xRT", "p50_frame_step_ms", "p95_frame_step_ms", "p99_frame_step_ms", "max_frame_step_ms",
+                                                              "frames_over_budget", "lm_step_ms")})
             mine = dict(mine, sessions=world, per_gpu=allr, xRT_min=min(r["xRT"] for r in allr),
                         p50_frame_step_ms_max=max(r["p50_frame_step_ms"] for r in allr))
         out["duplex"] = mine
@@ -407,8 +384,7 @@ def main():
                 out[f"duplex_{fmt}"]["roofline_lm"] = rq
     if rank == 0:
         print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    cp.close()
 
 
 if __name__ == "__main__":

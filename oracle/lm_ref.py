@@ -82,8 +82,23 @@ class LMRef:
         return w * (x * torch.rsqrt(var + self.cfg.rms_eps))
 
     @torch.no_grad()
-    def eval(self, ids) -> torch.Tensor:
-        """Append ids at position n_tokens; returns logits [len(ids), V] (fp32)."""
+    def eval(self, ids, last_only: bool = False, chunk: Optional[int] = None, drop_keys=None) -> torch.Tensor:
+        """Append ids at position n_tokens; returns logits [len(ids), V] (fp32), or [1, V] of the last position with last_only
+        (a long context at a 259 k vocabulary: the head product of every position is TFLOPs nobody reads).  chunk: walk a long
+        eval in pieces of that many tokens (bounds the [heads, S, T] score tensor; same arithmetic per row).  drop_keys=(a, b): keys
+        [a, b) are masked out -- ONLY for the "this tolerance would catch a lost attention split" assertions of the long-context tests."""
+        ids = list(ids)
+        if chunk and len(ids) > chunk:
+            outs = []
+            for i in range(0, len(ids), chunk):
+                last = i + chunk >= len(ids)
+                o = self._eval(ids[i:i + chunk], last_only, drop_keys)
+                if not last_only or last:
+                    outs.append(o)
+            return torch.cat(outs, 0) if not last_only else outs[-1]
+        return self._eval(ids, last_only, drop_keys)
+
+    def _eval(self, ids, last_only, drop_keys) -> torch.Tensor:
         c = self.cfg
         ids = torch.as_tensor(list(ids), dtype=torch.long)
         S = ids.shape[0]
@@ -107,18 +122,22 @@ class LMRef:
                 k = torch.cat((self.k[l][:, : self.n_tokens], k), dim=1)
                 v = torch.cat((self.v[l][:, : self.n_tokens], v), dim=1)
             self.k[l], self.v[l] = k, v
-            kk = k.repeat_interleave(G, dim=0)
-            vv = v.repeat_interleave(G, dim=0)
-            att = (q @ kk.transpose(1, 2)) * (c.head_dim ** -0.5)  # [nh,S,T]
-            T = kk.shape[1]
+            T = k.shape[1]
+            # GQA without materialising the repeated K / V (a 10 k-token cache times G is gigabytes): [nkv, G * S, hd] queries
+            qg = q.reshape(c.n_kv_heads, G * S, c.head_dim)
+            att = (qg @ k.transpose(1, 2)) * (c.head_dim ** -0.5)  # [nkv, G*S, T]
             mask = torch.arange(T)[None, :] > (self.n_tokens + torch.arange(S))[:, None]
-            att = att.masked_fill(mask[None], float("-inf")).softmax(-1)
-            o = (att @ vv).transpose(0, 1).reshape(S, c.n_heads * c.head_dim)
+            if drop_keys is not None:
+                mask = mask | ((torch.arange(T) >= drop_keys[0]) & (torch.arange(T) < drop_keys[1]))[None, :]
+            att = att.view(c.n_kv_heads, G, S, T).masked_fill(mask[None, None], float("-inf")).softmax(-1).view(c.n_kv_heads, G * S, T)
+            o = (att @ v).view(c.n_heads, S, c.head_dim).transpose(0, 1).reshape(S, c.n_heads * c.head_dim)
             x = x + o @ self.w[p + "self_attn.o_proj.weight"].T
             h = self._norm(x, self.w[p + "post_attention_layernorm.weight"])
             g = h @ self.w[p + "mlp.gate_proj.weight"].T
             u = h @ self.w[p + "mlp.up_proj.weight"].T
             x = x + (torch.nn.functional.silu(g) * u) @ self.w[p + "mlp.down_proj.weight"].T
+        if last_only:
+            x = x[-1:]
         x = self._norm(x, self.w["model.norm.weight"])
         self.n_tokens += S
         return x @ self.w["lm_head.weight"].T

@@ -193,8 +193,31 @@ def sources() -> List[str]:
     return [os.path.join(CSRC_DIR, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC_DIR, s))]
 
 
+def _build_key() -> Tuple[str, List[str], List[str]]:
+    """(key of compiler + flags, hipcc, compile flags): the key names the objects under csrc/.obj and is stamped next to the library"""
+    import hashlib
+    extra = os.environ.get("RCA_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DRCA_CONV_TIMELINE (scripts/conv_timeline.py)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + extra
+    return hashlib.sha1(" ".join([hipcc] + cflags).encode()).hexdigest()[:10], hipcc, cflags
+
+
+def _stamp_path() -> str:
+    return LIB_PATH + ".flags"
+
+
 def needs_build() -> bool:
+    """True when the library is missing, older than a source / header, or was built with other flags than this process asks for
+    (the stamp file next to it holds the flags key: a diagnostic build left in place is never mistaken for the product build)."""
     if not os.path.exists(LIB_PATH):
+        return True
+    try:
+        with open(_stamp_path()) as f:
+            if f.read().strip() != _build_key()[0]:
+                return True
+    except OSError:
         return True
     deps = sources() + [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith(".h")]
     deps.append(os.path.join(os.path.dirname(_PKG_DIR), "include", "rca.h"))
@@ -203,42 +226,60 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc cross-compiles every HIP source for gfx950 into ONE in-tree shared library."""
-    extra = os.environ.get("RCA_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DRCA_CONV_TIMELINE (scripts/conv_timeline.py)
-    if not force and not extra and not needs_build():
+    """hipcc cross-compiles every HIP source for gfx950 into ONE in-tree shared library.
+
+    Safe against concurrent builders (torchrun ranks, spawned session workers on a fresh tree): an flock on csrc/.obj/.lock
+    serialises compile + link, the second process then finds the library current; temporaries carry the pid and are removed
+    when a compile fails.  A build with RCA_EXTRA_HIPCC_FLAGS (diagnostic -D switches) refuses to overwrite the in-tree library:
+    it needs RCA_LIB_PATH pointing somewhere else."""
+    key, hipcc, cflags = _build_key()
+    extra = os.environ.get("RCA_EXTRA_HIPCC_FLAGS", "").split()
+    if extra and not os.environ.get("RCA_LIB_PATH"):
+        raise RcaError(f"RCA_EXTRA_HIPCC_FLAGS={' '.join(extra)!r} without RCA_LIB_PATH: a diagnostic build must not replace "
+                       f"{LIB_PATH}; set RCA_LIB_PATH=/tmp/<name>.so")
+    if not force and not needs_build():
         return LIB_PATH
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    if not os.path.exists(hipcc):
-        hipcc = "hipcc"
+    import fcntl
     # one object per source, compiled side by side and kept under csrc/.obj (keyed by the flags): editing one kernel file
     # recompiles that file only; `force` recompiles everything
-    import hashlib
-    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + extra
-    key = hashlib.sha1(" ".join([hipcc] + cflags).encode()).hexdigest()[:10]
     obj_dir = os.path.join(CSRC_DIR, ".obj")
     os.makedirs(obj_dir, exist_ok=True)
-    headers = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith(".h")]
-    headers.append(os.path.join(os.path.dirname(_PKG_DIR), "include", "rca.h"))
-    hdr_t = max([os.path.getmtime(p) for p in headers if os.path.exists(p)] + [0.0])
-    objs, jobs = [], []
-    for src in sources():
-        obj = os.path.join(obj_dir, f"{os.path.splitext(os.path.basename(src))[0]}.{key}.o")
-        objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
-            cmd = [hipcc] + cflags + ["-c", src, "-o", obj + ".tmp"]
+    with open(os.path.join(obj_dir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not needs_build():      # another process built it while this one waited
+            return LIB_PATH
+        headers = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith(".h")]
+        headers.append(os.path.join(os.path.dirname(_PKG_DIR), "include", "rca.h"))
+        hdr_t = max([os.path.getmtime(p) for p in headers if os.path.exists(p)] + [0.0])
+        sfx = f".{os.getpid()}.tmp"
+        objs, jobs = [], []
+        for src in sources():
+            obj = os.path.join(obj_dir, f"{os.path.splitext(os.path.basename(src))[0]}.{key}.o")
+            objs.append(obj)
+            if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+                cmd = [hipcc] + cflags + ["-c", src, "-o", obj + sfx]
+                if verbose:
+                    print(" ".join(cmd))
+                jobs.append((subprocess.Popen(cmd), cmd, obj))
+        tmps = [obj + sfx for _, _, obj in jobs] + [LIB_PATH + sfx]
+        try:
+            failed = [cmd for p, cmd, _ in jobs if p.wait() != 0]
+            if failed:
+                raise subprocess.CalledProcessError(1, failed[0])
+            for _, _, obj in jobs:
+                os.replace(obj + sfx, obj)
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH + sfx]
             if verbose:
                 print(" ".join(cmd))
-            jobs.append((subprocess.Popen(cmd), cmd, obj))
-    failed = [cmd for p, cmd, _ in jobs if p.wait() != 0]
-    if failed:
-        raise subprocess.CalledProcessError(1, failed[0])
-    for _, _, obj in jobs:
-        os.replace(obj + ".tmp", obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+            subprocess.check_call(cmd)
+            os.replace(LIB_PATH + sfx, LIB_PATH)
+            with open(_stamp_path() + sfx, "w") as f:
+                f.write(key + "\n")
+            os.replace(_stamp_path() + sfx, _stamp_path())
+        finally:
+            for t in tmps + [_stamp_path() + sfx]:
+                if os.path.exists(t):
+                    os.remove(t)
     return LIB_PATH
 
 

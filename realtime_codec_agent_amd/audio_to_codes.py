@@ -39,7 +39,7 @@ from typing import Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .dist_utils import env_rank_world, init_dist, max_over_ranks, shard_by_duration, sum_over_ranks
+from .dist_utils import ControlPlane, env_rank_world, shard_by_duration
 
 AUDIO_EXTS = (".wav", ".npy")
 # The reference's corpora are mp3 (tools/sph_to_mp3.py:28-41) and codec_bpe reads them through librosa / soundfile.  Neither is part
@@ -379,24 +379,22 @@ def main(argv=None, encoder=None, backend: Optional[str] = None) -> dict:
         encoder = HipWindowEncoder(args.codec_model, local)
         encoder.model.hip.set_window_trim(args.receptive_field_trim)
         backend = backend or os.environ.get("RCA_DIST_BACKEND", "nccl")
-    dist = init_dist(backend or "gloo", local) if world > 1 else None
+    cp = ControlPlane(prefer=backend or "gloo", device_index=local)     # falls back to gloo by itself when RCCL cannot come up
     files = list_audio_files(args.audio_path, args.audio_filter)
     shards = shard_by_duration([probe_duration(f) for f in files], world)
     mine = [files[i] for i in shards[rank]]
-    dev = getattr(encoder, "device", None) if backend == "nccl" else None
-    if dist is not None:
-        dist.barrier()
+    dev = getattr(encoder, "device", None)
+    cp.barrier()
     t0 = time.perf_counter()
     secs, ncodes = encode_files(mine, encoder, args, rank)
-    if dev is not None:
+    if dev is not None and hasattr(encoder, "torch"):
         encoder.torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0, dist, dev)
-    total_secs = sum_over_ranks(secs, dist, dev)
-    total_codes = sum_over_ranks(float(ncodes), dist, dev)
+    cp.barrier()
+    elapsed = cp.max(time.perf_counter() - t0)
+    total_secs = cp.sum(secs)
+    total_codes = cp.sum(float(ncodes))
     summary = dict(files=len(files), world_size=world, audio_hours=total_secs / 3600.0, codes=int(total_codes), elapsed_s=elapsed,
-                   audio_hours_per_hour=(total_secs / elapsed) if elapsed > 0 else None)
+                   audio_hours_per_hour=(total_secs / elapsed) if elapsed > 0 else None, control_plane=cp.backend)
     if rank == 0:
         print(json.dumps(summary))
     return summary

@@ -259,7 +259,10 @@ class LlamaForAlternatingCodeChannels:
     def _query_format(self):
         fmt, nbytes = C.c_int32(), C.c_int64()
         N.check(self._lib.rca_lm_weight_format(self._h, C.byref(fmt), C.byref(nbytes)), "rca_lm_weight_format")
-        return {0: "bf16", 1: "q8_0", 2: "f16", 3: "q4_k"}[fmt.value], int(nbytes.value)
+        names = {0: "bf16", 1: "q8_0", 2: "f16", 3: "q4_k", 4: "q6_k"}    # 4: a file whose gate / up tensors are Q6_K (llama-quantize Q6_K)
+        if fmt.value not in names:
+            raise N.RcaError(f"rca_lm_weight_format reported an unknown format id {fmt.value}")
+        return names[fmt.value], int(nbytes.value)
 
     def _finish_init(self, seed: int) -> None:
         self._ctx = _Ctx(self)

@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf /tmp/convfetch_$1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/convfetch_$1 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-duplex --no-trim-leg --no-bf16-leg > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/convfetch_$1 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-duplex --no-trim-leg --no-bf16-leg --no-cli-leg > /dev/null 2>&1
 python3 - <<PY
 import csv, glob, collections
 rows = list(csv.DictReader(open(glob.glob("/tmp/convfetch_$1/*/*counter_collection.csv")[0])))

@@ -210,7 +210,7 @@ class OracleLLM:
     def eval(self, tokens):
         tokens = [int(t) for t in tokens]
         if tokens:
-            self._logits = np.ascontiguousarray(self.ref.eval(tokens)[-1].numpy(), dtype=np.float32)
+            self._logits = np.ascontiguousarray(self.ref.eval(tokens, last_only=True, chunk=512)[-1].numpy(), dtype=np.float32)
             self.n_evals += 1
 
     def init_sampler_for_generate(self, top_k=40, top_p=0.95, min_p=0.05, temp=0.8, seed=None, logits_processor=None, **_):

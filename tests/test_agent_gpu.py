@@ -149,6 +149,43 @@ def test_agent_over_hip_objects_equals_agent_over_oracle_objects(chunk, exact_pr
     assert len(set(a_hip.input_ids[a_hip.context_start_pos + 8::2])) > 10           # the agent channel is not stuck on one code
 
 
+def test_long_session_over_hip_objects_equals_oracle_session_past_1k_tokens_with_shadow_trims():
+    """The paired session above at the context lengths of a real dialogue: a 10 s window (header ~150 + 100 tokens per second) that
+    grows past 1 100 tokens before the first sliding-window trim and is trimmed twice (realtime_agent_v2.py:187-190,725-733;
+    window knobs realtime_agent_config.py:23-24).  The HIP agent runs its default fast paths -- one graph replay per frame
+    (rca_duplex_frame), flash prefill tiles, the post-trim cache built ahead on the shadow twin and swapped in -- the oracle agent
+    the reference's own call sequence over CPU objects (C codec oracle, LMRef, C sampler).  Ids exact, PCM bit for bit, final logits
+    within the MFMA-prefill tolerance of the short paired test."""
+    from realtime_codec_agent_amd.realtime_agent_config import RealtimeAgentConfig
+    from realtime_codec_agent_amd.realtime_agent_v2 import RealtimeAgent
+    hip, ora = _paired_resources()
+    cfg = dict(chunk_size_secs=0.08, use_whisper=False, force_trans_after_inactivity_secs=0.0, force_response_after_inactivity_secs=0.0,
+               temperature=0.0, max_context_secs=10.0, trim_by_secs=2.5)
+    a_hip = RealtimeAgent(resources=hip, config=RealtimeAgentConfig(**cfg))
+    a_ora = RealtimeAgent(resources=ora, config=RealtimeAgentConfig(**cfg))
+    assert a_hip.use_kv_shadow and a_hip.use_frame_graph
+    assert a_hip.input_ids == a_ora.input_ids
+    n = 1280
+    sig = rich_signal(n * 170, 29)            # 13.6 s: trims at 10 s and 12.5 s
+    peak = 0
+    for s in range(0, len(sig), n):
+        o_hip = a_hip.process_audio(sig[s:s + n])
+        o_ora = a_ora.process_audio(sig[s:s + n])
+        assert a_hip.input_ids == a_ora.input_ids, f"token streams diverge in chunk {s // n}"
+        assert np.array_equal(o_hip, o_ora), f"emitted PCM differs in chunk {s // n}"
+        assert hip.llm.n_tokens == ora.llm.n_tokens
+        peak = max(peak, hip.llm.n_tokens)
+    assert peak > 1100, peak
+    assert a_hip.trim_to_secs == a_ora.trim_to_secs == 5.0                           # two trims
+    st = a_hip._kv_shadow.stats
+    print("peak context", peak, "tokens; shadow stats", st)
+    assert st["swaps"] == 2 and st["fallbacks"] == 0 and st["tiles"] >= 8
+    assert np.array_equal(a_hip.get_audio_history(), a_ora.get_audio_history())
+    d = np.abs(hip.llm._scores[-1] - ora.llm._logits).max()
+    print(f"last-step logits HIP vs oracle after {len(a_hip.input_ids)} tokens: max|d| = {d:.2e}")
+    assert d < 6e-4
+
+
 @pytest.mark.parametrize("mfma_prefill", [True, False])
 def test_trim_through_shadow_cache_equals_reference_recompute(mfma_prefill):
     """a16 / SURVEY 8f-1: the same sampled session (seeded top-k sampling, several sliding-window trims) with the post-trim cache

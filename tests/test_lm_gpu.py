@@ -692,6 +692,35 @@ def test_q4_k_m_gguf_mix_of_q4_k_and_q6_k_loads_and_matches_its_dequantisation(t
     assert np.all(g._scores[-1][:64] == 0) and np.array_equal(g._scores[-1][64:], got[64:])
 
 
+def test_q6_k_only_gguf_loads_reports_its_format_and_matches_its_dequantisation(tmp_path):
+    """A `llama-quantize ... Q6_K` file: EVERY matrix is Q6_K, so the format the handle reports is that of its gate / up tensors
+    (rca_lm_weight_format -> "q6_k"; a bare KeyError at the end of the constructor before round 4).  Logits equal LMRef over the
+    file's own blocks de-quantised by llama.cpp's rule, decode and prefill tiles; weight_bytes_per_step() answers."""
+    import gguf_writer as gw
+    from realtime_codec_agent_amd.gguf import load_llama_gguf
+    from realtime_codec_agent_amd.llm import LlamaForAlternatingCodeChannels, LMConfig, bf16_bits_to_f32
+    cfg = LMConfig(vocab_size=1024, hidden=256, n_layers=2, n_heads=4, n_kv_heads=2, head_dim=64, ffn=512, rope_scaling=None, rope_theta=10000.0)
+    w = lm_ref.random_weights(cfg, 9, 0.05)
+    wf = {k: (bf16_bits_to_f32(v) if v.dtype == np.uint16 else v.astype(np.float32)) for k, v in w.items()}
+    path = str(tmp_path / "small-q6_k.gguf")
+    gw.write_llama_gguf(path, cfg, wf, matrix_type=gw.Q6_K)
+    _, file_w, _ = load_llama_gguf(path)
+    assert type(file_w["model.layers.0.mlp.gate_proj.weight"]).__name__ == "Q6KBlocks"
+    g = LlamaForAlternatingCodeChannels(model_path=path, n_ctx=512, device=0)
+    assert g.weight_format == "q6_k" and g.weight_bytes_per_step() > 0
+    deq = {k: (v.dequantize() if hasattr(v, "dequantize") else v) for k, v in file_w.items() if k != "rope.inv_freq"}
+    ref = lm_ref.LMRef(cfg, deq, kv_dtype=torch.float16)
+    ids = np.random.default_rng(2).integers(0, 1024, 40)
+    for mfma in (False, True):
+        g.set_mfma_prefill(mfma)
+        g.reset(); ref.reset()
+        g.eval(ids.tolist())
+        want = ref.eval(ids)[-1].numpy()
+        d = np.abs(g._scores[-1] - want).max()
+        print(f"Q6_K GGUF (mfma_prefill={mfma}) vs LMRef over the file's blocks: max|dlogit| = {d:.3e}")
+        assert d < (2e-3 if mfma else 1e-3) * max(1.0, np.abs(want).max()) and g._scores[-1].argmax() == want.argmax()
+
+
 def test_full_size_1b_properties():
     """BASELINE config 3 dims (Llama-3.2-1B, V=259344) with random-init weights: checks that do not
     need a CPU forward -- graph replay == eager, prefill == incremental, rollback, determinism."""

@@ -87,6 +87,47 @@ def test_sharded_batch_encode_two_gloo_ranks(tmp_path):
     assert os.path.isdir(os.path.join(c1, "MagiCodec-50Hz-Base", "0.1s_2.0s", "stereo", "CallHome", "a"))
 
 
+CP_WORKER = """
+import json, os, sys
+sys.path.insert(0, {root!r})
+from realtime_codec_agent_amd.dist_utils import ControlPlane
+cp = ControlPlane(prefer="nccl")          # no GPU in this container: RCCL cannot come up on any rank
+rank = cp.rank
+cp.barrier()
+out = dict(backend=cp.backend, reason=cp.fallback_reason, mx=cp.max(1.5 + rank), sm=cp.sum(float(rank + 1)),
+           gathered=cp.all_gather_object(dict(r=rank)), active=cp.active)
+cp.barrier()
+cp.close()
+if rank == 0:
+    print(json.dumps(out))
+"""
+
+
+def test_control_plane_falls_back_to_gloo_when_rccl_cannot_come_up(tmp_path):
+    """bench.py / audio_to_codes ask for RCCL; where it cannot be brought up (here: no GPU; on a node: IPC handles, topology, two
+    ranks on one card) the SAME processes carry barrier / max / sum / gather over gloo on CPU tensors and say so -- the data path
+    has no collective, so the control plane must never be the thing that takes an 8-GPU run down."""
+    script = os.path.join(str(tmp_path), "cp_worker.py")
+    with open(script, "w") as f:
+        f.write(CP_WORKER.format(root=ROOT))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29547", script], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["backend"] == "gloo" and r["active"] and r["reason"] and r["reason"].startswith("rank 0:")
+    assert r["mx"] == 2.5 and r["sm"] == 3.0 and r["gathered"] == [{"r": 0}, {"r": 1}]
+    assert "[control plane] 2 ranks" in out.stderr and "carried by gloo" in out.stderr
+    # a single process has no control plane at all
+    from realtime_codec_agent_amd.dist_utils import ControlPlane
+    env = {k: os.environ.pop(k) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK") if k in os.environ}
+    try:
+        cp = ControlPlane(prefer="nccl")
+        assert cp.backend == "none" and not cp.active and cp.max(3.0) == 3.0 and cp.all_gather_object(1) == [1]
+        cp.barrier(); cp.close()
+    finally:
+        os.environ.update(env)
+
+
 def test_shard_plans():
     d = [5.0, 1.0, 3.0, 3.0, 8.0, 0.5, 2.0]
     for world in (1, 2, 3, 8):
