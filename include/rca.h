@@ -243,16 +243,23 @@ typedef struct {
 } rca_lm_config_t;
 
 typedef struct {
-    int32_t top_k;   /* 1..256 ranked candidates, or <= 0 = llama.cpp's "whole vocabulary" (llamacpp_utils.py:39-77 passes top_k straight
-                        through): min_p -> temp -> softmax -> draw over every token by the Gumbel-max rule, top_p >= 1 only.  top_k > 256
-                        and top_k <= 0 with top_p < 1 are refused by rca_lm_sampler_init (never clamped); temp <= 0 is greedy whatever top_k */
-    float top_p;     /* 1.0 = off */
+    int32_t top_k;   /* llama.cpp semantics (llamacpp_utils.py:39-77 passes it straight through): 1..256 = that many ranked candidates on the
+                        serial chain (float sums, inverse-CDF draw); <= 0 or >= vocabulary = the whole vocabulary; 257..vocabulary - 1 = a rank
+                        cut found by a radix select, then the whole-vocabulary draw (Gumbel-max).  Never clamped.  temp <= 0 is greedy */
+    float top_p;     /* 1.0 = off.  With top_k outside 1..256 the cut is a mass threshold over the sorted vocabulary in 2^-40 fixed point */
     float min_p;     /* 0.0 = off */
     float temp;      /* <=0: greedy */
     uint32_t seed;
     int32_t n_bias;          /* logit bias entries (llamacpp_utils.py:8-24) */
     const int32_t* bias_ids;
     const float* bias_vals;
+    /* llama.cpp's penalties sampler, in front of top_k (realtime_agent_v2.py:172-185 forwards repeat_penalty / presence_penalty /
+       frequency_penalty of realtime_agent_config.py:18-20): over the last `penalty_last_n` tokens this sampler accepted.
+       repeat_penalty 1.0 (or 0 = unset) with 0 / 0 = off */
+    float repeat_penalty;
+    float freq_penalty;
+    float presence_penalty;
+    int32_t penalty_last_n;  /* 0 = llama-cpp-python's default window (last_n_tokens_size = 64), 1..64, < 0 = no window */
 } rca_sampler_params_t;
 
 /* llama_cpp.Llama(model_path=..., n_ctx=..., n_gpu_layers=-1) (realtime_agent_resources.py:19-33) */

@@ -260,6 +260,7 @@ def _slib():
     if _lib is None:
         _lib = C.CDLL(build())
         _lib.oracle_sample.restype = C.c_int
+        _lib.oracle_sample_ex.restype = C.c_int
         _lib.oracle_expf.restype = C.c_float
         _lib.oracle_expf.argtypes = [C.c_float]
         _lib.oracle_logf.restype = C.c_float
@@ -268,13 +269,19 @@ def _slib():
 
 
 def sample(logits: np.ndarray, top_k: int, top_p: float, min_p: float, temp: float, seed: int, counter: int,
-           logit_bias: Optional[Dict[int, float]] = None) -> int:
+           logit_bias: Optional[Dict[int, float]] = None, repeat_penalty: float = 1.0, frequency_penalty: float = 0.0,
+           presence_penalty: float = 0.0, prev_tokens=()) -> int:
+    """prev_tokens: the tokens this sampler accepted before this draw (the restatement looks at the last 64, like llama.cpp's
+    penalties sampler with llama-cpp-python's default window)."""
     logits = np.ascontiguousarray(logits, dtype=np.float32)
     bias = logit_bias or {}
     ids = (C.c_int32 * max(1, len(bias)))(*bias.keys())
     vals = (C.c_float * max(1, len(bias)))(*bias.values())
-    return _slib().oracle_sample(logits.ctypes.data_as(C.POINTER(C.c_float)), logits.shape[0], int(top_k), C.c_float(top_p), C.c_float(min_p),
-                                 C.c_float(temp), C.c_uint32(seed & 0xFFFFFFFF), C.c_uint64(counter), len(bias), ids, vals)
+    prev = [int(t) for t in list(prev_tokens)[-64:]]
+    pv = (C.c_int32 * max(1, len(prev)))(*prev)
+    return _slib().oracle_sample_ex(logits.ctypes.data_as(C.POINTER(C.c_float)), logits.shape[0], int(top_k), C.c_float(top_p), C.c_float(min_p),
+                                    C.c_float(temp), C.c_uint32(seed & 0xFFFFFFFF), C.c_uint64(counter), len(bias), ids, vals,
+                                    C.c_float(repeat_penalty), C.c_float(frequency_penalty), C.c_float(presence_penalty), len(prev), pv)
 
 
 def expf(x: float) -> float:

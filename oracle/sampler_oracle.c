@@ -13,7 +13,19 @@
  * softmax(logits / temp) over every token that passes min_p is made by the Gumbel-max rule -- argmax of
  * (v_i - max) / temp + g_i with g_i = -log(-log(u_i)), u_i from the counter RNG keyed by (seed, draw, token) -- which has
  * exactly that distribution and needs no sort of 259 k candidates; polynomial log in fma so that device and host agree
- * bit for bit.  top_k <= 0 with top_p < 1 is not defined here (the device refuses it).
+ * bit for bit.
+ *
+ * Round 4 -- the members the reference's config exposes and llama.cpp honours (realtime_agent_v2.py:172-185,
+ * realtime_agent_config.py:18-20; llama-cpp-python's _init_sampler builds: custom logits processor (the logit bias) ->
+ * penalties(last_n = 64, repeat, freq, present) -> top_k -> typical -> top_p -> min_p -> temp -> dist):
+ *   * penalties: llama.cpp's llama_sampler_penalties restated -- over the last `n_prev` tokens THIS sampler accepted (sampled),
+ *     a token seen `count` times has its logit multiplied (<= 0) or divided (> 0) by repeat_penalty, then
+ *     count * frequency_penalty + presence_penalty subtracted; applied after the bias, before everything else.
+ *   * top_k > 256 (up to the vocabulary) and top_k <= 0 together with top_p < 1: the "big" path.  Candidates = the top_k largest
+ *     (value, lowest index first) keys (all of them for top_k <= 0); top_p keeps the smallest prefix of the sorted candidates whose
+ *     mass reaches top_p of the candidates' total, with the masses in 2^-40 fixed point (w_i = trunc(exp(v_i - max) * 2^40), integer
+ *     sums: independent of summation order, so the device's histogram passes and this loop agree exactly; need = max(1,
+ *     trunc(top_p * W))); min_p as before; the draw by the Gumbel-max rule over what is left.
  */
 #include <math.h>
 #include <stdint.h>
@@ -78,19 +90,65 @@ static int cmp_cand(const void* a, const void* b) {
     return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
 }
 
-/* returns the sampled token for draw number `counter` of the stream started by `seed` */
-int oracle_sample(const float* logits, int V, int top_k, float top_p, float min_p, float temp, uint32_t seed, uint64_t counter,
-                  int n_bias, const int32_t* bias_ids, const float* bias_vals) {
+/* llama.cpp's llama_sampler_penalties_apply on one logit: `count` occurrences in the window of accepted tokens */
+static float penalise(float v, int count, float repeat, float freq, float present) {
+    if (count <= 0) return v;
+    if (v <= 0.0f) v = v * repeat; else v = v / repeat;
+    const float t = (float)count * freq + present;
+    return v - t;
+}
+
+/* returns the sampled token for draw number `counter` of the stream started by `seed`; prev[0..n_prev) = the window of tokens this
+   sampler accepted before this draw (at most the last 64), in any order */
+int oracle_sample_ex(const float* logits, int V, int top_k, float top_p, float min_p, float temp, uint32_t seed, uint64_t counter,
+                     int n_bias, const int32_t* bias_ids, const float* bias_vals,
+                     float repeat_penalty, float freq_penalty, float presence_penalty, int n_prev, const int32_t* prev) {
     cand_t* c = (cand_t*)malloc((size_t)V * sizeof(cand_t));
+    const int pen = n_prev > 0 && (repeat_penalty != 1.0f || freq_penalty != 0.0f || presence_penalty != 0.0f);
     for (int i = 0; i < V; ++i) {
         float v = logits[i];
         for (int b = 0; b < n_bias; ++b)
             if (bias_ids[b] == i) v = v + bias_vals[b];
         c[i].v = v; c[i].idx = i;
     }
+    if (pen) {
+        for (int j = 0; j < n_prev; ++j) {
+            int first = 1, count = 0;
+            for (int q = 0; q < n_prev; ++q) { if (prev[q] == prev[j]) { if (q < j) first = 0; ++count; } }
+            if (first && prev[j] >= 0 && prev[j] < V) c[prev[j]].v = penalise(c[prev[j]].v, count, repeat_penalty, freq_penalty, presence_penalty);
+        }
+    }
     const int greedy = temp <= 0.0f;
-    if (!greedy && top_k <= 0) {   /* whole vocabulary: Gumbel-max over every token that passes min_p */
-        if (top_p < 1.0f) { free(c); return -1; }
+    if (!greedy && (top_k <= 0 || top_k > 256) && (top_p < 1.0f || (top_k > 256 && top_k < V))) {
+        /* the "big" path: rank cut and / or fixed-point mass cut over the sorted vocabulary, then Gumbel-max */
+        qsort(c, (size_t)V, sizeof(cand_t), cmp_cand);
+        int cnt = (top_k <= 0 || top_k > V) ? V : top_k;
+        const float mx = c[0].v;
+        if (top_p < 1.0f) {
+            uint64_t W = 0;
+            for (int i = 0; i < cnt; ++i) W += (uint64_t)(oracle_expf(c[i].v - mx) * 1099511627776.0f);
+            uint64_t need = (uint64_t)((double)top_p * (double)W);
+            if (need < 1) need = 1;
+            uint64_t cum = 0; int keep = cnt;
+            for (int i = 0; i < cnt; ++i) { cum += (uint64_t)(oracle_expf(c[i].v - mx) * 1099511627776.0f); if (cum >= need) { keep = i + 1; break; } }
+            cnt = keep;
+        }
+        const float inv_t = 1.0f / temp;
+        const uint64_t draw = oracle_splitmix((uint64_t)seed, counter);
+        int best = -1; float best_key = 0.0f;
+        for (int i = 0; i < cnt; ++i) {
+            const float d = c[i].v - mx;
+            if (min_p > 0.0f && !(oracle_expf(d) >= min_p)) continue;
+            const uint64_t z = oracle_splitmix(draw, (uint64_t)c[i].idx);
+            const float u = (float)(uint32_t)(((z >> 41) << 1) | 1u) * 5.9604644775390625e-08f;
+            const float g = -oracle_logf(-oracle_logf(u));
+            const float key = fmaf(d, inv_t, g);
+            if (best < 0 || key > best_key || (key == best_key && c[i].idx < best)) { best = c[i].idx; best_key = key; }   /* ties: lowest index */
+        }
+        free(c);
+        return best;
+    }
+    if (!greedy && (top_k <= 0 || top_k > 256)) {   /* whole vocabulary: Gumbel-max over every token that passes min_p */
         float mx = c[0].v;
         for (int i = 1; i < V; ++i) if (c[i].v > mx) mx = c[i].v;
         const float inv_t = 1.0f / temp;
@@ -140,4 +198,9 @@ int oracle_sample(const float* logits, int V, int top_k, float top_p, float min_
     const int tok = c[pick].idx;
     free(c);
     return tok;
+}
+
+int oracle_sample(const float* logits, int V, int top_k, float top_p, float min_p, float temp, uint32_t seed, uint64_t counter,
+                  int n_bias, const int32_t* bias_ids, const float* bias_vals) {
+    return oracle_sample_ex(logits, V, top_k, top_p, min_p, temp, seed, counter, n_bias, bias_ids, bias_vals, 1.0f, 0.0f, 0.0f, 0, 0);
 }

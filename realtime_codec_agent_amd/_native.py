@@ -161,6 +161,10 @@ class SamplerParamsC(C.Structure):
         ("n_bias", C.c_int32),
         ("bias_ids", C.POINTER(C.c_int32)),
         ("bias_vals", C.POINTER(C.c_float)),
+        ("repeat_penalty", C.c_float),
+        ("freq_penalty", C.c_float),
+        ("presence_penalty", C.c_float),
+        ("penalty_last_n", C.c_int32),
     ]
 
 

@@ -38,6 +38,9 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #define LM_MAXSPLIT 4      // ffn <= LM_KSLICE * LM_MAXSPLIT (up to four chunks per lane and wave)
 #define ATT_KEYS 256       // keys per attention workgroup (8 waves x 32 keys)
 #define LM_GRAPH_BUCKETS 8  // 4, 8, ..., 256 splits, the last bucket = all of them
+#define ATT_EPOCH_INTS 64          // att_arrive: 64 launch counters (one per kv head), then the granules [kv head][split][8 rows][66]
+#define ATT_TAG_MAXSP 128         // splits the in-launch merge can gather: nkv * splits <= 256 with at least 2 kv heads
+#define ATT_TAG_SPINS (1 << 22)   // bound of the merger's re-polls (seconds): a NaN row tells
 #define SAMP_MAXK 256
 #define LM_FRAME_MAX 8        // steps of one frame graph (a chunk is 4-5 frames per channel, realtime_agent_config.py:21,56)
 #define LM_FRAME_USER0 8     // LmDevState::ids[LM_FRAME_USER0 + i] = the user's token of frame i (ids[0..1] is the pair being evaluated)
@@ -59,6 +62,13 @@ struct SamplerDev {
     int n_bias;
     int bias_ids[8];
     float bias_vals[8];
+    // llama.cpp's penalties sampler (llama_sampler_penalties; llama-cpp-python adds it with penalty_last_n = last_n_tokens_size = 64
+    // behind the logits processor and in front of top_k): over the last `last_n` tokens THIS sampler accepted
+    float repeat_penalty, freq_penalty, presence_penalty;
+    int last_n;
+    int patch;      // 1: logit bias and / or penalties are applied IN PLACE by samp_prepare_kernel and undone by the sampler's last kernel
+    int big_k;      // > 0: the "big" path cuts at this rank (top_k > SAMP_MAXK); 0: no rank cut
+    int big_p;      // 1: the "big" path cuts at top_p of the candidates' mass (fixed point)
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -941,20 +951,92 @@ __device__ __forceinline__ unsigned long long sample_key(float v, unsigned idx) 
 #define SAMP_BINS 2048
 #define SAMP_CAND_CAP 4096
 #define SAMP_FAST_CAP 1024   // candidate lists up to this size are ranked by counting in samp_final_kernel
+#define SAMP_RING 128          // accepted tokens kept (window <= 64 + the <= 8 speculative steps of a frame graph: a cut frame only rewinds the counter)
+#define SAMP_OV_CAP 80         // logits patched in place per draw: <= 64 penalised + <= 8 biased
+#define SAMP_LEVELS 6          // radix levels of the 64-bit (value, ~index) key: 11 + 11 + 11 + 11 + 11 + 9 bits
 struct SampWork {
     unsigned hist[SAMP_BINS];
     unsigned ncand;
     unsigned overflow;
     unsigned pad[2];
     unsigned long long cand[SAMP_CAND_CAP];
+    // ---- round 4
+    int ring[SAMP_RING];                   // token accepted by draw c sits in ring[c % SAMP_RING] (c = LmDevState::rng_counter before the draw)
+    int ov_n;                              // logits currently patched in place
+    int ov_ids[SAMP_OV_CAP];
+    float ov_orig[SAMP_OV_CAP];
+    unsigned long long rhist[2][SAMP_LEVELS][SAMP_BINS];   // [0] rank (counts) / [1] mass (2^-40 fixed point) histograms of the radix selects
+    unsigned long long rstate[2][SAMP_LEVELS][2];          // after level l: {key prefix fixed so far, what is still needed inside it}
 };
 
+// The value the sampler sees for token i.  Logit bias and penalties are NOT applied here any more: samp_prepare_kernel writes the
+// adjusted values of the (at most 72) affected tokens into the logits row before the sampler's passes and the sampler's last kernel
+// puts the originals back, so every pass is a plain read (llama.cpp applies both to its candidate copy, never to the context's
+// logits: _ctx.get_logits() / _scores keep the raw values here too).
 __device__ __forceinline__ float samp_value(const float* __restrict__ logits, const SamplerDev* __restrict__ sp, int i) {
-    float v = logits[i];
+    (void)sp;
+    return logits[i];
+}
+
+// llama_sampler_penalties_apply on one logit (llama.cpp llama-sampling.cpp): a token seen `count` times in the window
+__device__ __forceinline__ float samp_penalise(float v, int count, float repeat, float freq, float present) {
+    if (count <= 0) return v;
+    v = v <= 0.0f ? v * repeat : v / repeat;
+    const float t = (float)count * freq + present;
+    return v - t;
+}
+
+// One workgroup of 128 threads, in front of the sampler's passes when SamplerDev::patch is set: thread j < window takes the token
+// accepted j draws ago, thread 64 + b bias entry b.  The first holder of a token owns it: bias entries in order (as the logits
+// processor adds them, llamacpp_utils.py:8-24), then the penalty; the original goes to the override list, the adjusted value into
+// the row.
+__global__ __launch_bounds__(128) void samp_prepare_kernel(float* __restrict__ logits, int V, const SamplerDev* __restrict__ sp,
+                                                           const LmDevState* __restrict__ stt, SampWork* __restrict__ w) {
+    __shared__ int tok[72];
+    const int tid = threadIdx.x;
+    const unsigned long long cnt = stt->rng_counter;
+    const bool pen = sp->repeat_penalty != 1.0f || sp->freq_penalty != 0.0f || sp->presence_penalty != 0.0f;
+    const int nwin = pen ? (int)min((unsigned long long)max(min(sp->last_n, 64), 0), cnt) : 0;
     const int nb = sp->n_bias;
-    for (int b = 0; b < nb; ++b)
-        if (sp->bias_ids[b] == i) v = v + sp->bias_vals[b];
-    return v;
+    if (tid < 72) {
+        int t = -1;
+        if (tid < nwin) t = w->ring[(cnt - 1ull - (unsigned long long)tid) % SAMP_RING];
+        else if (tid >= 64 && tid - 64 < nb) t = sp->bias_ids[tid - 64];
+        tok[tid] = (t >= 0 && t < V) ? t : -1;
+    }
+    __syncthreads();
+    if (tid < 72 && tok[tid] >= 0) {
+        const int t = tok[tid];
+        bool first = true;
+        int count = 0;
+        for (int q = 0; q < 72; ++q) {
+            if (tok[q] != t) continue;
+            if (q < tid) first = false;
+            if (q < 64) ++count;
+        }
+        if (first) {
+            const float orig = logits[t];
+            float v = orig;
+            for (int b = 0; b < nb; ++b)
+                if (sp->bias_ids[b] == t) v = v + sp->bias_vals[b];
+            v = samp_penalise(v, count, sp->repeat_penalty, sp->freq_penalty, sp->presence_penalty);
+            const int slot = atomicAdd(&w->ov_n, 1);
+            w->ov_ids[slot] = t;
+            w->ov_orig[slot] = orig;
+            logits[t] = v;
+        }
+    }
+}
+// the sampler's last kernel: the token just drawn joins the window, the patched logits get their values back
+__device__ __forceinline__ void samp_accept_and_restore(float* __restrict__ logits, const SamplerDev* __restrict__ sp, SampWork* __restrict__ w,
+                                                        unsigned long long draw, int tok, int tid) {
+    if (tid == 0) w->ring[draw % SAMP_RING] = tok;
+    if (sp->patch) {
+        const int n = w->ov_n;
+        if (tid < n) logits[w->ov_ids[tid]] = w->ov_orig[tid];
+        __syncthreads();
+        if (tid == 0) w->ov_n = 0;
+    }
 }
 __device__ __forceinline__ int samp_k(const SamplerDev* sp, int V) {
     int k = sp->temp <= 0.0f ? 1 : sp->top_k;
@@ -1024,8 +1106,9 @@ struct SampTail {
     float* x;
     int H;
 };
-__global__ __launch_bounds__(1024) void samp_final_kernel(const float* __restrict__ logits, int V, const SamplerDev* __restrict__ sp,
+__global__ __launch_bounds__(1024) void samp_final_kernel(float* logits, int V, const SamplerDev* __restrict__ sp,
                                                           LmDevState* __restrict__ stt, SampWork* __restrict__ w, SampTail tail) {
+    __shared__ unsigned long long s_draw;
     __shared__ unsigned hist[256];
     __shared__ unsigned long long sel_prefix;
     __shared__ int sel_shift;      // bits already fixed (from the top)
@@ -1162,6 +1245,7 @@ __global__ __launch_bounds__(1024) void samp_final_kernel(const float* __restric
             }
         }
         const int tok = (int)(0xFFFFFFFFu - (unsigned)(cand[pick] & 0xFFFFFFFFull));
+        s_draw = stt->rng_counter;
         stt->rng_counter += 1ull;
         stt->out_token = tok;
         if (tail.frame_i >= 0) {   // the pair just evaluated is in the cache; the next pair is [token just sampled, user's token of this frame]
@@ -1174,6 +1258,7 @@ __global__ __launch_bounds__(1024) void samp_final_kernel(const float* __restric
     }
     // re-arm the shared work area for the next call
     __syncthreads();
+    samp_accept_and_restore(logits, sp, w, s_draw, s_tok, tid);
     for (int b = tid; b < SAMP_BINS; b += 1024) w->hist[b] = 0u;
     if (tid == 0) { w->ncand = 0u; w->overflow = 0u; }
     if (tail.frame_i >= 0) {   // lm_embed_kernel for the next pair (m = 2)
@@ -1242,13 +1327,16 @@ __global__ __launch_bounds__(1024) void samp_full_pick_kernel(const float* __res
         w->cand[blockIdx.x] = b;
     }
 }
-__global__ __launch_bounds__(1024) void samp_full_final_kernel(int V, LmDevState* __restrict__ stt, SampWork* __restrict__ w, SampTail tail) {
+__global__ __launch_bounds__(1024) void samp_full_final_kernel(float* logits, int V, const SamplerDev* __restrict__ sp, LmDevState* __restrict__ stt,
+                                                               SampWork* __restrict__ w, SampTail tail) {
     __shared__ int s_tok;
+    __shared__ unsigned long long s_draw;
     const int tid = threadIdx.x;
     if (tid == 0) {
         unsigned long long b = w->cand[0];
         for (int k = 1; k < SAMPF_SLICES; ++k) b = w->cand[k] > b ? w->cand[k] : b;
         const int tok = (int)(0xFFFFFFFFu - (unsigned)(b & 0xFFFFFFFFull));
+        s_draw = stt->rng_counter;
         stt->rng_counter += 1ull;
         stt->out_token = tok;
         if (tail.frame_i >= 0) {
@@ -1260,6 +1348,7 @@ __global__ __launch_bounds__(1024) void samp_full_final_kernel(int V, LmDevState
         s_tok = tok;
     }
     __syncthreads();
+    samp_accept_and_restore(logits, sp, w, s_draw, s_tok, tid);
     for (int b = tid; b < SAMPF_SLICES; b += 1024) w->hist[b] = 0u;   // the top-k sampler expects a zeroed histogram
     if (tail.frame_i >= 0) {   // lm_embed_kernel for the next pair (m = 2), as in samp_final_kernel
         const int id1 = stt->ids[LM_FRAME_USER0 + tail.frame_i];
@@ -1270,6 +1359,168 @@ __global__ __launch_bounds__(1024) void samp_full_final_kernel(int V, LmDevState
             tail.x[e] = tail.f32tab ? reinterpret_cast<const float*>(tail.table)[(long)id * tail.H + hh]
                                     : __uint_as_float((unsigned)reinterpret_cast<const bf16_t*>(tail.table)[(long)id * tail.H + hh] << 16);
         }
+    }
+}
+
+// ---- The "big" path (round 4): top_k > SAMP_MAXK (a rank cut anywhere up to the vocabulary) and / or top_p < 1 without a small top_k
+// (llamacpp_utils.py:39-77 hands both straight to llama.cpp; realtime_agent_config.py:11-13).  llama.cpp sorts the candidates and
+// walks the sorted list; here the two cuts are THRESHOLD KEYS found by radix selects over the 64-bit (value, ~index) keys of the whole
+// vocabulary -- 11 + 11 + 11 + 11 + 11 + 9 bits, one pass per level, 2048-bin histograms:
+//   rank cut:  the top_k-th largest key T_k (histograms of counts);
+//   mass cut:  the key T_p at which the mass of the keys above it first reaches top_p of the candidates' total, walking down from
+//              the top (histograms of mass; the candidates are the keys >= T_k).  Masses are 2^-40 fixed point,
+//              w_i = trunc(exp(v_i - max) * 2^40), so every sum is an integer sum -- independent of the order the atomics land in,
+//              and the C restatement's sorted loop (oracle/sampler_oracle.c) gets the same threshold bit for bit;
+//              need = max(1, trunc(top_p * W)) in double.
+// Every workgroup of pass l first takes level l - 1's decision from that level's histogram (redundantly: a parallel suffix scan by
+// one wave); workgroup 0 records it.  The draw itself is the whole-vocabulary sampler's Gumbel-max pick restricted to keys >= the
+// threshold (and to min_p).
+__device__ __constant__ int samp_rshift[SAMP_LEVELS] = {53, 42, 31, 20, 9, 0};
+__device__ __forceinline__ int samp_rbins(int level) { return level == SAMP_LEVELS - 1 ? 512 : 2048; }
+
+// decision of one level: walking the bins from the top, the bin in which the running total first reaches `need`, and what is still
+// needed inside it.  Called by all 256 threads of a workgroup; wave 0 decides.  total_out (optional): the sum of all bins.
+__device__ void samp_radix_decide(const unsigned long long* __restrict__ hist, int nbins, unsigned long long need, bool need_from_total, float top_p,
+                                  int* bin_out, unsigned long long* need_out) {
+    __shared__ unsigned long long grp[256];
+    __shared__ int s_bin;
+    __shared__ unsigned long long s_need;
+    const int tid = threadIdx.x, per = nbins / 256;      // 8 or 2 bins per thread
+    unsigned long long g = 0;
+    for (int j = 0; j < per; ++j) g += hist[tid * per + j];
+    grp[tid] = g;
+    __syncthreads();
+    if (tid < 64) {
+        unsigned long long s4 = grp[4 * tid] + grp[4 * tid + 1] + grp[4 * tid + 2] + grp[4 * tid + 3];
+        // inclusive suffix sums over the lanes (lane 63 = the top bins)
+        unsigned long long incl = s4;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long o = __shfl_down(incl, off);
+            if (tid + off < 64) incl += o;
+        }
+        const unsigned long long total = __shfl(incl, 0);
+        if (need_from_total) {   // mass cut: the target is a share of the candidates' total mass
+            need = (unsigned long long)((double)top_p * (double)total);
+            if (need < 1ull) need = 1ull;
+        }
+        const unsigned long long above = incl - s4;                   // total of the lanes above this one
+        const bool here = above < need && incl >= need;
+        const unsigned long long vote = __builtin_amdgcn_ballot_w64(here);
+        if (vote == 0ull) {                                           // cannot happen while need <= total; keep the state defined
+            if (tid == 0) { s_bin = 0; s_need = need; }
+        } else if (here) {
+            unsigned long long acc = above;
+            int gi = 4 * tid + 3;
+            for (; gi > 4 * tid; --gi) {
+                if (acc + grp[gi] >= need) break;
+                acc += grp[gi];
+            }
+            int b = gi * per + per - 1;
+            for (; b > gi * per; --b) {
+                if (acc + hist[b] >= need) break;
+                acc += hist[b];
+            }
+            s_bin = b;
+            s_need = need - acc;
+        }
+    }
+    __syncthreads();
+    *bin_out = s_bin;
+    *need_out = s_need;
+    __syncthreads();
+}
+
+// state after level `upto` (prefix of the key fixed so far, what is still needed inside it), for select m (0 rank, 1 mass);
+// upto = -1: the start.  Workgroup 0 records each decision it takes.
+__device__ void samp_radix_state(const SamplerDev* __restrict__ sp, SampWork* __restrict__ w, int m, int upto, unsigned long long* prefix,
+                                 unsigned long long* need) {
+    if (upto < 0) { *prefix = 0ull; *need = m == 0 ? (unsigned long long)sp->big_k : 0ull; return; }
+    unsigned long long pfx = 0ull, nd = m == 0 ? (unsigned long long)sp->big_k : 0ull;
+    if (upto >= 1) { pfx = w->rstate[m][upto - 1][0]; nd = w->rstate[m][upto - 1][1]; }
+    int bin;
+    unsigned long long nd2;
+    samp_radix_decide(w->rhist[m][upto], samp_rbins(upto), nd, m == 1 && upto == 0, sp->top_p, &bin, &nd2);
+    pfx |= (unsigned long long)bin << samp_rshift[upto];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { w->rstate[m][upto][0] = pfx; w->rstate[m][upto][1] = nd2; }
+    *prefix = pfx;
+    *need = nd2;
+}
+__device__ __forceinline__ unsigned long long samp_mass_fx(float d) {   // exp(v - max) in 2^-40 fixed point (d <= 0)
+    return (unsigned long long)(rca_expf(d) * 1099511627776.0f);
+}
+
+// pass `level` of select m over the whole vocabulary
+__global__ __launch_bounds__(256) void samp_radix_pass_kernel(const float* __restrict__ logits, int V, const SamplerDev* __restrict__ sp,
+                                                              SampWork* __restrict__ w, int m, int level) {
+    __shared__ unsigned long long hl[SAMP_BINS];
+    unsigned long long prefix, need;
+    samp_radix_state(sp, w, m, level - 1, &prefix, &need);
+    const int nb = samp_rbins(level), shift = samp_rshift[level];
+    for (int b = threadIdx.x; b < nb; b += 256) hl[b] = 0ull;
+    __syncthreads();
+    const int fixed = level == 0 ? 0 : 64 - samp_rshift[level - 1];       // key bits already decided (from the top)
+    unsigned long long tk = 0ull;
+    float mx = 0.0f;
+    if (m == 1) {
+        if (sp->big_k > 0) tk = w->rstate[0][SAMP_LEVELS - 1][0];          // candidates = keys >= T_k (the rank select is finished)
+        const float* smax = reinterpret_cast<const float*>(w->hist);
+        mx = smax[0];
+        for (int k = 1; k < SAMPF_SLICES; ++k) mx = fmaxf(mx, smax[k]);
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < V; i += gridDim.x * 256) {
+        const float v = logits[i];
+        const unsigned long long key = sample_key(v, (unsigned)i);
+        if (fixed && (key >> (64 - fixed)) != (prefix >> (64 - fixed))) continue;
+        if (m == 1 && key < tk) continue;
+        const unsigned long long add = m == 0 ? 1ull : samp_mass_fx(v - mx);
+        if (add) atomicAdd(&hl[(unsigned)(key >> shift) & (unsigned)(nb - 1)], add);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += 256)
+        if (hl[b]) atomicAdd(&w->rhist[m][level][b], hl[b]);
+}
+// closes select m: the last level's decision fixes the threshold key, recorded in rstate[m][last][0]
+__global__ __launch_bounds__(256) void samp_radix_finish_kernel(const SamplerDev* __restrict__ sp, SampWork* __restrict__ w, int m) {
+    unsigned long long prefix, need;
+    samp_radix_state(sp, w, m, SAMP_LEVELS - 1, &prefix, &need);
+    unsigned long long* hz = &w->rhist[m][0][0];          // the select is done: its histograms are zero again for the next draw
+    for (int b = threadIdx.x; b < SAMP_LEVELS * SAMP_BINS; b += 256) hz[b] = 0ull;
+}
+// the whole-vocabulary pick restricted to keys >= the threshold of the last select that ran
+__global__ __launch_bounds__(1024) void samp_big_pick_kernel(const float* __restrict__ logits, int V, const SamplerDev* __restrict__ sp,
+                                                             const LmDevState* __restrict__ stt, SampWork* __restrict__ w) {
+    __shared__ unsigned long long red[16];
+    const float* smax = reinterpret_cast<const float*>(w->hist);
+    float mx = smax[0];
+    for (int k = 1; k < SAMPF_SLICES; ++k) mx = fmaxf(mx, smax[k]);
+    const unsigned long long thr = w->rstate[sp->big_p ? 1 : 0][SAMP_LEVELS - 1][0];
+    const float inv_t = 1.0f / sp->temp, min_p = sp->min_p;
+    const unsigned long long draw = splitmix(sp->seed, stt->rng_counter);
+    const int per = (V + SAMPF_SLICES - 1) / SAMPF_SLICES;
+    const int i0 = blockIdx.x * per, i1 = min(V, i0 + per);
+    unsigned long long best = 0ull;
+    for (int i = i0 + threadIdx.x; i < i1; i += 1024) {
+        const float v = logits[i];
+        if (sample_key(v, (unsigned)i) < thr) continue;
+        const float d = v - mx;
+        if (min_p > 0.0f && !(rca_expf(d) >= min_p)) continue;
+        const unsigned long long z = splitmix(draw, (unsigned long long)i);
+        const float u = (float)(unsigned)(((z >> 41) << 1) | 1ull) * 5.9604644775390625e-08f;
+        const float g = -rca_logf(-rca_logf(u));
+        const unsigned long long key = sample_key(__builtin_fmaf(d, inv_t, g), (unsigned)i);
+        best = key > best ? key : best;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off);
+        best = o > best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = red[0];
+        for (int k = 1; k < 16; ++k) b = red[k] > b ? red[k] : b;
+        w->cand[blockIdx.x] = b;
     }
 }
 
@@ -1633,7 +1884,8 @@ struct rca_lm {
     int* h_probe = nullptr;        // pinned: [0, 64) probe ids in, [64, 128) their probabilities back (rca_lm_step_probe)
     int n_tokens = 0;           // host mirror (llama_cpp.Llama.n_tokens)
     bool sampler_set = false;
-    bool samp_full = false;     // top_k <= 0: the whole-vocabulary (Gumbel-max) sampler launches instead of the top-k ones
+    bool samp_full = false;     // top_k <= 0 or > SAMP_MAXK: the whole-vocabulary (Gumbel-max) sampler launches instead of the top-k ones
+    bool samp_patch = false, samp_big_k = false, samp_big_p = false;   // which other sampler launches a captured step holds (rca_lm_sampler_init)
     // captured steady-state steps (n = 1, 2)
     // decode-step graphs per (tokens 1..2, context bucket): bucket b launches min(n_splits, 4 << b) attention splits
     // Two sets: the handle's KV cache can be exchanged with a twin's (rca_lm_swap_kv) and the cache address is baked into the
@@ -2126,8 +2378,15 @@ static int lm_common_init(rca_lm* h, const rca_tensor_t* ts, int nt, const rca_l
     if ((rc = lm_alloc((void**)&h->logits, (size_t)h->logits_rows_cap * c.vocab_size * 4)) != RCA_OK) return rc;
     if ((rc = lm_alloc((void**)&h->probs_dev, (64 + 2 * PROBS_SLICES) * 4)) != RCA_OK) return rc;   // [64 probs][slice (max, sum) pairs]
     if ((rc = lm_alloc((void**)&h->probe_ids_dev, 64 * 4)) != RCA_OK) return rc;
-    if ((rc = lm_alloc((void**)&h->att_arrive, 64 * 4)) != RCA_OK) return rc;
-    RCA_HIP(hipMemsetAsync(h->att_arrive, 0, 64 * 4, h->stream));
+    {   // in-launch attention merge: 64 launch counters (tags start at 1: the zeroed granules match nothing), then the granules
+        const size_t gb = ATT_EPOCH_INTS * 4 + (size_t)c.n_kv_heads * h->n_splits * 8 * 66 * 8;
+        if ((rc = lm_alloc((void**)&h->att_arrive, gb)) != RCA_OK) return rc;
+        RCA_HIP(hipMemsetAsync(h->att_arrive, 0, gb, h->stream));
+        int ones[ATT_EPOCH_INTS];
+        for (int i = 0; i < ATT_EPOCH_INTS; ++i) ones[i] = 1;
+        RCA_HIP(hipMemcpyAsync(h->att_arrive, ones, sizeof(ones), hipMemcpyHostToDevice, h->stream));
+        RCA_HIP(hipStreamSynchronize(h->stream));
+    }
     {
         const size_t kmax = (size_t)std::max(std::max(H, AO), c.ffn);
         if ((rc = lm_alloc((void**)&h->xh, (size_t)LM_MAXM * kmax * 2)) != RCA_OK) return rc;
@@ -2466,64 +2725,140 @@ __device__ __forceinline__ float attn_merge_row(const float* __restrict__ base, 
 // part[((qblock * nkv + g) * n_splits + split) * 32 + row][66] = {m, l, o[64]}, row = token_in_block * G + q_head.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short flash_s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 // Diagnostic build only (-DRCA_ATTN_TIMELINE, scripts/attn_timeline.py): thread 0 of every decode-attention workgroup stamps its phases
 // with the 100 MHz wall clock into a buffer no other code reads.
 #ifdef RCA_ATTN_TIMELINE
 __device__ long* rca_attn_tl = nullptr;
 #define ATL_STAMP(k) do { if (atl && threadIdx.x == 0) atl[k] = (long)wall_clock64(); } while (0)
+#define ATL_STAMP_W7(k) do { if (atl && threadIdx.x == 448) atl[k] = (long)wall_clock64(); } while (0)   // the same phases seen by the last wave
 #else
 #define ATL_STAMP(k)
+#define ATL_STAMP_W7(k)
 #endif
 
-#define ATTM_VT_PITCH 40     // fp16 per transposed-V row (32 keys + pad): 8-byte fragment reads stay aligned
-#define ATTM_LDS (8 * 32 * 64 * 4 + 2 * 8 * 32 * 4)   // wo (aliases vt) + wm + wl
+#define ATTM_LDS (8 * 32 * 64 * 4 + 2 * 8 * 32 * 4)   // wo (aliases the K / V images) + wm + wl
 template <int G>
 __global__ __launch_bounds__(512) void lm_attn_mfma_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ qkv,
                                                            const f16_t* __restrict__ kc, const f16_t* __restrict__ vc,
                                                            float* __restrict__ part, int nh, int nkv, int n_splits, float scale, int n_ctx,
                                                            int* __restrict__ arrive, float* __restrict__ attn_out) {
-    // arrive != nullptr (decode steps, one query block, at most one workgroup per CU): the merge of the splits happens HERE -- every
-    // workgroup publishes its partial with write-through (sc1) stores, drains them, and adds to its kv head's arrival counter; the
-    // workgroup whose add comes last re-reads all partials with sc1 loads and writes the attention output, one wave per
-    // (token, head) row with the arithmetic of the separate combine kernel (MI355X_MICROARCH.md, hand-off table row 1: every
-    // handed-off byte stored sc1, vmcnt(0) in every storing wave, workgroup barrier, ONE lane's agent-scope add; the last adder's
-    // waves load behind a barrier that lane joins; every load sc1).  Saves the combine launch (1.7 us dispatch + its round trip).
+    // arrive != nullptr (decode steps: one query block, at most one workgroup per CU, at most 8 live query rows): the merge of the
+    // splits happens HERE, by data-tagged granules (MI355X_MICROARCH.md, price list rows handoff-1to1 / allgather: "granule = one
+    // naturally aligned 8-byte {data, tag} written by ONE sc1 store", polled with sc1 loads; R2: a granule needs no ordering).  Every
+    // workgroup publishes its partial (m, l, o[64]) of the 8 live rows as 528 granules {f32 bits, tag} -- no drain, no barrier, no
+    // ticket -- and leaves; the workgroups of the first splits then gather, one wave per (token, head) row and lane <-> dim, the
+    // granules of every launched split, re-polling until each carries this launch's tag, and merge them in split order with the
+    // arithmetic of the separate combine kernel (same bits).  The tag is the kv head's launch counter arrive[g]: read at entry by every workgroup of the
+    // head, advanced by split 0's workgroup at its very end -- after it has seen every producer's granules, so no workgroup of this
+    // launch can read the new value; the next launch (another layer, the same buffer) starts behind the kernel boundary.  Producers
+    // never wait, so the merger's wait ends whatever the placement; its spin is bounded all the same (a NaN row would tell).
+    // Round 3 did this with drained sc1 stores + an arrival ticket + a re-read by the last arriver: 4.2 us from the last partial's
+    // stores to the merged row at 6.6 k context (profiles/r04/attn_decode_timeline.txt); the granules take the drain, the two
+    // barriers and the ticket round trip out of the chain.
     const bool fused = arrive != nullptr;
 #ifdef RCA_ATTN_TIMELINE
-    long* const atl = (rca_attn_tl && fused) ? rca_attn_tl + ((long)(blockIdx.y * gridDim.x + blockIdx.x) & 1023) * 8 : nullptr;
+    long* const atl = (rca_attn_tl && fused) ? rca_attn_tl + ((long)(blockIdx.y * gridDim.x + blockIdx.x) & 1023) * 16 : nullptr;
 #endif
     ATL_STAMP(0);
-    auto part_store = [&](float* p, float v) {
-        if (fused) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else *p = v;
+    ATL_STAMP_W7(11);
+    unsigned long long* const gran = reinterpret_cast<unsigned long long*>(arrive + ATT_EPOCH_INTS) +
+                                     ((long)blockIdx.x * n_splits + blockIdx.y) * (8 * 66);     // this workgroup's 8 x 66 granules
+    unsigned tag = 0;
+    auto part_store = [&](float* p, float v) { *p = v; };
+    auto gran_store = [&](int row, int e, float v) {
+        __hip_atomic_store(gran + row * 66 + e, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     };
-    __shared__ int s_last;
-    auto arrive_and_merge = [&](int M_) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial stores have left the CU
-        __syncthreads();
-        ATL_STAMP(4);
-        if (threadIdx.x == 0) {
-            const int old = __hip_atomic_fetch_add(arrive + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = old == (int)gridDim.y - 1;
-        }
-        __syncthreads();
-        ATL_STAMP(5);
-        if (!s_last) return;
-        const int w = threadIdx.x >> 6, d = threadIdx.x & 63;       // wave <-> row (token_in_block * G + q head), lane <-> dim
+    auto tag_merge = [&](int M_) {
+        // The rows of a kv head are merged by DIFFERENT workgroups -- row r by the workgroup of split r % nmerge, nmerge = min(8,
+        // launched splits) -- one wave per row, lane <-> dim: a row's sweep is splits x 528 bytes, and eight rows gathered by ONE
+        // workgroup (139 KB of 8-byte sc1 loads through one CU at 6.6 k context) took 2 us per sweep.
+        const int d = threadIdx.x & 63;
+        const int nsp = (int)gridDim.y;
+        const int nmerge = min(nsp, 8);
+        const int w = (int)blockIdx.y + nmerge * (int)(threadIdx.x >> 6);       // row (token_in_block * G + q head) of this wave
         if (w < M_ * G) {
+            const unsigned long long* base = reinterpret_cast<const unsigned long long*>(arrive + ATT_EPOCH_INTS) + ((long)blockIdx.x * n_splits) * (8 * 66) + w * 66;
+            auto gload = [&](const unsigned long long* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+            int spins = 0;
+            // ONE sweep asks for everything the row needs -- (m, l) of split d + 64 c in lane d and this lane's output element of the
+            // first CMB_PRE splits -- and is repeated as a whole until every granule carries the tag: in the common case the merge
+            // costs one memory round trip behind the last producer's stores (two sweeps in sequence, (m, l) first, cost two).
+            unsigned long long gm[ATT_TAG_MAXSP / 64], gl[ATT_TAG_MAXSP / 64], pg[CMB_PRE];
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int c = 0; c < ATT_TAG_MAXSP / 64; ++c) {
+                    gm[c] = gl[c] = (unsigned long long)tag << 32;
+                    if (64 * c < nsp) {
+                        const int spj = min(64 * c + d, nsp - 1);
+                        gm[c] = gload(base + (long)spj * (8 * 66));
+                        gl[c] = gload(base + (long)spj * (8 * 66) + 1);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < CMB_PRE; ++j) pg[j] = gload(base + (long)min(j, nsp - 1) * (8 * 66) + 2 + d);
+#pragma unroll
+                for (int c = 0; c < ATT_TAG_MAXSP / 64; ++c) ok = ok && (unsigned)(gm[c] >> 32) == tag && (unsigned)(gl[c] >> 32) == tag;
+#pragma unroll
+                for (int j = 0; j < CMB_PRE; ++j) ok = ok && (unsigned)(pg[j] >> 32) == tag;
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0ull || ++spins > ATT_TAG_SPINS) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            float ml[ATT_TAG_MAXSP / 64], ll[ATT_TAG_MAXSP / 64];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < ATT_TAG_MAXSP / 64; ++c) {
+                const bool live = 64 * c + d < nsp;
+                ml[c] = live ? __uint_as_float((unsigned)gm[c]) : -INFINITY;
+                ll[c] = live ? __uint_as_float((unsigned)gl[c]) : 0.0f;
+                mx = fmaxf(mx, ml[c]);
+            }
+            mx = wave_max(mx);
+            float L = 0.0f, O = 0.0f;
+#pragma unroll
+            for (int c = 0; c < ATT_TAG_MAXSP / 64; ++c) {
+                if (64 * c >= nsp) break;
+                const float fl = (ml[c] == -INFINITY) ? 0.0f : __expf(ml[c] - mx);
+                for (int j0 = 64 * c; j0 < min(nsp, 64 * c + 64); j0 += CMB_PRE) {
+                    const int cnt = min(CMB_PRE, nsp - j0);
+                    if (j0 > 0) {   // later blocks of CMB_PRE splits (models with fewer kv heads): their granules are long there by now
+                        for (;;) {
+                            bool ok = true;
+#pragma unroll
+                            for (int j = 0; j < CMB_PRE; ++j) pg[j] = gload(base + (long)min(j0 + j, nsp - 1) * (8 * 66) + 2 + d);
+#pragma unroll
+                            for (int j = 0; j < CMB_PRE; ++j) ok = ok && (unsigned)(pg[j] >> 32) == tag;
+                            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull || ++spins > ATT_TAG_SPINS) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < CMB_PRE; ++j) {
+                        if (j < cnt) {
+                            const float f = __shfl(fl, (j0 + j) & 63), l = __shfl(ll[c], (j0 + j) & 63);
+                            const float pv = __uint_as_float((unsigned)pg[j]);
+                            L = __builtin_fmaf(l, f, L);
+                            O = __builtin_fmaf(f == 0.0f ? 0.0f : pv, f, O);
+                        }
+                    }
+                }
+            }
             const int m = w / G, head = blockIdx.x * G + w % G;
-            const float* base = part + ((long)blockIdx.x * n_splits) * 32 * 66 + w * 66;
-            attn_out[(long)m * nh * 64 + head * 64 + d] = attn_merge_row<true>(base, (int)gridDim.y, d);
+            attn_out[(long)m * nh * 64 + head * 64 + d] = spins > ATT_TAG_SPINS ? __builtin_nanf("") : O / L;
         }
-        if (threadIdx.x == 0) __hip_atomic_store(arrive + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
-        __syncthreads();
+        // the next launch's tag (never 0: a zeroed buffer matches nothing).  Written by split 0's workgroup once its row is merged:
+        // by then every producer has stored -- so has read -- this launch's tag; the other rows' mergers compare with the tag they
+        // hold in a register, not with this word.
+        if (blockIdx.y == 0 && threadIdx.x == 0) arrive[blockIdx.x] = (int)(tag + 1u == 0u ? 1u : tag + 1u);
         ATL_STAMP(6);
     };
     constexpr int HD = 64;
     constexpr int TPB = 32 / G;   // tokens per query block
     extern __shared__ __attribute__((aligned(16))) float attm_lds[];
     float (*wo)[32][HD] = reinterpret_cast<float (*)[32][HD]>(attm_lds);                        // [8][32][64]
-    _Float16 (*vt)[HD][ATTM_VT_PITCH] = reinterpret_cast<_Float16 (*)[HD][ATTM_VT_PITCH]>(attm_lds);   // [8][64][40], dead before wo is written
+    // (the waves' K / V images, 8 KB each, alias wo: they are dead before wo is written)
     float (*wm)[32] = reinterpret_cast<float (*)[32]>(attm_lds + 8 * 32 * HD);
     float (*wl)[32] = wm + 8;
     const int g = blockIdx.x, sp = blockIdx.y, qb = blockIdx.z;
@@ -2535,19 +2870,37 @@ __global__ __launch_bounds__(512) void lm_attn_mfma_kernel(const LmDevState* __r
     const int t0 = qb * TPB;
     const int tl = col / G, hq = col % G;
     const int ld = (nh + 2 * nkv) * HD;
-    // every load that does not depend on the step state goes out first (rows past the visible range: clamped, masked)
+    // every load that does not depend on the step state goes out first (rows past the visible range: clamped, masked).
+    // K / V of this wave's 32 keys are loaded in WHOLE ROWS -- lane l of load i takes 16-byte chunk l % 8 of key 8 i + l / 8: 8 cache
+    // lines per instruction -- and reach the MFMA operand layouts through two wave-private 4 KB LDS images (the flash kernel's
+    // swizzles).  Loading the A layout directly (lane <-> key: 16 bytes of each of 32 rows per instruction) made the CU's address
+    // path the bottleneck of the whole launch: round-4 timeline, 1 k context, 32 workgroups: wave 0 had its keys 2.4 us after entry
+    // and wave 7 1.55 us later (profiles/r04/attn_decode_timeline.txt).  K first, then q, then V: S^T starts while V is in flight.
     u32x4 kf[4], vf[4];
     f32x4 qf[4][2];
+    char* const kbytes = reinterpret_cast<char*>(attm_lds) + wave * 8192;   // K image [key][128 bytes], chunk c of key k at c ^ ((k >> 1) & 7)
+    char* const vbytes = kbytes + 4096;                                     // V image, chunk c of key k at c ^ (k1 k2 k0)
+    const int ld_key = lane >> 3, ld_chunk = lane & 7;
     {
-        const long row = ((long)min(kwb + col, n_ctx - 1) * nkv + g) * HD + 8 * half;
+        long roff[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) roff[i] = ((long)min(kwb + 8 * i + ld_key, n_ctx - 1) * nkv + g) * HD + 8 * ld_chunk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kf[i] = *reinterpret_cast<const u32x4*>(kc + roff[i]);
+        // a decode step (fused merge) has at most two tokens: the lanes of the 24 dead query rows load nothing (their scores are
+        // masked whatever q they hold) -- the q loads were as many bytes through the CU's address path as K and V together
         const float* qp = qkv + (long)min(t0 + tl, LM_MAXM - 1) * ld + (g * G + hq) * HD + 8 * half;
 #pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {
-            kf[sub] = *reinterpret_cast<const u32x4*>(kc + row + 16 * sub);
-            vf[sub] = *reinterpret_cast<const u32x4*>(vc + row + 16 * sub);
-            qf[sub][0] = *reinterpret_cast<const f32x4*>(qp + 16 * sub);
-            qf[sub][1] = *reinterpret_cast<const f32x4*>(qp + 16 * sub + 4);
+        for (int sub = 0; sub < 4; ++sub) { qf[sub][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; qf[sub][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+        if (!fused || tl * G < 8) {   // the fused merge is only used while M * G <= 8
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) {
+                qf[sub][0] = *reinterpret_cast<const f32x4*>(qp + 16 * sub);
+                qf[sub][1] = *reinterpret_cast<const f32x4*>(qp + 16 * sub + 4);
+            }
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vf[i] = *reinterpret_cast<const u32x4*>(vc + roff[i]);
     }
     __builtin_amdgcn_sched_barrier(0);
     auto pin_loads = [&]() {
@@ -2559,22 +2912,28 @@ __global__ __launch_bounds__(512) void lm_attn_mfma_kernel(const LmDevState* __r
     const int pos0 = stt->n_tokens;
     const int ntok = min(TPB, M - t0);
     const int kmax = pos0 + t0 + ntok;   // keys [0, kmax) are visible to the last token of the block
+    ATL_STAMP(12);
     float* pout = part + ((long)(qb * nkv + g) * n_splits + sp) * 32 * 66;
+    if (fused) tag = (unsigned)arrive[blockIdx.x];
     if (kbase >= kmax) {   // nothing visible in this split
-        if (threadIdx.x < 32) { part_store(pout + threadIdx.x * 66, -INFINITY); part_store(pout + threadIdx.x * 66 + 1, 0.0f); }
+        if (fused) {   // all 8 x 66 granules, so that the merger has one rule: every granule of every launched split carries the tag
+            for (int i = threadIdx.x; i < 8 * 66; i += 512) gran_store(i / 66, i % 66, (i % 66) == 0 ? -INFINITY : 0.0f);
+        } else if (threadIdx.x < 32) { part_store(pout + threadIdx.x * 66, -INFINITY); part_store(pout + threadIdx.x * 66 + 1, 0.0f); }
         pin_loads();
-        if (fused) arrive_and_merge(M);
+        if (fused && sp < 8) tag_merge(M);   // a launched split beyond the context still merges the rows that fall to it
         return;
     }
-    // ---- V block of this wave, transposed into LDS: vt[wave][dim][key]
+    // ---- K image of this wave (written and read by this wave only: LDS operations of a wave complete in order)
 #pragma unroll
-    for (int sub = 0; sub < 4; ++sub) {
-        const f16x8 v8 = __builtin_bit_cast(f16x8, vf[sub]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) vt[wave][8 * half + 16 * sub + j][col] = v8[j];
+    for (int i = 0; i < 4; ++i) {
+        const int k = 8 * i + ld_key;
+        *reinterpret_cast<u32x4*>(kbytes + k * 128 + ((ld_chunk ^ ((k >> 1) & 7)) << 4)) = kf[i];
     }
-    ATL_STAMP(1);   // V of this wave is in registers (its transposed copy requested)
-    // ---- S^T = K Q^T (hi + lo)
+    ATL_STAMP(13);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- S^T = K Q^T (hi + lo): lane (key = col, half) reads chunk half + 2 sub (dims 8 half + 16 sub .. + 8) of its key
     f32x16 sacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
@@ -2588,10 +2947,19 @@ __global__ __launch_bounds__(512) void lm_attn_mfma_kernel(const LmDevState* __r
             qh[j] = h16;
             ql[j] = (_Float16)(q - (float)h16);
         }
-        const f16x8 kfr = __builtin_bit_cast(f16x8, kf[sub]);
+        const u32x4 kraw = *reinterpret_cast<const u32x4*>(kbytes + col * 128 + (((half | (sub << 1)) ^ ((col >> 1) & 7)) << 4));
+        const f16x8 kfr = __builtin_bit_cast(f16x8, kraw);
         sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfr, qh, sacc, 0, 0, 0);
         sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfr, ql, sacc, 0, 0, 0);
     }
+    // ---- V image (its loads were issued behind K and q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = 8 * i + ld_key;
+        *reinterpret_cast<u32x4*>(vbytes + k * 128 + ((ld_chunk ^ ((((k >> 1) & 1) << 2) | (((k >> 2) & 1) << 1) | (k & 1))) << 4)) = vf[i];
+    }
+    ATL_STAMP(1);   // V of this wave is in registers (its image requested)
+    ATL_STAMP_W7(9);
     // ---- softmax statistics of this wave's 32 keys for query row `col`: registers are keys
     const int qpos = pos0 + t0 + tl;
     const bool qvalid = tl < ntok;
@@ -2631,35 +2999,43 @@ __global__ __launch_bounds__(512) void lm_attn_mfma_kernel(const LmDevState* __r
             ph[i][j] = h16;
             pl[i][j] = (_Float16)(pv - (float)h16);
         }
-    // vt[wave] is written and read by this wave only
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- O = P V: dims 32 * nt + col; slot j of MFMA i, half h is key 16 i + 4 h + 8 (j >> 2) + (j & 3)
+    // ---- O = P V: dims 32 * nt + col; slot j of MFMA i, half h is key 16 i + 4 h + 8 (j >> 2) + (j & 3).  Transposed reads:
+    // lane 4 q + p of a 16-lane group supplies row (key) q, dims 4 p .. 4 p + 3 of the group's 16 dims
     f32x16 oacc[2];
+    {
+        const int l16 = lane & 15, q4 = l16 >> 2, pp = l16 & 3;
+        const int sw = ((q4 >> 1) << 2) | (half << 1) | (q4 & 1);   // rows 16 i + 4 half + q4 (+ 8)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < 2; ++nt) {
+            const int tr_off = (4 * half + q4) * 128 + (((4 * nt + 2 * (col >> 4) + (pp >> 1)) ^ sw) << 4) + 8 * (pp & 1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[nt][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) oacc[nt][r] = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const _Float16* vrow = &vt[wave][32 * nt + col][16 * i + 4 * half];
-            const f16x4 v0 = *reinterpret_cast<const f16x4*>(vrow);
-            const f16x4 v1 = *reinterpret_cast<const f16x4*>(vrow + 8);
-            // keys past the visible range may hold anything (their p is 0): zero them
-            f16x8 vb;
+            for (int i = 0; i < 2; ++i) {
+                const char* tp = vbytes + tr_off + 16 * i * 128;
+                const flash_s16x4 t0v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) flash_s16x4*)tp);
+                const flash_s16x4 t1v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) flash_s16x4*)(tp + 8 * 128));
+                const f16x4 v0 = __builtin_bit_cast(f16x4, t0v), v1 = __builtin_bit_cast(f16x4, t1v);
+                // keys past the visible range may hold anything (their p is 0): zero them
+                f16x8 vb;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int key = kwb + 16 * i + 4 * half + 8 * (j >> 2) + (j & 3);
-                const _Float16 x = j < 4 ? v0[j] : v1[j - 4];
-                vb[j] = key < kmax ? x : (_Float16)0.0f;
+                for (int j = 0; j < 8; ++j) {
+                    const int key = kwb + 16 * i + 4 * half + 8 * (j >> 2) + (j & 3);
+                    const _Float16 x = j < 4 ? v0[j] : v1[j - 4];
+                    vb[j] = key < kmax ? x : (_Float16)0.0f;
+                }
+                oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[i], vb, oacc[nt], 0, 0, 0);
+                oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl[i], vb, oacc[nt], 0, 0, 0);
             }
-            oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[i], vb, oacc[nt], 0, 0, 0);
-            oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl[i], vb, oacc[nt], 0, 0, 0);
         }
     }
     ATL_STAMP(2);      // S, softmax, P V of this wave
+    ATL_STAMP_W7(10);
     __syncthreads();   // every wave is done with vt: wo may overwrite it
+    ATL_STAMP(7);
     if (half == 0) { wm[wave][col] = mx; wl[wave][col] = lsum; }
     // (a decode step has at most 8 live query rows -- registers 0..3 of the accumulators: the other 24 rows are never merged)
 #pragma unroll
@@ -2668,6 +3044,7 @@ __global__ __launch_bounds__(512) void lm_attn_mfma_kernel(const LmDevState* __r
         for (int r = 0; r < 16; ++r)
             if (r < 4 || !fused) wo[wave][(r & 3) + 8 * (r >> 2) + 4 * half][32 * nt + col] = oacc[nt][r];
     __syncthreads();
+    ATL_STAMP(8);
     // ---- merge the 8 waves, write the split partial (a decode step has M * G <= 8 live rows of the 32: the others are skipped)
     const int live_rows = fused ? M * G : 32;
     for (int i = threadIdx.x; i < live_rows * HD; i += 512) {
@@ -2682,22 +3059,27 @@ __global__ __launch_bounds__(512) void lm_attn_mfma_kernel(const LmDevState* __r
             L = __builtin_fmaf(wl[w][r], f, L);
             O = __builtin_fmaf(wo[w][r][d], f, O);
         }
-        part_store(pout + r * 66 + 2 + d, O);
-        if (d == 0) { part_store(pout + r * 66, m2); part_store(pout + r * 66 + 1, L); }
+        if (fused) {
+            gran_store(r, 2 + d, O);
+            if (d == 0) { gran_store(r, 0, m2); gran_store(r, 1, L); }
+        } else {
+            part_store(pout + r * 66 + 2 + d, O);
+            if (d == 0) { part_store(pout + r * 66, m2); part_store(pout + r * 66 + 1, L); }
+        }
     }
     ATL_STAMP(3);      // 8 waves merged, partial stores issued
-    if (fused) arrive_and_merge(M);
+    if (fused && sp < 8) tag_merge(M);
 }
 #ifdef RCA_ATTN_TIMELINE
 extern "C" int rca_debug_attn_timeline(long* out_host, int enable) {   // enable: allocate + arm; else copy the 1024 x 8 stamps out
     static long* buf = nullptr;
     if (enable) {
-        if (!buf) { if (hipMalloc((void**)&buf, 1024 * 8 * sizeof(long)) != hipSuccess) return 1; }
-        (void)hipMemset(buf, 0, 1024 * 8 * sizeof(long));
+        if (!buf) { if (hipMalloc((void**)&buf, 1024 * 16 * sizeof(long)) != hipSuccess) return 1; }
+        (void)hipMemset(buf, 0, 1024 * 16 * sizeof(long));
         return hipMemcpyToSymbol(HIP_SYMBOL(rca_attn_tl), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
     }
     (void)hipDeviceSynchronize();
-    return buf && hipMemcpy(out_host, buf, 1024 * 8 * sizeof(long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+    return buf && hipMemcpy(out_host, buf, 1024 * 16 * sizeof(long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }
 #endif
 #ifdef RCA_ATTN_TIMELINE
@@ -2769,7 +3151,6 @@ __global__ __launch_bounds__(64) void lm_attn_mfma_combine_kernel(const LmDevSta
 // each of 32 cache lines per instruction: 4100 of 4900 cycles per block were spent waiting on the L1) -> one workgroup per CU ~78.
 #define FLASH_WAVES 3        // waves that split the key blocks of one query tile
 #define FLASH_OPITCH 68      // f32 per query row of a wave's O in the merge buffer
-typedef short flash_s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 // TEAMS query tiles per workgroup (a team = FLASH_WAVES waves = one tile).  With 4 teams a workgroup takes more than half of a CU's
 // LDS, so every CU gets exactly one and the dispatcher cannot pile five tiles on one CU and three on another (measured with one tile
 // per workgroup: 414 .. 730 key blocks per CU, the last CU done at 135 us against a median of 101); the four tiles of workgroup j
@@ -3116,7 +3497,7 @@ static void launch_attention_mfma(rca_lm* h, int M, int nsp_launch, const f16_t*
     }
     // decode steps: the merge of the splits is fused into the attention launch while the grid is at most one workgroup per CU (the
     // regime the sc1 hand-off is measured for); prefill tiles and longer contexts keep the separate combine launch
-    const bool fuse = h->fuse_attn && !hi && agm.z == 1 && c.n_kv_heads * nsp_launch <= 256 && M * G <= 8;
+    const bool fuse = h->fuse_attn && !hi && agm.z == 1 && c.n_kv_heads * nsp_launch <= 256 && M * G <= 8 && nsp_launch <= ATT_TAG_MAXSP && c.n_kv_heads <= ATT_EPOCH_INTS;
     int* arrive = fuse ? h->att_arrive : nullptr;
 #define RCA_ATTN_LAUNCH(GG)                                                                                                                        \
     lm_attn_mfma_kernel<GG><<<agm, 512, ATTM_LDS, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx, \
@@ -3874,18 +4255,26 @@ extern "C" int rca_lm_get_logits_row(rca_lm_t* h, int32_t row, float* out_host) 
 extern "C" int rca_lm_sampler_init(rca_lm_t* h, const rca_sampler_params_t* p) {
     if (!h || !p) return fail(RCA_ERR_ARG, "null");
     if (p->n_bias < 0 || p->n_bias > 8) return fail(RCA_ERR_ARG, "at most 8 logit-bias entries");
-    // llama.cpp reads top_k <= 0 as "whole vocabulary"; the device sampler ranks at most SAMP_MAXK candidates, so anything it
-    // cannot honour is refused instead of being clamped silently (greedy, temp <= 0, needs one candidate whatever top_k says)
-    if (p->temp > 0.0f && p->top_k > SAMP_MAXK)
-        return fail(RCA_ERR_ARG, "sampler: top_k %d unsupported (1..%d, or <= 0 = whole vocabulary)", p->top_k, SAMP_MAXK);
-    if (p->temp > 0.0f && p->top_k <= 0 && p->top_p < 1.0f)
-        return fail(RCA_ERR_ARG, "sampler: top_k %d (whole vocabulary) with top_p %g < 1 is not implemented (top_p >= 1 is; min_p and temp apply)", p->top_k, (double)p->top_p);
-    const bool full = p->temp > 0.0f && p->top_k <= 0;
+    // llama.cpp reads top_k <= 0 as "whole vocabulary" and honours any top_k up to it; penalties default to off.  Nothing is clamped:
+    // 1..SAMP_MAXK ranked candidates take the serial chain (float sums, inverse-CDF draw), everything else the whole-vocabulary
+    // sampler -- plain (top_p >= 1, no rank cut) or with the radix-select thresholds of the "big" path.
+    const int V = h->cfg.vocab_size;
+    if (!(p->repeat_penalty > 0.0f) && p->repeat_penalty != 0.0f) return fail(RCA_ERR_ARG, "sampler: repeat_penalty %g must be positive", (double)p->repeat_penalty);
+    const float rep = p->repeat_penalty == 0.0f ? 1.0f : p->repeat_penalty;    // a zero-initialised struct (older callers) means "off"
+    const bool stoch = p->temp > 0.0f;
+    const bool full = stoch && (p->top_k <= 0 || p->top_k > SAMP_MAXK);
+    const bool big_k = full && p->top_k > SAMP_MAXK && p->top_k < V;
+    const bool big_p = full && p->top_p < 1.0f;
+    const bool pen = rep != 1.0f || p->freq_penalty != 0.0f || p->presence_penalty != 0.0f;
+    const bool patch = p->n_bias > 0 || pen;
     RCA_HIP(hipSetDevice(h->device));
     SamplerDev s;
     memset(&s, 0, sizeof(s));
     s.top_k = p->top_k; s.top_p = p->top_p; s.min_p = p->min_p; s.temp = p->temp; s.seed = p->seed; s.n_bias = p->n_bias;
     for (int i = 0; i < p->n_bias; ++i) { s.bias_ids[i] = p->bias_ids[i]; s.bias_vals[i] = p->bias_vals[i]; }
+    s.repeat_penalty = rep; s.freq_penalty = p->freq_penalty; s.presence_penalty = p->presence_penalty;
+    s.last_n = p->penalty_last_n > 0 ? std::min(p->penalty_last_n, 64) : (p->penalty_last_n == 0 ? 64 : 0);   // 0 = llama-cpp-python's default window, < 0 = off
+    s.patch = patch ? 1 : 0; s.big_k = big_k ? p->top_k : 0; s.big_p = big_p ? 1 : 0;
     RCA_HIP(hipStreamSynchronize(h->stream));
     RCA_HIP(hipMemcpy(h->samp, &s, sizeof(s), hipMemcpyHostToDevice));
     // set_seed restarts the stream of draws (llamacpp_utils.py:58)
@@ -3893,19 +4282,30 @@ extern "C" int rca_lm_sampler_init(rca_lm_t* h, const rca_sampler_params_t* p) {
     RCA_HIP(hipMemcpy(&h->stt->rng_counter, &zero, 8, hipMemcpyHostToDevice));
     h->rng_host = 0;
     h->sampler_set = true;
-    if (full != h->samp_full) lm_drop_graphs(h);   // the captured steps hold the other sampler's launches
-    h->samp_full = full;
+    if (full != h->samp_full || patch != h->samp_patch || big_k != h->samp_big_k || big_p != h->samp_big_p)
+        lm_drop_graphs(h);   // the captured steps hold another set of sampler launches
+    h->samp_full = full; h->samp_patch = patch; h->samp_big_k = big_k; h->samp_big_p = big_p;
     return RCA_OK;
 }
 
 // frame_i >= 0: step i of a frame graph -- the sampler's tail also advances the device state and gathers the next pair's embeddings
-static void lm_enqueue_sample(rca_lm* h, const float* lg, hipStream_t st, int frame_i = -1) {
+static void lm_enqueue_sample(rca_lm* h, float* lg, hipStream_t st, int frame_i = -1) {
     const int V = h->cfg.vocab_size;
     const SampTail tail{frame_i, h->embed, h->embed_f32, h->x, h->cfg.hidden};
-    if (h->samp_full) {   // top_k <= 0: whole vocabulary (Gumbel-max)
+    if (h->samp_patch) samp_prepare_kernel<<<1, 128, 0, st>>>(lg, V, h->samp, h->stt, h->swork);   // logit bias / penalties, in place
+    if (h->samp_full) {   // top_k <= 0 or > SAMP_MAXK: whole vocabulary (Gumbel-max), with a rank and / or mass threshold on the big path
         samp_full_max_kernel<<<SAMPF_SLICES, 1024, 0, st>>>(lg, V, h->samp, h->swork);
-        samp_full_pick_kernel<<<SAMPF_SLICES, 1024, 0, st>>>(lg, V, h->samp, h->stt, h->swork);
-        samp_full_final_kernel<<<1, 1024, 0, st>>>(V, h->stt, h->swork, tail);
+        if (h->samp_big_k || h->samp_big_p) {
+            for (int m = 0; m < 2; ++m) {
+                if (!(m == 0 ? h->samp_big_k : h->samp_big_p)) continue;
+                for (int l = 0; l < SAMP_LEVELS; ++l) samp_radix_pass_kernel<<<128, 256, 0, st>>>(lg, V, h->samp, h->swork, m, l);
+                samp_radix_finish_kernel<<<1, 256, 0, st>>>(h->samp, h->swork, m);
+            }
+            samp_big_pick_kernel<<<SAMPF_SLICES, 1024, 0, st>>>(lg, V, h->samp, h->stt, h->swork);
+        } else {
+            samp_full_pick_kernel<<<SAMPF_SLICES, 1024, 0, st>>>(lg, V, h->samp, h->stt, h->swork);
+        }
+        samp_full_final_kernel<<<1, 1024, 0, st>>>(lg, V, h->samp, h->stt, h->swork, tail);
         return;
     }
     samp_hist_kernel<<<128, 256, 0, st>>>(lg, V, h->samp, h->swork);
@@ -3926,7 +4326,7 @@ extern "C" int rca_lm_sample(rca_lm_t* h, int32_t* token) {
     if (!h->sampler_set) return fail(RCA_ERR_STATE, "sampler not initialised");
     if (h->logits_rows < 1) return fail(RCA_ERR_STATE, "no logits: call eval first");
     RCA_HIP(hipSetDevice(h->device));
-    const float* lg = h->logits + (long)(h->logits_rows - 1) * h->cfg.vocab_size;
+    float* lg = h->logits + (long)(h->logits_rows - 1) * h->cfg.vocab_size;
     lm_enqueue_sample(h, lg, h->stream);
     RCA_LAUNCH_CHECK();
     h->rng_host += 1;

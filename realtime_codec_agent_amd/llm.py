@@ -274,6 +274,7 @@ class LlamaForAlternatingCodeChannels:
         self._seed = seed
         self._sampler_params = None
         self._mfma_prefill = True
+        self.last_n_tokens_size = 64      # llama_cpp.Llama's default penalty window (the reference never overrides it)
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -393,10 +394,12 @@ class LlamaForAlternatingCodeChannels:
         seed: Optional[int] = None,
         logit_bias: Optional[Dict[int, float]] = None,
     ) -> None:
-        """llamacpp_utils.py:39-77.  Supported chain: logit bias -> top_k -> top_p -> min_p -> temp -> dist
-        (the only members the agent configures, realtime_agent_v2.py:172-185); penalties must be neutral."""
-        if repeat_penalty != 1.0 or frequency_penalty != 0.0 or presence_penalty != 0.0 or typical_p != 1.0 or mirostat_mode != 0 or grammar is not None:
-            raise NotImplementedError("only the sampler members the duplex agent uses are implemented")
+        """llamacpp_utils.py:39-77.  The chain llama-cpp-python builds for these arguments, on the device: logit bias (the logits
+        processor) -> penalties over the last 64 accepted tokens (repeat / frequency / presence) -> top_k -> top_p -> min_p -> temp ->
+        dist -- every member the agent's config forwards (realtime_agent_v2.py:172-185, realtime_agent_config.py:11-20), top_k anywhere
+        from 1 to the vocabulary or <= 0.  typical_p, mirostat and grammars are not part of the duplex path and are refused."""
+        if typical_p != 1.0 or mirostat_mode != 0 or grammar is not None:
+            raise NotImplementedError("typical_p / mirostat / grammar samplers are not implemented (the duplex agent never sets them)")
         self.set_seed(seed if seed is not None else -1)
         bias = dict(logit_bias or {})
         if logits_processor is not None:
@@ -407,10 +410,13 @@ class LlamaForAlternatingCodeChannels:
         ids = (C.c_int32 * max(1, len(bias)))(*bias.keys())
         vals = (C.c_float * max(1, len(bias)))(*bias.values())
         p = N.SamplerParamsC(top_k=int(top_k), top_p=float(top_p), min_p=float(min_p), temp=float(temp), seed=self._seed,
-                             n_bias=len(bias), bias_ids=ids, bias_vals=vals)
+                             n_bias=len(bias), bias_ids=ids, bias_vals=vals, repeat_penalty=float(repeat_penalty),
+                             freq_penalty=float(frequency_penalty), presence_penalty=float(presence_penalty),
+                             penalty_last_n=int(getattr(self, "last_n_tokens_size", 64)))
         N.check(self._lib.rca_lm_sampler_init(self._h, C.byref(p)), "rca_lm_sampler_init")
         self._sampler = True
-        self._sampler_params = dict(top_k=top_k, top_p=top_p, min_p=min_p, temp=temp, seed=self._seed, logit_bias=bias)
+        self._sampler_params = dict(top_k=top_k, top_p=top_p, min_p=min_p, temp=temp, seed=self._seed, logit_bias=bias,
+                                    repeat_penalty=repeat_penalty, frequency_penalty=frequency_penalty, presence_penalty=presence_penalty)
 
     def sample(self, idx: Optional[int] = None) -> int:
         assert self.n_tokens > 0

@@ -1,7 +1,7 @@
 """Per-wave timeline of conv1d_mfma_kernel.  Needs a library built with -DRCA_CONV_TIMELINE:
-    RCA_EXTRA_HIPCC_FLAGS=-DRCA_CONV_TIMELINE python -c "from realtime_codec_agent_amd import _native; _native.build()"
+    export RCA_EXTRA_HIPCC_FLAGS=-DRCA_CONV_TIMELINE RCA_LIB_PATH=/tmp/rca_convtl.so; python -c "from realtime_codec_agent_amd import _native; _native.build()"
     RCA_CONV_TIMELINE_OUT=/tmp/tl.bin python scripts/conv_timeline.py && RCA_CONV_TIMELINE_OUT=/tmp/tl.bin python scripts/conv_timeline.py analyse
-(rebuild afterwards with _native.build(force=True) and no flag: the stamps cost a few registers).
+(RCA_LIB_PATH keeps the diagnostic build away from the in-tree library: _native.build refuses extra flags without it).
 
 Runs two bench-shaped encode passes (256 windows), lets the library dump (t_entry, t_loop, t_epilogue, t_exit, HW_ID)
 per wave at codec destruction and prints, per layer: prologue / chunk loop / epilogue time of a wave and the gap between

@@ -4,7 +4,8 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from realtime_codec_agent_amd import _native
-_native.build(force=True)
+assert os.environ.get('RCA_LIB_PATH'), 'set RCA_LIB_PATH: the diagnostic build must not replace the in-tree library'
+_native.build()
 from realtime_codec_agent_amd.llm import LlamaForAlternatingCodeChannels, LMConfig
 prefix = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 tile = int(sys.argv[2]) if len(sys.argv) > 2 else 1024

@@ -213,15 +213,20 @@ class OracleLLM:
             self._logits = np.ascontiguousarray(self.ref.eval(tokens, last_only=True, chunk=512)[-1].numpy(), dtype=np.float32)
             self.n_evals += 1
 
-    def init_sampler_for_generate(self, top_k=40, top_p=0.95, min_p=0.05, temp=0.8, seed=None, logits_processor=None, **_):
+    def init_sampler_for_generate(self, top_k=40, top_p=0.95, min_p=0.05, temp=0.8, seed=None, logits_processor=None,
+                                  repeat_penalty=1.0, frequency_penalty=0.0, presence_penalty=0.0, **_):
         bias = dict(getattr(logits_processor, "logit_bias_map", {}) or {})
-        self._sampler = dict(top_k=top_k, top_p=top_p, min_p=min_p, temp=temp, seed=(seed if seed is not None else -1) & 0xFFFFFFFF, bias=bias)
+        self._sampler = dict(top_k=top_k, top_p=top_p, min_p=min_p, temp=temp, seed=(seed if seed is not None else -1) & 0xFFFFFFFF, bias=bias,
+                             pen=dict(repeat_penalty=repeat_penalty, frequency_penalty=frequency_penalty, presence_penalty=presence_penalty))
         self._counter = 0
+        self._accepted = []          # a fresh llama.cpp sampler starts with an empty penalty window
 
     def sample(self, idx=None):
         s = self._sampler
-        tok = self._lm_ref.sample(self._logits, s["top_k"], s["top_p"], s["min_p"], s["temp"], s["seed"], self._counter, s["bias"])
+        tok = self._lm_ref.sample(self._logits, s["top_k"], s["top_p"], s["min_p"], s["temp"], s["seed"], self._counter, s["bias"],
+                                  prev_tokens=self._accepted, **s["pen"])
         self._counter += 1
+        self._accepted.append(tok)
         return tok
 
     def generate(self, tokens, reset=False):

@@ -195,6 +195,122 @@ def test_whole_vocabulary_sampler_matches_restatement(min_p, temp):
     assert llm.step(ids[9:11].tolist()) == seqs[0][0]
 
 
+def test_sampler_penalties_match_restatement_and_leave_the_logits_raw():
+    """repeat / frequency / presence penalties (realtime_agent_v2.py:172-185 forwards realtime_agent_config.py:18-20 to llama.cpp's
+    penalties sampler, window = the last 64 tokens the sampler accepted): applied on the device in place, undone by the sampler's
+    last kernel.  Token for token the C restatement's choice given the device's logits and the history of sampled tokens -- 150 steps
+    (the 128-slot ring wraps, the 64-token window slides), eager and graph replays -- together with a logit bias; the logits the caller
+    reads afterwards are the RAW ones (llama.cpp penalises its candidate copy, never the context's logits); a frame graph equals
+    single steps, also when it is cut short (the speculative steps' tokens must leave the window again)."""
+    from realtime_codec_agent_amd.llm import get_logits_bias_processor
+    llm, w, ids = make_llm("llama3")
+    ids = ids.tolist()
+    pen = dict(repeat_penalty=1.3, frequency_penalty=0.25, presence_penalty=0.15)
+    params = dict(top_k=20, top_p=1.0, min_p=0.0, temp=1.0, seed=77, **pen)
+    seqs = []
+    for use_graph in (True, False):
+        llm.set_graphs(use_graph)
+        llm.reset()
+        llm.init_sampler_for_generate(logits_processor=get_logits_bias_processor({5: 2.0, 120: -3.0}), **params)
+        llm.eval(ids[:9])
+        toks, hist = ids[9:11], []
+        for step in range(150):
+            if step == 60:
+                llm.n_tokens = 11          # keep the context inside n_ctx: roll the cache back, the sampler's history stays (as in llama.cpp)
+            t = llm.step(toks)
+            want = lm_ref.sample(llm._scores[-1], 20, 1.0, 0.0, 1.0, 77, step, {5: 2.0, 120: -3.0}, prev_tokens=hist, **pen)
+            assert t == want, (use_graph, step, t, want)
+            hist.append(t)
+            toks = [t, ids[9 + (step % 20)]]
+            if step == 100:
+                llm.n_tokens = 11
+        seqs.append(hist)
+    assert seqs[0] == seqs[1]
+    plain = []
+    llm.reset(); llm.init_sampler_for_generate(top_k=20, top_p=1.0, min_p=0.0, temp=1.0, seed=77); llm.eval(ids[:9])
+    toks = ids[9:11]
+    for step in range(40):
+        t = llm.step(toks); plain.append(t); toks = [t, ids[9 + (step % 20)]]
+    assert plain != seqs[0][:40]                      # the penalties really change the stream
+    # raw logits after a penalised draw: eval -> logits -> sample -> the same logits
+    llm.reset(); llm.init_sampler_for_generate(**params); llm.eval(ids[:9]); llm.eval(ids[9:11])
+    for _ in range(3):
+        llm.sample()
+    before = llm._scores[-1].copy()
+    llm.sample()
+    assert np.array_equal(llm._scores[-1], before)
+    llm.n_tokens = 9; llm.eval(ids[9:11])
+    assert np.array_equal(llm._scores[-1], before)
+    # frame graph == single steps, whole and cut short
+    llm.set_graphs(True)
+
+    def run(use_frame, fl):
+        llm.reset(); llm.init_sampler_for_generate(**params); llm.eval(ids[:9])
+        for _ in range(5):                         # a history before the frame
+            llm.sample()
+        if use_frame:
+            toks = llm.frame(ids[9:11], ids[11:15], fl)
+        else:
+            toks, cur = [], ids[9:11]
+            for u in ids[11:15]:
+                t = llm.step(cur); toks.append(t)
+                if t <= fl:
+                    break
+                cur = [t, u]
+        follow = [llm.step([toks[-1], ids[20]])]
+        follow.append(llm.step([follow[0], ids[21]]))
+        return toks, follow, llm.n_tokens
+    whole = run(True, -1)
+    assert whole == run(False, -1) and len(whole[0]) == 4
+    fl = whole[0][1]                               # the second sampled token counts as "not audio": the frame is cut there (or at the first)
+    cut = run(True, fl)
+    assert cut == run(False, fl) and len(cut[0]) <= 2
+
+
+@pytest.mark.parametrize("top_k,top_p,min_p,temp", [(1000, 1.0, 0.0, 1.0), (0, 0.9, 0.0, 1.0), (3000, 0.7, 0.01, 0.8), (-1, 0.35, 0.0, 1.2)])
+def test_big_path_sampler_matches_restatement(top_k, top_p, min_p, temp):
+    """top_k > 256 (a rank cut up to the vocabulary) and top_p < 1 without a small top_k -- values llamacpp_utils.py:39-77 passes
+    straight to llama.cpp, refused here until round 4: the thresholds come from radix selects over the whole vocabulary (counts /
+    fixed-point masses), the draw is the whole-vocabulary Gumbel-max pick above them.  Token for token the C restatement (which sorts
+    the vocabulary and walks it) on an 8192-token model, eager, graph replays and a frame graph; with penalties on top; and the
+    histograms are left clean for the next draw (a second sampler configuration on the same handle stays right)."""
+    from realtime_codec_agent_amd.llm import LlamaForAlternatingCodeChannels, LMConfig
+    cfg = LMConfig(vocab_size=8192, hidden=512, n_layers=2, n_heads=8, n_kv_heads=2, head_dim=64, ffn=1024)
+    llm = LlamaForAlternatingCodeChannels(model_path="random:mid", config=cfg, n_ctx=512, random_seed=3, init_std=0.05, device=0)
+    ids = np.random.default_rng(4).integers(0, 8192, 80).tolist()
+    params = dict(top_k=top_k, top_p=top_p, min_p=min_p, temp=temp, seed=31)
+    seqs = []
+    for use_graph in (True, False):
+        llm.set_graphs(use_graph)
+        llm.reset(); llm.init_sampler_for_generate(**params); llm.eval(ids[:30])
+        toks, out = ids[30:32], []
+        for step in range(20):
+            t = llm.step(toks)
+            want = lm_ref.sample(llm._scores[-1], top_k, top_p, min_p, temp, 31, step)
+            assert t == want, (use_graph, step, t, want)
+            out.append(t)
+            toks = [t, ids[32 + step]]
+        seqs.append(out)
+    assert seqs[0] == seqs[1] and len(set(seqs[0])) > 8
+    llm.set_graphs(True)
+    llm.reset(); llm.init_sampler_for_generate(**params); llm.eval(ids[:30])
+    assert llm.frame(ids[30:32], ids[32:36], -1) == seqs[0][:4]
+    # penalties on top of the big path
+    pen = dict(repeat_penalty=1.2, frequency_penalty=0.3, presence_penalty=0.0)
+    llm.reset(); llm.init_sampler_for_generate(**params, **pen); llm.eval(ids[:30])
+    toks, hist = ids[30:32], []
+    for step in range(12):
+        t = llm.step(toks)
+        assert t == lm_ref.sample(llm._scores[-1], top_k, top_p, min_p, temp, 31, step, prev_tokens=hist, **pen), step
+        hist.append(t); toks = [t, ids[32 + step]]
+    # another configuration on the same handle: the small-k chain, then the plain whole-vocabulary sampler
+    llm.reset(); llm.init_sampler_for_generate(top_k=50, top_p=0.9, min_p=0.0, temp=1.0, seed=5); llm.eval(ids[:30])
+    assert llm.step(ids[30:32]) == lm_ref.sample(llm._scores[-1], 50, 0.9, 0.0, 1.0, 5, 0)
+    llm.reset(); llm.init_sampler_for_generate(top_k=0, top_p=1.0, min_p=0.0, temp=1.0, seed=5); llm.eval(ids[:30])
+    assert llm.step(ids[30:32]) == lm_ref.sample(llm._scores[-1], 0, 1.0, 0.0, 1.0, 5, 0)
+    llm.close()
+
+
 def test_step_probe_equals_step_plus_token_probs():
     """rca_lm_step_probe (the agent's speculative <|end_audio|> step as one replay): same token, same probabilities, same state as
     step() followed by token_probs(), replayed and eager, across a graph-bucket boundary, and the rollback afterwards works."""
@@ -268,9 +384,12 @@ def test_sampler_and_token_ids_are_validated():
     vocabulary are an error, not a clamped embedding row."""
     from realtime_codec_agent_amd._native import RcaError
     llm, w, ids = make_llm("default")
-    for bad in (dict(top_k=257, top_p=1.0), dict(top_k=0, top_p=0.9), dict(top_k=-1, top_p=0.5)):
-        with pytest.raises(RcaError):
-            llm.init_sampler_for_generate(min_p=0.0, temp=1.0, seed=1, **bad)
+    for ok in (dict(top_k=257, top_p=1.0), dict(top_k=0, top_p=0.9), dict(top_k=-1, top_p=0.5), dict(top_k=10 ** 6, top_p=0.5)):
+        llm.init_sampler_for_generate(min_p=0.0, temp=1.0, seed=1, **ok)          # refused until round 4; llama.cpp honours them all
+    with pytest.raises(RcaError):
+        llm.init_sampler_for_generate(top_k=20, top_p=1.0, min_p=0.0, temp=1.0, seed=1, repeat_penalty=-1.0)
+    with pytest.raises(NotImplementedError):
+        llm.init_sampler_for_generate(top_k=20, top_p=1.0, min_p=0.0, temp=1.0, seed=1, typical_p=0.5)
     llm.init_sampler_for_generate(top_k=0, top_p=1.0, min_p=0.0, temp=0.0, seed=1)      # greedy ignores top_k
     llm.init_sampler_for_generate(top_k=256, top_p=1.0, min_p=0.0, temp=1.0, seed=1)
     llm.eval(ids[:4].tolist())
