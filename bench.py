@@ -85,10 +85,13 @@ def cpu_baseline_lm_step(cfg, ctx_tokens=64, steps=3):
                        f"context {ctx_tokens}+ tokens; weights regenerated from the device hash in {gen_s:.1f} s")
 
 
-def batch_cli_leg(hours=0.5, seed=0):
+def batch_cli_leg(hours=2.0, seed=0):
     """The SAME encode through the batch CLI (`audio_to_codes`, the drop-in for codec_bpe.audio_to_codes in encode_audio_gpu_*.sh) on
     a synthetic corpus of 10-60 s stereo .wav utterances written to a temporary directory: file reading, cross-file window batching,
-    H2D, encode, D2H and .npy writing included -- the deployment-level number next to the kernel-level `value`."""
+    H2D, encode, D2H and .npy writing included -- the deployment-level number next to the kernel-level `value`.  2 h of audio (~2.3 s
+    of encoding: several super-batches, so that start-up and steady state can be told apart): `value` is end to end;
+    `gpu_busy_fraction` = encoder time on the GPU / wall time of the pipeline; `steady_state` leaves out the time before the first
+    super-batch reached the GPU."""
     import shutil
     import tempfile
     import wave
@@ -101,8 +104,9 @@ def batch_cli_leg(hours=0.5, seed=0):
         while total < hours * 3600:
             secs = float(rng.uniform(10, 60))
             n = int(secs * 16000)
-            t = np.arange(n) / 16000.0
-            sig = np.stack([0.1 * np.sin(2 * np.pi * f * t) + rng.normal(0, 0.02, n) for f in (220.0 + i, 330.0 + i)])
+            t = np.arange(n, dtype=np.float32) / np.float32(16000.0)
+            noise = rng.standard_normal((2, n), dtype=np.float32) * np.float32(0.02)
+            sig = np.stack([np.float32(0.1) * np.sin(np.float32(2 * np.pi * f) * t) for f in (220.0 + i, 330.0 + i)]) + noise
             d = os.path.join(raw, f"spk{i % 7:02d}")
             os.makedirs(d, exist_ok=True)
             with wave.open(os.path.join(d, f"utt{i:04d}.wav"), "wb") as w:
@@ -114,8 +118,17 @@ def batch_cli_leg(hours=0.5, seed=0):
         import contextlib
         with contextlib.redirect_stdout(sys.stderr):
             s = audio_to_codes.main(["--audio_path", raw, "--codes_path", os.path.join(root, "codes"), "--stereo"])
-        return dict(value=s["audio_hours_per_hour"], unit="audio-hours/hour", files=i, audio_hours=total / 3600.0, elapsed_s=s["elapsed_s"],
-                    note="audio_to_codes CLI end to end (read .wav, batch windows across files, encode, write .npy), one process")
+        st = s.get("stages") or {}
+        out = dict(value=s["audio_hours_per_hour"], unit="audio-hours/hour", files=i, audio_hours=total / 3600.0, elapsed_s=s["elapsed_s"],
+                   note="audio_to_codes CLI end to end (read .wav, batch windows across files, encode, write .npy), one process")
+        if st.get("total_s"):
+            gpu_s = st.get("encode_many_gpu_ms", 0.0) * 1e-3
+            out["gpu_busy_fraction"] = gpu_s / st["total_s"]
+            out["startup_s"] = st.get("first_batch_ready_s")
+            out["steady_state"] = (total / 3600.0) / ((st["total_s"] - (st.get("first_batch_ready_s") or 0.0)) / 3600.0) if st["total_s"] > 0 else None
+            out["gpu_level"] = (total / 3600.0) / (gpu_s / 3600.0) if gpu_s > 0 else None
+            out["stages"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items()}
+        return out
     finally:
         shutil.rmtree(root, ignore_errors=True)
 

@@ -42,6 +42,12 @@ import numpy as np
 from .dist_utils import ControlPlane, env_rank_world, shard_by_duration
 
 AUDIO_EXTS = (".wav", ".npy")
+# PCM samples (all channels) per super-batch: 2^25 = 35 min of mono audio = ~0.28 s of encoder time on an MI355X.  Measured on a
+# 2.0 h corpus of 10-60 s stereo utterances (profiles/r04/cli_corpus_bench.txt): 2^22 2 850, 2^23 3 110, 2^24 2 950-3 100, 2^25 3 170,
+# 2^26 3 110 audio-hours/hour -- small super-batches leave the window-length groups of the files' warm-up windows with a few dozen
+# rows per pass, a 2^26 one spends 0.5 s enqueueing before the GPU has anything (and swallowed a whole 0.5 h corpus: nothing
+# overlapped anything).  From the second super-batch on reading / packing the next one and writing the previous one hide behind the GPU.
+DEFAULT_SUPER_BATCH = 1 << 25
 # The reference's corpora are mp3 (tools/sph_to_mp3.py:28-41) and codec_bpe reads them through librosa / soundfile.  Neither is part
 # of this image; when one of them is importable these extensions are picked up too, otherwise such files are reported and skipped.
 COMPRESSED_EXTS = (".mp3", ".flac", ".ogg", ".m4a")
@@ -133,12 +139,38 @@ class HipWindowEncoder:
         self.model, _, _ = load_magicodec_model(codec_model, self.device)
         self.cfg = self.model.cfg
 
+    RING = 3      # super-batches in flight: one being packed, one on the GPU, one being written
+
+    def _slot(self, k: int, n_samples: int, n_codes: int, n_windows: int):
+        """Ring slot k: pinned staging + device buffers, grown on demand and reused (a pinned allocation of a few hundred MB costs
+        tens of milliseconds: once per slot, not once per super-batch)."""
+        torch = self.torch
+        if not hasattr(self, "_ring"):
+            self._ring = [dict() for _ in range(self.RING)]
+        sl = self._ring[k]
+        if sl.get("ev") is not None:
+            sl["ev"].synchronize()                              # the slot's previous super-batch has left the GPU (its codes are on the host)
+        if sl.get("free") is not None:
+            sl["free"].wait()                                   # ... and the writer is done with its host codes
+        sl["free"] = threading.Event()
+        def grow(name, n, dtype, pinned):
+            cur = sl.get(name)
+            if cur is None or cur.numel() < n:
+                cap = max(int(n * 1.25), 1)
+                sl[name] = torch.empty(cap, dtype=dtype).pin_memory() if pinned else torch.empty(cap, dtype=dtype, device=self.device)
+            return sl[name]
+        return (grow("stage", n_samples, torch.float32, True), grow("dev_audio", n_samples, torch.float32, False),
+                grow("host_codes", n_codes, torch.int64, True), grow("dev_codes", n_codes, torch.int64, False),
+                grow("tab_host", 2 * n_windows, torch.int64, True), grow("tab_dev", 2 * n_windows, torch.int64, False), sl)
+
     def encode_many(self, audios: Sequence[np.ndarray], chunk: int, ctx: int, batch_windows: int):
         """audios: float32 [C_f, N_f] per file (a --stereo corpus may mix mono and stereo files: every file brings its own
         channel count).  -> (pinned host int64 codes [total], [(a, b)] slice of every (file, channel) row, wait()) -- wait()
         blocks until the codes have landed in the host buffer.  Everything up to the D2H copy is enqueued asynchronously, so the
-        caller can prepare the next super-batch while this one runs."""
+        caller can prepare the next super-batch while this one runs.  Staging and device buffers come from a ring of RING slots
+        (the returned host buffer stays valid until RING - 1 further calls have been made)."""
         torch, hip = self.torch, self.model.hip
+        t_in = time.perf_counter()
         W = max(chunk, ctx)
         fpc = hip.frames_per_chunk(chunk)
         lengths = [a.shape[-1] for a in audios for _ in range(a.shape[0])]      # one entry per (file, channel) row
@@ -150,22 +182,32 @@ class HipWindowEncoder:
         dst_base = np.concatenate([[0], np.cumsum(n_codes)[:-1]]).astype(np.int64)
         total_codes = int(sum(n_codes))
         slices = [(int(b), int(b + n)) for b, n in zip(dst_base, n_codes)]
-        stage = torch.empty(max(total, 1), dtype=torch.float32).pin_memory()
+        T, src, dst = window_table(lengths, chunk, W, fpc, src_base, dst_base)
+        self._calls = getattr(self, "_calls", 0) + 1
+        stage, dev_audio, host_codes, dev_codes, tab_host, tab_dev, sl = self._slot(self._calls % self.RING, total, total_codes, len(T))
+        t_slot = time.perf_counter()
         sv = stage.numpy()
         r = 0
         for a in audios:
             for c in range(a.shape[0]):
                 sv[src_base[r]:src_base[r] + a.shape[-1]] = a[c]
                 r += 1
-        T, src, dst = window_table(lengths, chunk, W, fpc, src_base, dst_base)
-        host_codes = torch.empty(max(total_codes, 1), dtype=torch.int64).pin_memory()
+        st_ = getattr(self, "stage_times", None)
+        if st_ is None:
+            st_ = self.stage_times = dict(slot_wait_s=0.0, pack_s=0.0, enqueue_s=0.0, gpu_ms=0.0, super_batches=0, passes=0)
         if len(T) == 0:
+            sl["free"].set()
             return host_codes.numpy()[:0], slices, (lambda: None)
+        tab_host.numpy()[:len(T)] = src
+        tab_host.numpy()[len(T):2 * len(T)] = dst
+        t_pack = time.perf_counter()
         with torch.cuda.device(self.device):
             st = torch.cuda.current_stream(self.device)
-            dev_audio = stage.to(self.device, non_blocking=True)
-            tables = torch.from_numpy(np.stack([src, dst])).pin_memory().to(self.device, non_blocking=True)   # [2, n] int64
-            dev_codes = torch.empty(max(total_codes, 1), dtype=torch.int64, device=self.device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            dev_audio[:total].copy_(stage[:total], non_blocking=True)
+            tab_dev[:2 * len(T)].copy_(tab_host[:2 * len(T)], non_blocking=True)
+            e0.record(st)
+            src_ptr, dst_ptr = tab_dev.data_ptr(), tab_dev.data_ptr() + 8 * len(T)
             i, n = 0, len(T)
             while i < n:
                 t = int(T[i])
@@ -174,17 +216,23 @@ class HipWindowEncoder:
                     j += 1                                        # rows [i, j): one window length
                 for k in range(i, j, batch_windows):
                     b = min(batch_windows, j - k)
-                    hip.encode_rows_dev(dev_audio.data_ptr(), tables[0].data_ptr() + 8 * k, b, t, fpc, dev_codes.data_ptr(),
-                                        tables[1].data_ptr() + 8 * k, total, st.cuda_stream)
+                    hip.encode_rows_dev(dev_audio.data_ptr(), src_ptr + 8 * k, b, t, fpc, dev_codes.data_ptr(),
+                                        dst_ptr + 8 * k, total, st.cuda_stream)
+                    st_["passes"] += 1
                 i = j
-            host_codes.copy_(dev_codes, non_blocking=True)
+            e1.record(st)
+            host_codes[:max(total_codes, 1)].copy_(dev_codes[:max(total_codes, 1)], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(st)
-            keep = (stage, dev_audio, tables, dev_codes)          # alive until the copy has landed
+            sl["ev"] = ev
         hc = host_codes.numpy()[:total_codes]
+        t_out = time.perf_counter()
+        st_["slot_wait_s"] += t_slot - t_in; st_["pack_s"] += t_pack - t_slot; st_["enqueue_s"] += t_out - t_pack; st_["super_batches"] += 1
 
-        def wait(_keep=keep):
+        def wait(_e0=e0, _e1=e1):
             ev.synchronize()
+            st_["gpu_ms"] += _e0.elapsed_time(_e1)
+        wait.release = sl["free"].set                           # the consumer calls it once it no longer reads `hc`
         return hc, slices, wait
 
     def encode(self, audio: np.ndarray, chunk: int, ctx: int, batch_windows: int) -> np.ndarray:
@@ -293,15 +341,18 @@ def _super_batches(files: Sequence[str], sr: int, stereo: bool, budget_samples: 
 
 def encode_files_pipelined(files: Sequence[str], encoder, args, rank: int = 0) -> Tuple[float, int]:
     """The same output tree as the one-file-at-a-time loop below, with windows batched across files and the three stages
-    (read, encode, write) overlapped."""
+    (read, encode, write) overlapped.  Per-stage wall times are left in `encoder.pipeline_times` (what the main thread and the
+    writer spent where): the steady state is GPU-bound when read_wait_s + pack + enqueue < the GPU's busy time."""
     cfg = encoder.cfg
     sr = cfg.sample_rate
     chunk = int(args.chunk_size_secs * sr)
     ctx = int(args.context_secs * sr)
     out_root = _out_root(args, cfg, rank)
-    done: "queue.Queue" = queue.Queue(maxsize=4)
+    done: "queue.Queue" = queue.Queue(maxsize=1)     # the ring of the encoder bounds what is in flight
     totals = [0.0, 0]
     errors: List[BaseException] = []
+    times = dict(read_wait_s=0.0, encode_many_s=0.0, queue_wait_s=0.0, writer_wait_s=0.0, writer_save_s=0.0, first_batch_ready_s=None)
+    made_dirs = set()
 
     def writer():
         while True:
@@ -310,23 +361,47 @@ def encode_files_pipelined(files: Sequence[str], encoder, args, rank: int = 0) -
                 return
             try:
                 names, wait, host_codes, slices = item
+                t0 = time.perf_counter()
                 wait()                                        # the D2H copy of this super-batch has landed
+                t1 = time.perf_counter()
                 for (rel, c), (a, b) in zip(names, slices):
                     dst = os.path.join(out_root, f"{rel}_c{c}.npy")
-                    os.makedirs(os.path.dirname(dst), exist_ok=True)
+                    d = os.path.dirname(dst)
+                    if d not in made_dirs:
+                        os.makedirs(d, exist_ok=True)
+                        made_dirs.add(d)
                     np.save(dst, host_codes[a:b][None, :])    # (num_codebooks, T)
+                times["writer_wait_s"] += t1 - t0
+                times["writer_save_s"] += time.perf_counter() - t1
             except BaseException as e:                        # surfaced by the main thread after the join
                 errors.append(e)
+            finally:
+                rel_fn = getattr(item[1], "release", None) if item is not None else None
+                if rel_fn is not None:
+                    rel_fn()
     wt = threading.Thread(target=writer, daemon=True)
     wt.start()
+    t_start = time.perf_counter()
     try:
-        for group in _super_batches(files, sr, args.stereo, getattr(args, "super_batch_samples", 1 << 26), getattr(args, "reader_threads", 4)):
+        gen = _super_batches(files, sr, args.stereo, getattr(args, "super_batch_samples", DEFAULT_SUPER_BATCH), getattr(args, "reader_threads", 4))
+        while True:
+            t0 = time.perf_counter()
+            group = next(gen, None)
+            t1 = time.perf_counter()
+            times["read_wait_s"] += t1 - t0
+            if group is None:
+                break
+            if times["first_batch_ready_s"] is None:
+                times["first_batch_ready_s"] = t1 - t_start
             audios = [a for _, a in group]
             host_codes, slices, wait = encoder.encode_many(audios, chunk, ctx, args.batch_size)
+            t2 = time.perf_counter()
+            times["encode_many_s"] += t2 - t1
             names = [(os.path.splitext(os.path.relpath(p, args.audio_path))[0], c) for p, a in group for c in range(a.shape[0])]
             if len(names) != len(slices):
                 raise RuntimeError(f"encode_many returned {len(slices)} code rows for {len(names)} (file, channel) rows")
             done.put((names, wait, host_codes, slices))
+            times["queue_wait_s"] += time.perf_counter() - t2
             totals[0] += sum(a.shape[-1] for a in audios) / sr
             totals[1] += int(sum(b - a for a, b in slices))
     finally:
@@ -334,6 +409,10 @@ def encode_files_pipelined(files: Sequence[str], encoder, args, rank: int = 0) -
         wt.join()
     if errors:
         raise errors[0]
+    times["total_s"] = time.perf_counter() - t_start
+    if hasattr(encoder, "stage_times"):
+        times.update({f"encode_many_{k}": v for k, v in encoder.stage_times.items()})
+    encoder.pipeline_times = times
     return totals[0], totals[1]
 
 
@@ -360,7 +439,7 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--stereo", action="store_true")
     ap.add_argument("--audio_filter", nargs="+")
     ap.add_argument("--one_file_at_a_time", action="store_true", help="the simple loop (a pass never spans files, no overlap of read / encode / write)")
-    ap.add_argument("--super_batch_samples", type=int, default=1 << 26, help="PCM samples (all channels) uploaded and encoded per super-batch")
+    ap.add_argument("--super_batch_samples", type=int, default=DEFAULT_SUPER_BATCH, help="PCM samples (all channels) uploaded and encoded per super-batch")
     ap.add_argument("--reader_threads", type=int, default=4)
     ap.add_argument("--receptive_field_trim", action="store_true",
                     help="encode only what each chunk's kept frames can see instead of the whole context window: identical "
@@ -394,7 +473,8 @@ def main(argv=None, encoder=None, backend: Optional[str] = None) -> dict:
     total_secs = cp.sum(secs)
     total_codes = cp.sum(float(ncodes))
     summary = dict(files=len(files), world_size=world, audio_hours=total_secs / 3600.0, codes=int(total_codes), elapsed_s=elapsed,
-                   audio_hours_per_hour=(total_secs / elapsed) if elapsed > 0 else None, control_plane=cp.backend)
+                   audio_hours_per_hour=(total_secs / elapsed) if elapsed > 0 else None, control_plane=cp.backend,
+                   stages=getattr(encoder, "pipeline_times", None))
     if rank == 0:
         print(json.dumps(summary))
     return summary

@@ -27,11 +27,16 @@ while total < hours * 3600:
     i += 1
 print(f"corpus: {i} files, {total / 3600:.2f} h stereo, written in {time.perf_counter() - t0:.1f} s", flush=True)
 res = {}
-for name, extra in (("one_file_at_a_time", ["--one_file_at_a_time"]), ("cross_file_pipelined", []),
-                    ("cross_file_pipelined+rf_trim", ["--receptive_field_trim"])):
-    out = os.path.join(root, name.replace("+", "_"))
+sweep = [int(x) for x in os.environ.get("RCA_CLI_SWEEP", "").split(",") if x]      # super-batch sizes (log2) to try, e.g. 22,23,24,25,26
+runs = [("one_file_at_a_time", ["--one_file_at_a_time"]), ("cross_file_pipelined", []), ("cross_file_pipelined+rf_trim", ["--receptive_field_trim"])]
+runs += [(f"super_batch_2^{k}", ["--super_batch_samples", str(1 << k)]) for k in sweep]
+for name, extra in runs:
+    out = os.path.join(root, name.replace("+", "_").replace("^", ""))
     s = audio_to_codes.main(["--audio_path", raw, "--codes_path", out, "--stereo"] + extra)
     res[name] = dict(audio_hours_per_hour=s["audio_hours_per_hour"], elapsed_s=s["elapsed_s"])
+    st = s.get("stages")
+    if st:
+        res[name]["stages"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()}
     print(name, json.dumps(res[name]), flush=True)
 same = True
 a, b = os.path.join(root, "one_file_at_a_time"), os.path.join(root, "cross_file_pipelined")
