@@ -251,6 +251,7 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     hip.profile(False)
+    prof = {k: hip.profile_read(k) for k in (0, 1, 2, 3)}       # the headline's launches (later legs profile on their own)
     elapsed = cp.max(elapsed)
 
     # SURVEY 8f-1 leg (reported beside the headline, never as `value`): the same steps with every window cut down
@@ -277,7 +278,8 @@ def main():
     # Opt-in arithmetic legs (reported beside the headline, never as `value`): the same steps with the encoder's conv layers on the
     # bf16 matrix instruction -- operands split into bf16 hi + lo (mode 3) or rounded to bf16 like the reference's bf16 autocast
     # (mode 1, audio_tokenizer.py:24,78-82).  Not bit-exact: the fraction of code ids equal to the f32 path is measured here.
-    bf16_legs = None
+    bf16_legs, roofline_bf16 = None, None
+    conv_bytes_f32 = prof[0]["bytes"]
     if not args.no_bf16_leg:
         bf16_legs = {}
         codes_f32 = codes.clone()
@@ -287,20 +289,36 @@ def main():
                 step(i)
             torch.cuda.synchronize(dev)
             cp.barrier()
+            hip.profile(True)
             t0 = time.perf_counter()
             for i in range(args.warmup, total_steps):
                 step(i)
             torch.cuda.synchronize(dev)
             cp.barrier()
             el = time.perf_counter() - t0
+            hip.profile(False)
             el = cp.max(el)
             eq = float((codes == codes_f32).double().mean().item())
             bf16_legs[name] = {"value": world * args.steps * chunks_per_step * chunk / cfg.sample_rate / el, "unit": "audio-hours/hour",
                                "ms_per_step": 1e3 * el / args.steps, "code_ids_equal_to_f32_path": eq, "mfma_mode": mode}
+            leg_prof = {k: hip.profile_read(k) for k in (0, 1, 2, 3)}       # (reading empties the records of this leg)
+            if mode == 1:
+                # the reference's own arithmetic class (bf16 autocast, audio_tokenizer.py:24,78-82) is HBM-bound: conv launches of the
+                # blocked bf16 pipeline (conv_in_blk + conv_bf16_blk), algorithmic bytes = every activation once in and once out as
+                # bf16 (PCM f32 in, the last layer f32 out) + the weights, over their HIP-event time
+                pc, pi = leg_prof[0], leg_prof[2]
+                ms, by = pc["ms"] + pi["ms"], pc["bytes"] + pi["bytes"]
+                if ms > 0:
+                    roofline_bf16 = {"kernel": "conv_in_blk_kernel + conv_bf16_blk_kernel (rca_codec_set_mfma_mode(1): bf16 MFMA, channel-blocked bf16 activations)",
+                                     "bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": by / args.steps,
+                                     "conv_ms_per_step": ms / args.steps, "launches": pc["launches"] + pi["launches"],
+                                     "f32_path_bytes_per_step": conv_bytes_f32 / args.steps,
+                                     "frac_if_counted_in_f32_bytes": conv_bytes_f32 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "traffic": None, "opt_in": True}
         hip.set_mfma_mode(0)
         codes.copy_(codes_f32)
 
-    prof = {k: hip.profile_read(k) for k in (0, 1, 2, 3)}
     audio_secs = args.steps * chunks_per_step * chunk / cfg.sample_rate  # per rank, stereo seconds
     value = world * audio_secs / elapsed
     conv = prof[0]
@@ -368,6 +386,8 @@ def main():
                     "frac": conv["bytes"] / (conv["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if conv["ms"] > 0 else None},
         },
     }
+    if roofline_bf16 is not None:
+        out["roofline_bf16"] = roofline_bf16
     if rank == 0 and world == 1 and not args.no_cli_leg:
         out["config"]["batch_cli"] = batch_cli_leg()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

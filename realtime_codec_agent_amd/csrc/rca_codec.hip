@@ -1640,6 +1640,258 @@ static int conv_cic_ws(int k, int s) {
     return 0;
 }
 
+// =====================================================================================================================
+// bf16 "blocked" encoder pipeline (opt-in: rca_codec_set_mfma_mode 1 / 3, never the default and never the bench's `value`).
+//
+// Round 3's bf16 modes ran conv1d_mfma_kernel with its f32 data path: f32 activations in HBM, 4-byte LDS reads, one conversion per
+// operand per use -- 1.84 ms per 256-window step against an HBM floor of ~0.3 ms.  This pipeline is built for the bf16 matrix
+// instruction instead (the reference's own GPU arithmetic class is bf16 autocast, audio_tokenizer.py:24,78-82):
+//   * activations live in HBM as bf16 in CHANNEL-BLOCKED layout  X[b][c / 16][t][c % 16]  (32 bytes per time step and block): the 16
+//     input channels of one MFMA k step are contiguous, so a B operand (lane <-> output column, 8 channels of one tap) is ONE
+//     16-byte LDS read and staging is a straight 16-byte copy;
+//   * weights are rounded (mode 1) or split into hi + lo (mode 3) ONCE at pack time, in A-fragment order
+//     wp[co / 32][ci / 16][tap][lane][8]: one 16-byte load per lane and MFMA;
+//   * the LDS window is phase-de-interleaved like the f32 kernel's:  xs[plane][half][t % S][t / S]  of 16-byte cells, so the 16 lanes
+//     of a ds_read_b128 group read 16 consecutive cells for every tap (conflict-free);
+//   * a workgroup of 4 waves owns 128 channels x 128 columns (64 x 256 for the 64-channel layer) of ONE batch row, each wave 32 x 128
+//     (one weight fragment feeds four MFMAs, no two waves load the same fragment);
+//     per stage (CPS blocks of 16 input channels) the next stage's window is loaded into registers before the MFMA block and written
+//     to the other LDS buffer behind it: one barrier per stage;
+//   * mode 3 can run here too (a second, lo, plane of every activation and weight; hi hi + hi lo + lo hi; RCA_BF16_BLK_SPLIT=1) but
+//     stays on conv1d_mfma_kernel<BF = 3> by default: with two planes in LDS the wide layers fit one workgroup per CU and the variant
+//     measures 2.66 ms per step against 2.40-2.49.
+// k order inside an MFMA differs from the f32 definition (tap-major over a 16-channel block), like every bf16 mode: not bit-exact,
+// the fraction of equal code ids is measured by the bench and the test.
+typedef unsigned short conv_bf16raw;
+typedef __attribute__((ext_vector_type(4))) unsigned conv_u32x4;
+
+template <int KS, int SPLIT>
+__global__ __launch_bounds__(256) void conv_in_blk_kernel(RowSrc src, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          conv_bf16raw* __restrict__ y_hi, conv_bf16raw* __restrict__ y_lo, int B, int Cout, int L,
+                                                          int act, float slope) {
+    // conv_in (Cin = 1) -> blocked bf16; the f32 chain is conv_in_kernel's (bias first, taps ascending, out-of-range taps skipped).
+    // `w` is the PADDED table [co][8] = 7 taps + the bias (built once at pack time): wave-uniform 32-byte rows, one s_load_dwordx8
+    // per channel through the scalar cache.  (224 separate scalar loads with a test per tap: 410 us; the table in LDS read by
+    // broadcast: 127 us, bound by the LDS instruction rate; the memory floor of this launch is ~50 us.)
+    static_assert(KS <= 7, "taps + bias fit 8 floats");
+    (void)bias;
+    const int b = blockIdx.y;                                  // grid (L / 256, B): no 64-bit division per thread
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= L) return;
+    const float* xr = src.base + src.off(b);
+    constexpr int padL = KS / 2;
+    float xv[KS];
+    bool interior = true;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        const int i = t + kk - padL;
+        const bool ok = i >= 0 && i < src.T;
+        interior = interior && ok;
+        xv[kk] = ok ? xr[i] : 0.0f;
+    }
+    const int Cb = Cout / 16;
+#pragma unroll 2
+    for (int cb = 0; cb < Cb; ++cb) {
+        unsigned hi[8], lo[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int co = cb * 16 + 2 * j + e;
+                const float* wr = w + co * 8;
+                const float wk[8] = {wr[0], wr[1], wr[2], wr[3], wr[4], wr[5], wr[6], wr[7]};
+                float acc = wk[7];
+                if (interior) {
+#pragma unroll
+                    for (int kk = 0; kk < KS; ++kk) acc = __builtin_fmaf(wk[kk], xv[kk], acc);
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < KS; ++kk) {
+                        const int i = t + kk - padL;
+                        if (i >= 0 && i < src.T) acc = __builtin_fmaf(wk[kk], xv[kk], acc);
+                    }
+                }
+                v[e] = act ? fmaxf(acc, acc * slope) : acc;
+            }
+            hi[j] = conv_pack_bf16x2(v[0], v[1]);
+            if (SPLIT) lo[j] = conv_pack_bf16x2(v[0] - __uint_as_float(hi[j] << 16), v[1] - __uint_as_float(hi[j] & 0xffff0000u));
+        }
+        const long o = (((long)b * Cb + cb) * L + t) * 16;
+        *reinterpret_cast<conv_u32x4*>(y_hi + o) = conv_u32x4{hi[0], hi[1], hi[2], hi[3]};
+        *reinterpret_cast<conv_u32x4*>(y_hi + o + 8) = conv_u32x4{hi[4], hi[5], hi[6], hi[7]};
+        if (SPLIT) {
+            *reinterpret_cast<conv_u32x4*>(y_lo + o) = conv_u32x4{lo[0], lo[1], lo[2], lo[3]};
+            *reinterpret_cast<conv_u32x4*>(y_lo + o + 8) = conv_u32x4{lo[4], lo[5], lo[6], lo[7]};
+        }
+    }
+}
+
+// OUT = 0: y blocked bf16 (hi [+ lo]), LeakyReLU applied when `act` (the consumer is pre-activated); OUT = 1: y f32 [b][co][t].
+// A wave owns 32 channels x 128 columns (1 x 4 MFMA tiles): one weight fragment (16 bytes per lane, straight from L2 into registers,
+// PD taps ahead) feeds four MFMAs and no two waves of a workgroup load the same fragment; the workgroup is WGM waves along the channels
+// x 4 / WGM along the columns.
+template <int KS, int S, int WGM, int CPS, int SPLIT, int OUT>
+__global__ __launch_bounds__(256, SPLIT ? 2 : 3) void conv_bf16_blk_kernel(const conv_bf16raw* __restrict__ x_hi, const conv_bf16raw* __restrict__ x_lo,
+                                                               const conv_bf16raw* __restrict__ w_hi, const conv_bf16raw* __restrict__ w_lo,
+                                                               const float* __restrict__ bias, conv_bf16raw* __restrict__ y_hi,
+                                                               conv_bf16raw* __restrict__ y_lo, float* __restrict__ y_f32, int Cin, int Lin, int Cout,
+                                                               int Lout, int act, float slope) {
+    constexpr int WGN = 4 / WGM;
+    constexpr int NT = 128 * WGN;                         // columns per workgroup
+    constexpr int padL = (KS - S + 1) / 2;
+    constexpr int WIN = (NT - 1) * S + KS;                // input samples a column tile sees
+    constexpr int SLOTS = NT + (KS - 1) / S;              // 16-byte cells per (plane, half, phase) row
+    constexpr int NPL = SPLIT ? 2 : 1;
+    constexpr int CELLS = 2 * S * SLOTS;                  // cells of one block's window (one plane)
+    constexpr int PIECES = 2 * WIN;                       // 16-byte pieces of one block's window (one plane)
+    constexpr int NP = (PIECES + 255) / 256;              // per thread
+    constexpr int PD = KS < 8 ? KS : ((CPS * KS) % 8 == 0 ? (SPLIT ? 4 : 8) : 5);   // weight fragments in flight (taps ahead)
+    static_assert((CPS * KS) % PD == 0, "the fragment ring keeps static slots across stages");
+    extern __shared__ __attribute__((aligned(16))) conv_u32x4 blk_lds[];   // [2 buffers][CPS][NPL][CELLS]
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, n = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm_w = wave / WGN, wn_w = wave % WGN;       // this wave's 32 x 128 tile inside the workgroup tile
+    const int b = blockIdx.z;
+    const int n0 = blockIdx.x * NT;                       // first output column of the workgroup
+    const int co0 = (blockIdx.y * WGM + wm_w) * 32;       // first output channel of the wave
+    const int Cbi = Cin / 16, nstages = Cbi / CPS;
+    const int t_start = n0 * S - padL;
+    // ---- staging role (fixed per thread): piece -> (sample, half) -> LDS cell; global offset in 16-byte units from the block's row.
+    // Loads are issued unconditionally from a clamped offset and zeroed at the LDS write: a select or a branch in front of a load makes
+    // the compiler wait for each one separately.
+    int g_off[NP], l_off[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int piece = tid + 256 * i;
+        const int tr = piece >> 1, h = piece & 1;
+        const int t = t_start + tr;
+        const bool ok = piece < PIECES && t >= 0 && t < Lin;
+        g_off[i] = ok ? t * 2 + h : -1;                    // -1: outside the signal (zeros)
+        l_off[i] = piece < PIECES ? (h * S + tr % S) * SLOTS + tr / S : -1;
+    }
+    conv_u32x4 sreg[CPS][NPL][NP];
+    auto stage_load = [&](int st) {
+#pragma unroll
+        for (int cb = 0; cb < CPS; ++cb) {
+            const long row = ((long)b * Cbi + (st * CPS + cb)) * Lin * 2;    // 16-byte units
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                const conv_u32x4* src = reinterpret_cast<const conv_u32x4*>(pl ? x_lo : x_hi) + row;
+#pragma unroll
+                for (int i = 0; i < NP; ++i) sreg[cb][pl][i] = src[g_off[i] >= 0 ? g_off[i] : 0];
+            }
+        }
+    };
+    auto stage_write = [&](int buf) {
+#pragma unroll
+        for (int cb = 0; cb < CPS; ++cb)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                conv_u32x4* dst = blk_lds + ((buf * CPS + cb) * NPL + pl) * CELLS;
+#pragma unroll
+                for (int i = 0; i < NP; ++i)
+                    if (l_off[i] >= 0) dst[l_off[i]] = g_off[i] >= 0 ? sreg[cb][pl][i] : conv_u32x4{0u, 0u, 0u, 0u};
+            }
+    };
+    // ---- accumulators start at the bias
+    f32x16 acc[4];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float bv = bias[co0 + (r & 3) + 8 * (r >> 2) + 4 * half];
+#pragma unroll
+        for (int wn = 0; wn < 4; ++wn) acc[wn][r] = bv;
+    }
+    // weights: fragment (co tile, block, tap) = 64 lanes x 16 bytes; this wave's fragments are consecutive over (block, tap)
+    const conv_u32x4* wq_hi = reinterpret_cast<const conv_u32x4*>(w_hi) + (long)(co0 / 32) * Cbi * KS * 64 + lane;
+    const conv_u32x4* wq_lo = reinterpret_cast<const conv_u32x4*>(w_lo) + (long)(co0 / 32) * Cbi * KS * 64 + lane;
+    const int bcell0 = half * S * SLOTS + wn_w * 128 + n;   // + wn * 32 + (kk % S) * SLOTS + kk / S
+    const int nfrag = Cbi * KS;                              // fragments of this wave, in the order they are consumed
+    conv_u32x4 ah[PD], al[SPLIT ? PD : 1];
+#pragma unroll
+    for (int i = 0; i < PD; ++i) {
+        ah[i] = wq_hi[(long)i * 64];
+        if (SPLIT) al[i] = wq_lo[(long)i * 64];
+    }
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+    int f = 0;                                               // next fragment to consume
+    for (int st = 0; st < nstages; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nstages) stage_load(st + 1);
+#pragma unroll
+        for (int cb = 0; cb < CPS; ++cb) {
+            const conv_u32x4* xb = blk_lds + ((buf * CPS + cb) * NPL) * CELLS;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const int slot = (cb * KS + kk) % PD;        // static after unrolling (PD divides the stage's fragments or the ring is re-based below)
+                const int cell = bcell0 + (kk % S) * SLOTS + kk / S;
+                conv_u32x4 bh[4], bl[4];
+#pragma unroll
+                for (int wn = 0; wn < 4; ++wn) {
+                    bh[wn] = xb[cell + wn * 32];
+                    if (SPLIT) bl[wn] = xb[CELLS + cell + wn * 32];
+                }
+                const conv_u32x4 a_h = ah[slot];
+                conv_u32x4 a_l;
+                if (SPLIT) a_l = al[slot];
+                {   // refill the slot with the fragment PD taps ahead (past the end: the last fragment again, never used)
+                    const long fn = (long)min(f + PD, nfrag - 1) * 64;
+                    ah[slot] = wq_hi[fn];
+                    if (SPLIT) al[slot] = wq_lo[fn];
+                }
+                ++f;
+                const conv_bf16x8 av = __builtin_bit_cast(conv_bf16x8, a_h);
+#pragma unroll
+                for (int wn = 0; wn < 4; ++wn) {
+                    const conv_bf16x8 bv = __builtin_bit_cast(conv_bf16x8, bh[wn]);
+                    acc[wn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[wn], 0, 0, 0);
+                    if (SPLIT) {
+                        acc[wn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(conv_bf16x8, bl[wn]), acc[wn], 0, 0, 0);
+                        acc[wn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(conv_bf16x8, a_l), bv, acc[wn], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (st + 1 < nstages) stage_write(buf ^ 1);
+        __syncthreads();
+    }
+    // ---- epilogue: lane <-> column, register r <-> channel (r & 3) + 8 (r >> 2) + 4 half of the 32-row tile
+#pragma unroll
+    for (int wn = 0; wn < 4; ++wn) {
+        const int t = n0 + wn_w * 128 + wn * 32 + n;
+        if (t >= Lout) continue;
+        if (OUT == 1) {
+            float* yr = y_f32 + ((long)b * Cout + co0 + 4 * half) * Lout + t;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yr[(long)((r & 3) + 8 * (r >> 2)) * Lout] = acc[wn][r];
+        } else {
+            const int Cbo = Cout / 16;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {          // registers 4 g .. 4 g + 3: channels 8 g + 4 half .. + 3 of the tile
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = acc[wn][4 * g + j];
+                    v[j] = act ? fmaxf(a, a * slope) : a;
+                }
+                const int ch = co0 + 8 * g + 4 * half;
+                const long o = (((long)b * Cbo + ch / 16) * Lout + t) * 16 + (ch & 15);
+                const unsigned h0 = conv_pack_bf16x2(v[0], v[1]), h1 = conv_pack_bf16x2(v[2], v[3]);
+                *reinterpret_cast<uint2*>(y_hi + o) = make_uint2(h0, h1);
+                if (SPLIT) {
+                    const unsigned l0 = conv_pack_bf16x2(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u));
+                    const unsigned l1 = conv_pack_bf16x2(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u));
+                    *reinterpret_cast<uint2*>(y_lo + o) = make_uint2(l0, l1);
+                }
+            }
+        }
+    }
+}
+
+struct Bf16Pack { conv_bf16raw* hi = nullptr; conv_bf16raw* lo = nullptr; float* w_in8 = nullptr; };   // w_in8: conv_in's [co][7 taps + bias]
+
 struct rca_codec {
     rca_codec_config_t cfg;
     int device = 0;
@@ -1652,6 +1904,8 @@ struct rca_codec {
     int enc_left_frames = 0, dec_left_frames = 0;
     bool window_trim = false;   // batch windows: encode only what the kept frames can see (same codes)
     std::vector<ConvLayer> enc, dec;
+    std::vector<Bf16Pack> bf16_packs;   // per encoder layer: weights of the blocked bf16 pipeline (built on first use)
+    bool bf16_blk_split = false;        // mode 3 on the blocked pipeline too (RCA_BF16_BLK_SPLIT=1: experiments)
     float *q_in_w = nullptr, *q_in_b = nullptr;
     float *cb = nullptr, *hc = nullptr, *cbp = nullptr;
     DevBuf act[2], zbuf, keys, io_a, io_b, tail;
@@ -1800,6 +2054,11 @@ extern "C" int rca_codec_destroy(rca_codec_t* h) {
 
     if (!h) return RCA_OK;
     (void)hipSetDevice(h->device);
+    for (auto& pk : h->bf16_packs) {
+        if (pk.hi) (void)hipFree(pk.hi);
+        if (pk.lo) (void)hipFree(pk.lo);
+        if (pk.w_in8) (void)hipFree(pk.w_in8);
+    }
     for (auto* v : {&h->enc, &h->dec})
         for (auto& L : *v) {
             if (L.w) (void)hipFree(L.w);
@@ -2185,6 +2444,133 @@ static int run_conv(rca_codec* h, const ConvLayer& L, const float* x, float* y, 
     return RCA_OK;
 }
 
+// weights of encoder layer li (>= 1) in A-fragment order, rounded to bf16 (hi) + the rounded remainder (lo)
+static int pack_weights_bf16(const ConvLayer& L, Bf16Pack* out) {
+    const long nw = (long)L.cout * L.cin * L.k;
+    std::vector<float> w(nw);
+    RCA_HIP(hipMemcpy(w.data(), L.w, nw * 4, hipMemcpyDeviceToHost));
+    const int ncot = L.cout / 32, ncb = L.cin / 16;
+    std::vector<conv_bf16raw> hi((size_t)ncot * ncb * L.k * 64 * 8), lo(hi.size());
+    auto rne = [](float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7FFFu + ((u >> 16) & 1u); return (conv_bf16raw)(u >> 16); };
+    auto up = [](conv_bf16raw h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; };
+    for (int cot = 0; cot < ncot; ++cot)
+        for (int cb = 0; cb < ncb; ++cb)
+            for (int kk = 0; kk < L.k; ++kk)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = cot * 32 + (lane & 31), ci = cb * 16 + 8 * (lane >> 5) + j;
+                        const float v = w[((long)co * L.cin + ci) * L.k + kk];
+                        const size_t o = ((((size_t)cot * ncb + cb) * L.k + kk) * 64 + lane) * 8 + j;
+                        hi[o] = rne(v);
+                        lo[o] = rne(v - up(hi[o]));
+                    }
+    RCA_HIP(hipMalloc((void**)&out->hi, hi.size() * 2));
+    RCA_HIP(hipMalloc((void**)&out->lo, lo.size() * 2));
+    RCA_HIP(hipMemcpy(out->hi, hi.data(), hi.size() * 2, hipMemcpyHostToDevice));
+    RCA_HIP(hipMemcpy(out->lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
+    return RCA_OK;
+}
+
+template <int KS, int S, int WGM, int CPS, int OUT>
+static int launch_conv_bf16(bool split, const ConvLayer& L, const Bf16Pack& wp, const conv_bf16raw* xh, const conv_bf16raw* xl, conv_bf16raw* yh,
+                            conv_bf16raw* yl, float* yf, int B, int Lin, int act, float slope, hipStream_t st) {
+    constexpr int WGN = 4 / WGM, NT = 128 * WGN;
+    constexpr int SLOTS = NT + (KS - 1) / S;
+    const int Lout = Lin / S;
+    const dim3 grid(cdiv(Lout, NT), L.cout / (32 * WGM), B);
+    const int nstages = L.cin / 16 / CPS;
+    const size_t lds = (size_t)(nstages > 1 ? 2 : 1) * CPS * (split ? 2 : 1) * 2 * S * SLOTS * 16;   // one-stage layers never touch the second buffer
+    if (split) {
+        auto k = conv_bf16_blk_kernel<KS, S, WGM, CPS, 1, OUT>;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+        k<<<grid, 256, lds, st>>>(xh, xl, wp.hi, wp.lo, L.b, yh, yl, yf, L.cin, Lin, L.cout, Lout, act, slope);
+    } else {
+        auto k = conv_bf16_blk_kernel<KS, S, WGM, CPS, 0, OUT>;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+        k<<<grid, 256, lds, st>>>(xh, xl, wp.hi, wp.lo, L.b, yh, yl, yf, L.cin, Lin, L.cout, Lout, act, slope);
+    }
+    RCA_LAUNCH_CHECK();
+    return RCA_OK;
+}
+
+// dispatch by layer geometry; false: no instantiation for this layer (the caller falls back to conv1d_mfma_kernel's bf16 modes)
+static bool bf16_blk_layer_ok(const ConvLayer& L, bool last) {
+    if (L.tr || L.cin % 16 || L.cout % 64) return false;
+    if (last) return L.k == 3 && L.s == 1 && L.cin % 64 == 0 && L.cout % 128 == 0;
+    if (L.k == 4 && L.s == 2) return L.cin % 32 == 0;
+    if ((L.k == 8 && L.s == 4) || (L.k == 10 && L.s == 5) || (L.k == 16 && L.s == 8)) return L.cout % 128 == 0;
+    return false;
+}
+static bool bf16_blk_ok(const rca_codec* h, int tap_layer) {
+    const size_t n = h->enc.size();
+    if (h->mfma_mode == 0 || h->lat_mode || h->variant != 1 || n < 3) return false;
+    if (h->mfma_mode == 3 && !h->bf16_blk_split) return false;   // hi + lo: the round-3 kernel is the faster one today (2.49 vs 2.66 ms per step)
+    if (tap_layer >= 0 && tap_layer != (int)n - 1) return false;
+    if (h->enc[0].k != 7 || h->enc[0].cin != 1 || h->enc[0].cout % 16 || h->enc[0].cout > 64) return false;
+    for (size_t li = 1; li < n; ++li)
+        if (!bf16_blk_layer_ok(h->enc[li], li + 1 == n)) return false;
+    return true;
+}
+static int run_encoder_bf16(rca_codec* h, RowSrc src, int B, int Tp, size_t max_elems, hipStream_t st, float** ze_out, int tap_layer, float* tap_dev) {
+    const bool split = h->mfma_mode == 3;
+    const float slope = h->cfg.leaky_slope;
+    const size_t n = h->enc.size();
+    int rc;
+    if (h->bf16_packs.size() != n) {
+        h->bf16_packs.assign(n, Bf16Pack{});
+        for (size_t li = 1; li < n; ++li)
+            if ((rc = pack_weights_bf16(h->enc[li], &h->bf16_packs[li])) != RCA_OK) return rc;
+        const ConvLayer& L0 = h->enc[0];
+        std::vector<float> w0((size_t)L0.cout * L0.k), b0(L0.cout), t8((size_t)L0.cout * 8, 0.0f);
+        RCA_HIP(hipMemcpy(w0.data(), L0.w, w0.size() * 4, hipMemcpyDeviceToHost));
+        RCA_HIP(hipMemcpy(b0.data(), L0.b, b0.size() * 4, hipMemcpyDeviceToHost));
+        for (int co = 0; co < L0.cout; ++co) {
+            for (int kk = 0; kk < L0.k; ++kk) t8[(size_t)co * 8 + kk] = w0[(size_t)co * L0.k + kk];
+            t8[(size_t)co * 8 + 7] = b0[co];
+        }
+        RCA_HIP(hipMalloc((void**)&h->bf16_packs[0].w_in8, t8.size() * 4));
+        RCA_HIP(hipMemcpy(h->bf16_packs[0].w_in8, t8.data(), t8.size() * 4, hipMemcpyHostToDevice));
+    }
+    auto hi_of = [&](int buf) { return h->act[buf].as<conv_bf16raw>(); };
+    auto lo_of = [&](int buf) { return h->act[buf].as<conv_bf16raw>() + max_elems; };   // second half of the 4-byte-per-element buffer
+    const double esz = split ? 4.0 : 2.0;
+    int cur = 0, L = Tp;
+    {
+        const ConvLayer& L0 = h->enc[0];
+        const long total = (long)B * L;
+        ProfScope ps(h, st, 2, 2.0 * L0.k * L0.cout * (double)total, 4.0 * (double)total + esz * (double)total * L0.cout);
+        const int act = h->enc[1].pre ? 1 : 0;
+        if (split) conv_in_blk_kernel<7, 1><<<dim3(cdiv(L, 256), B), 256, 0, st>>>(src, h->bf16_packs[0].w_in8, L0.b, hi_of(cur), lo_of(cur), B, L0.cout, L, act, slope);
+        else conv_in_blk_kernel<7, 0><<<dim3(cdiv(L, 256), B), 256, 0, st>>>(src, h->bf16_packs[0].w_in8, L0.b, hi_of(cur), lo_of(cur), B, L0.cout, L, act, slope);
+        RCA_LAUNCH_CHECK();
+    }
+    for (size_t li = 1; li < n; ++li) {
+        const ConvLayer& Ly = h->enc[li];
+        const bool last = li + 1 == n;
+        const int Lout = L / Ly.s;
+        const int act = (!last && h->enc[li + 1].pre) ? 1 : 0;
+        ProfScope ps(h, st, 0, 2.0 * Ly.cin * Ly.k * Ly.cout * (double)B * Lout,
+                     esz * (double)B * Ly.cin * L + (last ? 4.0 : esz) * (double)B * Ly.cout * Lout + esz * (double)Ly.cin * Ly.k * Ly.cout);
+        const Bf16Pack& wp = h->bf16_packs[li];
+        const conv_bf16raw *xh = hi_of(cur), *xl = lo_of(cur);
+        conv_bf16raw *yh = hi_of(cur ^ 1), *yl = lo_of(cur ^ 1);
+        float* yf = h->act[cur ^ 1].as<float>();
+        if (last) rc = launch_conv_bf16<3, 1, 4, 4, 1>(split, Ly, wp, xh, xl, yh, yl, yf, B, L, act, slope, st);
+        else if (Ly.k == 4) rc = launch_conv_bf16<4, 2, 2, 2, 0>(split, Ly, wp, xh, xl, yh, yl, yf, B, L, act, slope, st);
+        else if (Ly.k == 8) rc = launch_conv_bf16<8, 4, 4, 1, 0>(split, Ly, wp, xh, xl, yh, yl, yf, B, L, act, slope, st);
+        else if (Ly.k == 10) rc = launch_conv_bf16<10, 5, 4, 1, 0>(split, Ly, wp, xh, xl, yh, yl, yf, B, L, act, slope, st);
+        else rc = launch_conv_bf16<16, 8, 4, 1, 0>(split, Ly, wp, xh, xl, yh, yl, yf, B, L, act, slope, st);
+        if (rc != RCA_OK) return rc;
+        L = Lout;
+        cur ^= 1;
+        if (last && tap_layer == (int)li) RCA_HIP(hipMemcpyAsync(tap_dev, yf, (size_t)B * Ly.cout * L * 4, hipMemcpyDeviceToDevice, st));
+    }
+    *ze_out = h->act[cur].as<float>();
+    return RCA_OK;
+}
+
 // encoder stack: rows described by src -> ze [B][D][F] left in *ze_out (a workspace buffer).
 // tap_layer >= 0 copies that layer's output (device->device) into tap_dev.
 static int run_encoder(rca_codec* h, RowSrc src, int B, hipStream_t st, float** ze_out, int* F_out, int tap_layer, float* tap_dev) {
@@ -2202,6 +2588,10 @@ static int run_encoder(rca_codec* h, RowSrc src, int B, hipStream_t st, float** 
     int rc;
     if ((rc = h->act[0].ensure(max_elems * 4)) != RCA_OK) return rc;
     if ((rc = h->act[1].ensure(max_elems * 4)) != RCA_OK) return rc;
+    if (bf16_blk_ok(h, tap_layer) && (double)B * max_elems < 4.0e18 && Tp / h->enc[1].s >= 64) {   // opt-in bf16 modes: the blocked pipeline
+        *F_out = F;
+        return run_encoder_bf16(h, src, B, Tp, max_elems, st, ze_out, tap_layer, tap_dev);
+    }
     int cur = 0;
     int L = Tp;
     size_t first = 1;
@@ -2722,6 +3112,7 @@ extern "C" int rca_codec_set_mfma_mode(rca_codec_t* h, int32_t mode) {
             if (kv.second.exec) { (void)hipGraphExecDestroy(kv.second.exec); kv.second.exec = nullptr; }
     }
     h->mfma_mode = mode;
+    { const char* e = getenv("RCA_BF16_BLK_SPLIT"); h->bf16_blk_split = e && atoi(e) != 0; }
     return RCA_OK;
 }
 

