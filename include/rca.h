@@ -356,6 +356,13 @@ int rca_duplex_frame(rca_lm_t* lm, rca_codec_t* codec, const rca_duplex_frame_ar
 /* Optional: make rca_duplex_frame's one-time allocations for a call shape (pinned staging, device buffers, side stream) ahead of the
  * first frame -- a session calls it at reset() (realtime_agent_v2.py:127-161) so that no frame pays for a pinned allocation. */
 int rca_duplex_prepare(rca_lm_t* lm, int32_t T, int32_t F_ctx, int32_t n_steps, int32_t n_samples);
+/* Optional, after rca_duplex_prepare and rca_lm_sampler_init: capture every graph the session's frames can replay BEFORE the first
+ * frame -- the one-replay frame of the call shape in `args` (T, F_ctx, n_steps, n_samples, code_token_base, probe_id >= 0 or not; the
+ * data pointers and first_pair are not read) for every context bucket n_ctx reaches, on the KV cache of `lm` and, when the session
+ * trims through a shadow cache, on `twin`'s too (may be NULL), and with n_probe > 0 the speculative one-token step + n_probe
+ * probabilities (rca_lm_step_probe; realtime_agent_v2.py:455-466).  A session calls it at reset() (realtime_agent_v2.py:127-161): no
+ * frame then pays a graph capture. */
+int rca_duplex_precapture(rca_lm_t* lm, rca_lm_t* twin, rca_codec_t* codec, const rca_duplex_frame_args_t* args, int32_t n_probe);
 /* what rca_duplex_frame needs from a codec handle whose tail calls it captures: a signature of every address a captured tail
  * call bakes in, a hand-over of the handle's stream ordering to the capturing stream, the codebook size */
 int rca_codec_workspace_sig(rca_codec_t* h, uint64_t* sig);

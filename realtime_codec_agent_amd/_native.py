@@ -305,7 +305,7 @@ ABI_SYMBOLS = [
     "rca_lm_sync", "rca_lm_set_graphs", "rca_lm_mask_head_rows", "rca_lm_set_mfma_prefill", "rca_lm_set_logits_all",
     "rca_lm_persist_codec_embeddings", "rca_lm_create_shared", "rca_lm_eval_async", "rca_lm_copy_kv", "rca_lm_swap_kv",
     "rca_lm_set_low_priority", "rca_lm_frame", "rca_lm_weight_format", "rca_lm_set_attn_fuse",
-    "rca_duplex_frame", "rca_codec_workspace_sig", "rca_codec_stream_handoff", "rca_codec_codebook_size", "rca_codec_set_mfma_mode", "rca_lm_step_probe", "rca_duplex_prepare",
+    "rca_duplex_frame", "rca_codec_workspace_sig", "rca_codec_stream_handoff", "rca_codec_codebook_size", "rca_codec_set_mfma_mode", "rca_lm_step_probe", "rca_duplex_prepare", "rca_duplex_precapture",
 ]
 
 

@@ -4336,7 +4336,8 @@ extern "C" int rca_lm_sample(rca_lm_t* h, int32_t* token) {
 // eval(ids[0..n)) + sample with no host round trip in between.  For n <= 2 and a plain (not
 // logits_all) handle the whole step is one hipGraph replay.
 // eval + sample (+ optionally softmax(logits)[probe ids] of the evaluated position) as one replay and one synchronisation
-static int lm_step_impl(rca_lm_t* h, const int32_t* ids, int32_t n, const int32_t* probe_ids, int32_t n_probe, int32_t* token, float* probs_out) {
+static int lm_step_impl(rca_lm_t* h, const int32_t* ids, int32_t n, const int32_t* probe_ids, int32_t n_probe, int32_t* token, float* probs_out,
+                        int cap_bucket = -1) {
     if (!h || !ids || !token || n < 1) return fail(RCA_ERR_ARG, "step: bad argument");
     if (n_probe < 0 || n_probe > 8 || (n_probe > 0 && (!probe_ids || !probs_out))) return fail(RCA_ERR_ARG, "step: 0..8 probe ids");
     { const int src = lm_settle(h); if (src != RCA_OK) return src; }
@@ -4364,6 +4365,7 @@ static int lm_step_impl(rca_lm_t* h, const int32_t* ids, int32_t n, const int32_
     int bucket = 0;
     const int need = lm_splits_needed(h, n);
     while (bucket + 1 < LM_GRAPH_BUCKETS && (4 << bucket) < need) ++bucket;
+    if (cap_bucket >= 0) bucket = cap_bucket;
     const int nsp_launch = bucket + 1 == LM_GRAPH_BUCKETS ? h->n_splits : std::min(h->n_splits, 4 << bucket);
     rca_lm::GraphSet& gs = lm_graph_set(h);
     hipGraphExec_t& gexec = n_probe ? gs.gp[n][bucket] : gs.g[n][bucket];
@@ -4393,6 +4395,7 @@ static int lm_step_impl(rca_lm_t* h, const int32_t* ids, int32_t n, const int32_
         if (e2 != hipSuccess) { gexec = nullptr; return fail(RCA_ERR_HIP, "graph instantiate: %s", hipGetErrorString(e2)); }
         if (n_probe) gs.gp_nprobe[n][bucket] = n_probe;
     }
+    if (cap_bucket >= 0) return RCA_OK;      // rca_duplex_precapture: the graph exists now, nothing is launched
     RCA_HIP(hipGraphLaunch(gexec, st));
     RCA_HIP(hipStreamSynchronize(st));
     h->n_tokens += n;
@@ -4401,6 +4404,13 @@ static int lm_step_impl(rca_lm_t* h, const int32_t* ids, int32_t n, const int32_
     *token = h->h_stt->out_token;
     for (int i = 0; i < n_probe; ++i) probs_out[i] = reinterpret_cast<const float*>(h->h_probe + 64)[i];
     return RCA_OK;
+}
+static int lm_step_capture_only(rca_lm_t* h, int n, int n_probe, int bucket) {
+    if (h->cfg.logits_all || !h->graphs_enabled || n > 2) return RCA_OK;
+    const int32_t ids[2] = {0, 0}, probes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int32_t tok = 0;
+    float pr[8];
+    return lm_step_impl(h, ids, n, n_probe ? probes : nullptr, n_probe, &tok, n_probe ? pr : nullptr, bucket);
 }
 // eval(ids[0..n)) + sample with no host round trip in between.  For n <= 2 and a plain (not
 // logits_all) handle the whole step is one hipGraph replay.
@@ -4420,13 +4430,13 @@ extern "C" int rca_lm_step_probe(rca_lm_t* h, const int32_t* ids, int32_t n, con
 // of one per step.  If step j samples a token <= audio_id_floor (the loop leaves audio mode there), steps after j have run on a
 // wrong guess: n_done = j + 1, the KV position and the draw counter are put back to what the step-by-step loop would have (their
 // cache slots are stale and get overwritten, exactly like a rollback), and the caller carries on step by step.
-extern "C" int rca_lm_frame(rca_lm_t* h, const int32_t* first_pair, const int32_t* user_ids, int32_t n_steps, int32_t audio_id_floor,
-                            int32_t* out_tokens, int32_t* n_done) {
+static int lm_frame_core(rca_lm_t* h, const int32_t* first_pair, const int32_t* user_ids, int32_t n_steps, int32_t audio_id_floor,
+                         int32_t* out_tokens, int32_t* n_done, int cap_bucket) {
     if (!h || !first_pair || !user_ids || !out_tokens || !n_done) return fail(RCA_ERR_ARG, "frame: null argument");
     if (n_steps < 1 || n_steps > LM_FRAME_MAX) return fail(RCA_ERR_ARG, "frame: %d steps (1..%d)", n_steps, LM_FRAME_MAX);
     if (!h->sampler_set) return fail(RCA_ERR_STATE, "sampler not initialised");
     if (h->cfg.logits_all) return fail(RCA_ERR_STATE, "frame: not on a logits_all handle");
-    if (h->n_tokens + 2 * n_steps > h->cfg.n_ctx) return fail(RCA_ERR_STATE, "context overflow: %d + %d > n_ctx %d", h->n_tokens, 2 * n_steps, h->cfg.n_ctx);
+    if (cap_bucket < 0 && h->n_tokens + 2 * n_steps > h->cfg.n_ctx) return fail(RCA_ERR_STATE, "context overflow: %d + %d > n_ctx %d", h->n_tokens, 2 * n_steps, h->cfg.n_ctx);
     for (int i = 0; i < 2; ++i)
         if (first_pair[i] < 0 || first_pair[i] >= h->cfg.vocab_size) return fail(RCA_ERR_ARG, "frame: token id %d outside the vocabulary", first_pair[i]);
     for (int i = 0; i < n_steps; ++i)
@@ -4443,8 +4453,10 @@ extern "C" int rca_lm_frame(rca_lm_t* h, const int32_t* first_pair, const int32_
     int bucket = 0;
     const int need = lm_splits_needed(h, 2 * n_steps);
     while (bucket + 1 < LM_GRAPH_BUCKETS && (4 << bucket) < need) ++bucket;
+    if (cap_bucket >= 0) bucket = cap_bucket;
     const int nsp_launch = bucket + 1 == LM_GRAPH_BUCKETS ? h->n_splits : std::min(h->n_splits, 4 << bucket);
     hipGraphExec_t& gexec = lm_graph_set(h).fg[n_steps][bucket];
+    if (cap_bucket >= 0 && (gexec || !h->graphs_enabled)) return RCA_OK;
     if (!gexec || !h->graphs_enabled) {
         // graphs disabled (tests): the same launches, eagerly
         const bool capture = h->graphs_enabled;
@@ -4473,6 +4485,7 @@ extern "C" int rca_lm_frame(rca_lm_t* h, const int32_t* first_pair, const int32_
             return rc;
         }
     }
+    if (cap_bucket >= 0) return RCA_OK;      // rca_duplex_precapture: the graph exists now, nothing is launched
     if (h->graphs_enabled) RCA_HIP(hipGraphLaunch(gexec, st));
     RCA_HIP(hipStreamSynchronize(st));
     int done = n_steps;
@@ -4490,6 +4503,11 @@ extern "C" int rca_lm_frame(rca_lm_t* h, const int32_t* first_pair, const int32_
         RCA_HIP(hipMemcpy(&h->stt->rng_counter, &h->rng_host, 8, hipMemcpyHostToDevice));
     }
     return RCA_OK;
+}
+
+extern "C" int rca_lm_frame(rca_lm_t* h, const int32_t* first_pair, const int32_t* user_ids, int32_t n_steps, int32_t audio_id_floor,
+                            int32_t* out_tokens, int32_t* n_done) {
+    return lm_frame_core(h, first_pair, user_ids, n_steps, audio_id_floor, out_tokens, n_done, -1);
 }
 
 // ---- one duplex frame as ONE graph (process_audio, realtime_agent_v2.py:504-554): encode tail of the user's PCM window -> code ->
@@ -4622,15 +4640,19 @@ extern "C" int rca_duplex_prepare(rca_lm_t* h, int32_t T, int32_t F_ctx, int32_t
     return duplex_reserve(h, T, F_ctx, n_steps, n_samples);
 }
 
-extern "C" int rca_duplex_frame(rca_lm_t* h, rca_codec_t* codec, const rca_duplex_frame_args_t* a, rca_duplex_frame_out_t* out,
-                                float* pcm_out_host) {
-    if (!h || !codec || !a || !out || !pcm_out_host || !a->pcm_window || (a->F_ctx > 0 && !a->code_ctx)) return fail(RCA_ERR_ARG, "duplex_frame: null argument");
+// cap_bucket < 0: run the frame.  cap_bucket >= 0 (rca_duplex_precapture): make sure the graph of this call shape exists for that
+// context bucket on the KV cache currently installed -- nothing is launched except, once per shape, the codec's two tail calls on
+// scratch buffers (they size its workspace; a capture must not allocate) -- and return.
+static int duplex_frame_core(rca_lm_t* h, rca_codec_t* codec, const rca_duplex_frame_args_t* a, rca_duplex_frame_out_t* out,
+                             float* pcm_out_host, int cap_bucket) {
+    const bool cap_only = cap_bucket >= 0;
+    if (!h || !codec || !a || (!cap_only && (!out || !pcm_out_host || !a->pcm_window || (a->F_ctx > 0 && !a->code_ctx)))) return fail(RCA_ERR_ARG, "duplex_frame: null argument");
     const int n = a->n_steps;
     if (n < 1 || n > LM_FRAME_MAX) return fail(RCA_ERR_ARG, "duplex_frame: %d steps (1..%d)", n, LM_FRAME_MAX);
     if (a->T < 1 || a->F_ctx < 0 || a->n_samples < 1) return fail(RCA_ERR_ARG, "duplex_frame: bad shape (T=%d F_ctx=%d n_samples=%d)", a->T, a->F_ctx, a->n_samples);
     if (!h->sampler_set) return fail(RCA_ERR_STATE, "sampler not initialised");
     if (h->cfg.logits_all) return fail(RCA_ERR_STATE, "duplex_frame: not on a logits_all handle");
-    if (h->n_tokens + 2 * n > h->cfg.n_ctx) return fail(RCA_ERR_STATE, "context overflow: %d + %d > n_ctx %d", h->n_tokens, 2 * n, h->cfg.n_ctx);
+    if (!cap_only && h->n_tokens + 2 * n > h->cfg.n_ctx) return fail(RCA_ERR_STATE, "context overflow: %d + %d > n_ctx %d", h->n_tokens, 2 * n, h->cfg.n_ctx);
     int32_t n_codes = 0;
     int rc;
     if ((rc = rca_codec_codebook_size(codec, &n_codes)) != RCA_OK) return rc;
@@ -4638,7 +4660,7 @@ extern "C" int rca_duplex_frame(rca_lm_t* h, rca_codec_t* codec, const rca_duple
     for (int i = 0; i < 2; ++i)
         if (a->first_pair[i] < 0 || a->first_pair[i] >= h->cfg.vocab_size) return fail(RCA_ERR_ARG, "duplex_frame: token id %d outside the vocabulary", a->first_pair[i]);
     if (a->probe_id >= h->cfg.vocab_size) return fail(RCA_ERR_ARG, "duplex_frame: probe id %d outside the vocabulary", a->probe_id);
-    for (int i = 0; i < a->F_ctx; ++i)
+    for (int i = 0; !cap_only && i < a->F_ctx; ++i)
         if (a->code_ctx[i] < 0 || a->code_ctx[i] >= n_codes) return fail(RCA_ERR_ARG, "decode: code out of range [0, %d)", n_codes);
     { const int src = lm_settle(h); if (src != RCA_OK) return src; }
     RCA_HIP(hipSetDevice(h->device));
@@ -4657,11 +4679,14 @@ extern "C" int rca_duplex_frame(rca_lm_t* h, rca_codec_t* codec, const rca_duple
     h->h_stt->ids[1] = a->first_pair[1];
     for (int i = 0; i < n; ++i) h->h_stt->ids[LM_FRAME_USER0 + i] = 0;
     pin->probe_id = a->probe_id >= 0 ? a->probe_id : 0;
-    memcpy(d->pin + pin_pcm, a->pcm_window, (size_t)a->T * 4);
-    if (a->F_ctx) memcpy(d->pin + pin_codes, a->code_ctx, (size_t)a->F_ctx * 8);
+    if (!cap_only) {
+        memcpy(d->pin + pin_pcm, a->pcm_window, (size_t)a->T * 4);
+        if (a->F_ctx) memcpy(d->pin + pin_codes, a->code_ctx, (size_t)a->F_ctx * 8);
+    }
     int bucket = 0;
     const int need = lm_splits_needed(h, 2 * n);
     while (bucket + 1 < LM_GRAPH_BUCKETS && (4 << bucket) < need) ++bucket;
+    if (cap_only) bucket = cap_bucket;
     const int nsp_launch = bucket + 1 == LM_GRAPH_BUCKETS ? h->n_splits : std::min(h->n_splits, 4 << bucket);
     uint64_t csig = 0;
     if ((rc = rca_codec_workspace_sig(codec, &csig)) != RCA_OK) return rc;
@@ -4722,6 +4747,21 @@ extern "C" int rca_duplex_frame(rca_lm_t* h, rca_codec_t* codec, const rca_duple
     };
     // the codec's ordering moves to this stream (nothing of it is in flight elsewhere once this returns)
     if ((rc = rca_codec_stream_handoff(codec, d->fork ? d->side : st)) != RCA_OK) return rc;
+    if (cap_only && !warmed) {
+        // size the codec workspace of this shape without touching the LM: the two tail calls on zeroed scratch input
+        hipStream_t se = d->fork ? d->side : st;
+        RCA_HIP(hipMemsetAsync(d->pcm_in, 0, (size_t)a->T * 4, se));
+        RCA_HIP(hipMemsetAsync(d->code_win, 0, (size_t)F * 8, se));
+        if ((rc = rca_codec_encode_tail_dev(codec, d->pcm_in, 1, a->T, n, (int64_t*)d->dev->user_codes, se)) != RCA_OK) return rc;
+        if ((rc = rca_codec_decode_tail_dev(codec, (const int64_t*)d->code_win, 1, F, a->n_samples, d->pcm_out, se)) != RCA_OK) return rc;
+        RCA_HIP(hipStreamSynchronize(se));
+        uint64_t csig2 = 0;
+        if ((rc = rca_codec_workspace_sig(codec, &csig2)) != RCA_OK) return rc;
+        if (d->warm.size() >= 16) d->warm.clear();
+        d->warm.push_back(DuplexState::Warm{a->T, a->F_ctx, n, a->n_samples, (const void*)codec, csig2});
+        ent->key.codec_sig = csig2;
+        warmed = true;
+    }
     const bool want_graph = h->graphs_enabled && warmed;
     if (want_graph && !ent->exec) {
         // the eager frame before this one sized every workspace buffer of this shape: nothing allocates under capture
@@ -4737,6 +4777,7 @@ extern "C" int rca_duplex_frame(rca_lm_t* h, rca_codec_t* codec, const rca_duple
         if (e2 != hipSuccess) { ent->exec = nullptr; return fail(RCA_ERR_HIP, "duplex graph instantiate: %s", hipGetErrorString(e2)); }
         // a workspace that moved under the eager run (first call of a shape) would have changed the signature: checked by the key
     }
+    if (cap_only) return RCA_OK;
     if (want_graph) {
         RCA_HIP(hipGraphLaunch(ent->exec, st));
     } else if ((rc = enqueue()) != RCA_OK) {
@@ -4767,6 +4808,46 @@ extern "C" int rca_duplex_frame(rca_lm_t* h, rca_codec_t* codec, const rca_duple
     h->rng_host += (unsigned long long)done;
     if (done < n) RCA_HIP(hipMemcpy(&h->stt->rng_counter, &h->rng_host, 8, hipMemcpyHostToDevice));
     return RCA_OK;
+}
+
+extern "C" int rca_duplex_frame(rca_lm_t* h, rca_codec_t* codec, const rca_duplex_frame_args_t* a, rca_duplex_frame_out_t* out,
+                                float* pcm_out_host) {
+    return duplex_frame_core(h, codec, a, out, pcm_out_host, -1);
+}
+
+static int lm_step_capture_only(rca_lm_t* h, int n, int n_probe, int bucket);
+
+// Captures, ahead of the first frame, every graph the one-replay frame of this call shape can need: one per context bucket the
+// handle's n_ctx can reach, on the KV cache installed in `h` and -- when the session trims through a shadow cache (kv_shadow.py:
+// the two caches trade places at every trim) -- on `twin`'s as well; plus, with n_probe > 0, the one-token step + n_probe
+// probabilities of the agent's speculative <|end_audio|> step (rca_lm_step_probe).  Called at session start (reset()): no frame of
+// the session then pays a capture (in round 3 the first frame of every bucket and the first trim frame did: 10-14 ms against a
+// median of 4.7).  a->pcm_window / code_ctx / first_pair are not read.
+extern "C" int rca_duplex_precapture(rca_lm_t* h, rca_lm_t* twin, rca_codec_t* codec, const rca_duplex_frame_args_t* a, int32_t n_probe) {
+    if (!h || !codec || !a) return fail(RCA_ERR_ARG, "duplex_precapture: null argument");
+    if (!h->sampler_set) return fail(RCA_ERR_STATE, "sampler not initialised");
+    if (!h->graphs_enabled) return RCA_OK;
+    if (twin && (twin == h || twin->cfg.n_ctx != h->cfg.n_ctx || twin->n_splits != h->n_splits)) return fail(RCA_ERR_ARG, "duplex_precapture: the twin must be another handle of the same n_ctx");
+    { const int src = lm_settle(h); if (src != RCA_OK) return src; }
+    if (twin) { const int src = lm_settle(twin); if (src != RCA_OK) return src; }
+    int rc = RCA_OK;
+    for (int pass = 0; pass < (twin ? 2 : 1) && rc == RCA_OK; ++pass) {
+        if (pass == 1) { std::swap(h->kc, twin->kc); std::swap(h->vc, twin->vc); }      // host pointers only: nothing runs under capture
+        for (int b = 0; b < LM_GRAPH_BUCKETS && rc == RCA_OK; ++b) {
+            if (b > 0 && (4 << (b - 1)) >= h->n_splits) break;                       // the previous bucket already launches every split
+            rc = duplex_frame_core(h, codec, a, nullptr, nullptr, b);
+            if (rc == RCA_OK && n_probe > 0) rc = lm_step_capture_only(h, 1, n_probe, b);
+            // the frames that cannot take the one-replay path (a trim, a text branch) replay the LM chunk or single steps
+            if (rc == RCA_OK) {
+                const int32_t pair[2] = {0, 0}, users[LM_FRAME_MAX] = {0, 0, 0, 0, 0, 0, 0, 0};
+                int32_t toks[LM_FRAME_MAX], done = 0;
+                rc = lm_frame_core(h, pair, users, a->n_steps, -1, toks, &done, b);
+            }
+            if (rc == RCA_OK) rc = lm_step_capture_only(h, 2, 0, b);
+        }
+        if (pass == 1) { std::swap(h->kc, twin->kc); std::swap(h->vc, twin->vc); }
+    }
+    return rc;
 }
 
 extern "C" int rca_lm_token_probs(rca_lm_t* h, const int32_t* token_ids, int32_t n, float* probs_out) {

@@ -98,6 +98,7 @@ def run_duplex_bench(dev=None, secs: float = 125.0, chunk_size_secs: float = 0.0
         "max_frame_step_ms": float(lat_ms.max()) if lat_ms.size else None,
         "frame_budget_ms": budget_ms,
         "frames_over_budget": int((lat_ms > budget_ms).sum()),
+        "slowest_frames": [dict(frame=int(i), at_audio_secs=round((10 + int(i)) * chunk_size_secs, 2), ms=float(lat_ms[i])) for i in np.argsort(-lat_ms)[:5]] if lat_ms.size else [],
         "trims_in_timed_window": trims,
         "kv_shadow": bool(getattr(agent, "kv_shadow_active", False)),
         "frame_graph": bool(getattr(agent, "frame_graph_active", False)),

@@ -474,6 +474,16 @@ class LlamaForAlternatingCodeChannels:
         """duplex_frame's one-time allocations for a call shape, ahead of the first frame (rca_duplex_prepare)."""
         N.check(self._lib.rca_duplex_prepare(self._h, int(T), int(F_ctx), int(n_steps), int(n_samples)), "rca_duplex_prepare")
 
+    def duplex_precapture(self, codec_handle, T: int, F_ctx: int, n_steps: int, n_samples: int, code_token_base: int, with_probe: bool,
+                          twin: Optional["LlamaForAlternatingCodeChannels"] = None, n_step_probe: int = 0) -> None:
+        """Every graph the session's frames can replay, captured now (rca_duplex_precapture): the one-replay frame of this call
+        shape for every context bucket on this handle's KV cache and on `twin`'s (the shadow cache the two trade at a trim), and the
+        speculative step with n_step_probe probabilities.  Needs the sampler to be initialised."""
+        a = N.DuplexFrameArgsC(pcm_window=None, code_ctx=None, T=int(T), F_ctx=int(F_ctx), n_steps=int(n_steps), n_samples=int(n_samples),
+                               code_token_base=int(code_token_base), audio_id_floor=-1, probe_id=0 if with_probe else -1)
+        N.check(self._lib.rca_duplex_precapture(self._h, twin._h if twin is not None else None, codec_handle._h, C.byref(a), int(n_step_probe)),
+                "rca_duplex_precapture")
+
     def duplex_frame(self, codec_handle, pcm_window: np.ndarray, code_ctx: np.ndarray, n_steps: int, n_samples: int,
                      code_token_base: int, audio_id_floor: int, probe_id: int, first_pair: Sequence[int]) -> dict:
         """One whole duplex frame (encode tail -> the chunk's LM steps -> decode tail -> P(probe)) as ONE graph replay

@@ -207,7 +207,7 @@ def test_trim_through_shadow_cache_equals_reference_recompute(mfma_prefill):
             print("shadow stats:", st)
             assert st["swaps"] >= 5 and st["tiles"] >= 5 and st["fallbacks"] == 0
         else:
-            assert agent._kv_shadow is None
+            assert agent._kv_shadow is None or agent._kv_shadow.stats["swaps"] == agent._kv_shadow.stats["planned"] == 0   # (the twin may exist since reset(): never used)
     assert runs[0][3] == runs[1][3] >= 2.0
     assert runs[0][0] == runs[1][0]
     assert np.array_equal(runs[0][1], runs[1][1])
