@@ -1622,12 +1622,15 @@ struct ConvLayer {
 #define RCA_CIC_K8 4
 #define RCA_CIC_K16 2
 #endif
+#ifndef RCA_CIC_K3
+#define RCA_CIC_K3 8
+#endif
 static int conv_cic(int k, int s) {
     if (k == 4 && s == 2) return 4;
     if (k == 8 && s == 4) return RCA_CIC_K8;
     if (k == 10 && s == 5) return 4;
     if (k == 16 && s == 8) return RCA_CIC_K16;
-    if (k == 3 && s == 1) return 8;
+    if (k == 3 && s == 1) return RCA_CIC_K3;
     return 0;
 }
 // ... and of the warp-specialised kernel (32 k-pairs = 128 MFMAs per consumer between barriers)
@@ -1657,9 +1660,8 @@ static int conv_cic_ws(int k, int s) {
 //     (one weight fragment feeds four MFMAs, no two waves load the same fragment);
 //     per stage (CPS blocks of 16 input channels) the next stage's window is loaded into registers before the MFMA block and written
 //     to the other LDS buffer behind it: one barrier per stage;
-//   * mode 3 can run here too (a second, lo, plane of every activation and weight; hi hi + hi lo + lo hi; RCA_BF16_BLK_SPLIT=1) but
-//     stays on conv1d_mfma_kernel<BF = 3> by default: with two planes in LDS the wide layers fit one workgroup per CU and the variant
-//     measures 2.66 ms per step against 2.40-2.49.
+//   * mode 3 keeps a second (lo) plane of every activation and weight and issues hi hi + hi lo + lo hi, product-major (2.43 -> 2.18 ms
+//     per step against conv1d_mfma_kernel<BF = 3>, which RCA_BF16_BLK_SPLIT=0 brings back for A/B runs).
 // k order inside an MFMA differs from the f32 definition (tap-major over a 16-channel block), like every bf16 mode: not bit-exact,
 // the fraction of equal code ids is measured by the bench and the test.
 typedef unsigned short conv_bf16raw;
@@ -1731,14 +1733,21 @@ __global__ __launch_bounds__(256) void conv_in_blk_kernel(RowSrc src, const floa
 // A wave owns 32 channels x 128 columns (1 x 4 MFMA tiles): one weight fragment (16 bytes per lane, straight from L2 into registers,
 // PD taps ahead) feeds four MFMAs and no two waves of a workgroup load the same fragment; the workgroup is WGM waves along the channels
 // x 4 / WGM along the columns.
-template <int KS, int S, int WGM, int CPS, int SPLIT, int OUT>
-__global__ __launch_bounds__(256, SPLIT ? 2 : 3) void conv_bf16_blk_kernel(const conv_bf16raw* __restrict__ x_hi, const conv_bf16raw* __restrict__ x_lo,
+// FUSE = 1 (the first strided layer): the input is not read from HBM but computed while staging as conv_in(PCM) -- conv_in_blk_kernel's
+// f32 chain per (sample, channel), LeakyReLU, bf16 -- so conv_in's 524 MB write and this layer's 524 MB read per 256-window step
+// disappear (a third of all bytes the blocked pipeline moved).
+template <int KS, int S, int WGM, int CPS, int SPLIT, int OUT, int FUSE = 0>
+__global__ __launch_bounds__(256, (SPLIT || KS == 3) ? 2 : 3) void conv_bf16_blk_kernel(const conv_bf16raw* __restrict__ x_hi, const conv_bf16raw* __restrict__ x_lo,
                                                                const conv_bf16raw* __restrict__ w_hi, const conv_bf16raw* __restrict__ w_lo,
                                                                const float* __restrict__ bias, conv_bf16raw* __restrict__ y_hi,
                                                                conv_bf16raw* __restrict__ y_lo, float* __restrict__ y_f32, int Cin, int Lin, int Cout,
-                                                               int Lout, int act, float slope) {
+                                                               int Lout, int act, float slope, int n_rows, int n_ct, int n_cot, RowSrc fsrc,
+                                                               const float* __restrict__ w_in8, int in_act) {
     constexpr int WGN = 4 / WGM;
     constexpr int NT = 128 * WGN;                         // columns per workgroup
+    // hi + lo planes of the wide-stride layers: ONE LDS buffer (two barriers per stage) so that two workgroups fit a CU -- double
+    // buffered they need 82 / 132 KB and ran one workgroup = one wave per SIMD (k16s8 764 us against 148 us rounded)
+    constexpr bool SB = SPLIT && S >= 5;
     constexpr int padL = (KS - S + 1) / 2;
     constexpr int WIN = (NT - 1) * S + KS;                // input samples a column tile sees
     constexpr int SLOTS = NT + (KS - 1) / S;              // 16-byte cells per (plane, half, phase) row
@@ -1746,15 +1755,25 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 3) void conv_bf16_blk_kernel(const
     constexpr int CELLS = 2 * S * SLOTS;                  // cells of one block's window (one plane)
     constexpr int PIECES = 2 * WIN;                       // 16-byte pieces of one block's window (one plane)
     constexpr int NP = (PIECES + 255) / 256;              // per thread
-    constexpr int PD = KS < 8 ? KS : ((CPS * KS) % 8 == 0 ? (SPLIT ? 4 : 8) : 5);   // weight fragments in flight (taps ahead)
+    // weight fragments in flight (taps ahead).  The k = 3 layer keeps a whole stage's fragments in flight (every request of a stage is
+    // then for the NEXT stage and the window loads go out at the top: 44 -> 34 us); on the k = 10 / k = 16 layers the same ring
+    // costs the third wave per SIMD and measured slower (169 vs 161 us, 154 vs 147 us)
+    constexpr int PD = (KS == 3 && !SPLIT) ? CPS * KS : (KS < 8 ? KS : ((CPS * KS) % 8 == 0 ? (SPLIT ? 4 : 8) : 5));
     static_assert((CPS * KS) % PD == 0, "the fragment ring keeps static slots across stages");
     extern __shared__ __attribute__((aligned(16))) conv_u32x4 blk_lds[];   // [2 buffers][CPS][NPL][CELLS]
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, n = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm_w = wave / WGN, wn_w = wave % WGN;       // this wave's 32 x 128 tile inside the workgroup tile
-    const int b = blockIdx.z;
-    const int n0 = blockIdx.x * NT;                       // first output column of the workgroup
-    const int co0 = (blockIdx.y * WGM + wm_w) * 32;       // first output channel of the wave
+    // Workgroup id -> (batch row, column tile, channel tile).  Workgroups are dealt round-robin to the 8 XCDs, each with its own L2:
+    // the channel tiles of one (row, column tile) run back to back on ONE XCD, so the input window is fetched once (speed only; any
+    // placement is correct).  (With the channel tile on blockIdx.y the k16s8 layer fetched its input 4 x, k10s5 2 x.)
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int by = seq % n_cot;
+    const int ct = (seq / n_cot) * 8 + xcd;               // (row, column tile) index; the grid is padded to a multiple of 8 of them
+    if (ct >= n_ct * n_rows) return;
+    const int b = ct / n_ct;
+    const int n0 = (ct - b * n_ct) * NT;                  // first output column of the workgroup
+    const int co0 = (by * WGM + wm_w) * 32;               // first output channel of the wave
     const int Cbi = Cin / 16, nstages = Cbi / CPS;
     const int t_start = n0 * S - padL;
     // ---- staging role (fixed per thread): piece -> (sample, half) -> LDS cell; global offset in 16-byte units from the block's row.
@@ -1813,19 +1832,84 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 3) void conv_bf16_blk_kernel(const
         ah[i] = wq_hi[(long)i * 64];
         if (SPLIT) al[i] = wq_lo[(long)i * 64];
     }
-    stage_load(0);
-    stage_write(0);
+    if constexpr (FUSE) {
+        // conv_in for the workgroup's window: a thread takes samples tid, tid + 256, ... and every channel of them.  All PCM taps are
+        // requested first; the channel loop is outermost, so a channel's 8 weights (wave-uniform: one s_load_dwordx8) serve every
+        // sample of the thread and the samples' fma chains are independent.  Taps outside the signal hold 0 (fma(w, 0, a) = a; the
+        // f32 kernels skip them to keep the sign of a zero sum -- this arithmetic is not bit-exact anyway).
+        static_assert(!FUSE || (CPS * 16 <= 64), "the fused first layer stages all its input channels at once");
+        constexpr int NS = (WIN + 255) / 256;
+        const float* xr = fsrc.base + fsrc.off(b);
+        float xv[NS][7];
+        bool exists[NS];
+        int cell[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            const int tr = tid + 256 * q;
+            const int t = t_start + tr;
+            exists[q] = tr < WIN && t >= 0 && t < Lin;       // outside the layer's input: zero padding
+            cell[q] = tr < WIN ? (tr % S) * SLOTS + tr / S : -1;
+#pragma unroll
+            for (int kk = 0; kk < 7; ++kk) {
+                const int i = t + kk - 3;
+                xv[q][kk] = (tr < WIN && i >= 0 && i < fsrc.T) ? xr[i] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < CPS; ++cb)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                unsigned hi[NS][4], lo[NS][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v[NS][2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float* wr = w_in8 + (cb * 16 + 8 * h + 2 * j + e) * 8;      // wave-uniform: scalar loads
+                        const float w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3], w4 = wr[4], w5 = wr[5], w6 = wr[6], bi = wr[7];
+#pragma unroll
+                        for (int q = 0; q < NS; ++q) {
+                            float a = bi;
+                            a = __builtin_fmaf(w0, xv[q][0], a); a = __builtin_fmaf(w1, xv[q][1], a); a = __builtin_fmaf(w2, xv[q][2], a);
+                            a = __builtin_fmaf(w3, xv[q][3], a); a = __builtin_fmaf(w4, xv[q][4], a); a = __builtin_fmaf(w5, xv[q][5], a);
+                            a = __builtin_fmaf(w6, xv[q][6], a);
+                            a = in_act ? fmaxf(a, a * slope) : a;
+                            v[q][e] = exists[q] ? a : 0.0f;
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) {
+                        hi[q][j] = conv_pack_bf16x2(v[q][0], v[q][1]);
+                        if (SPLIT) lo[q][j] = conv_pack_bf16x2(v[q][0] - __uint_as_float(hi[q][j] << 16), v[q][1] - __uint_as_float(hi[q][j] & 0xffff0000u));
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NS; ++q)
+                    if (cell[q] >= 0) {
+                        blk_lds[(cb * NPL) * CELLS + h * S * SLOTS + cell[q]] = conv_u32x4{hi[q][0], hi[q][1], hi[q][2], hi[q][3]};
+                        if (SPLIT) blk_lds[(cb * NPL + 1) * CELLS + h * S * SLOTS + cell[q]] = conv_u32x4{lo[q][0], lo[q][1], lo[q][2], lo[q][3]};
+                    }
+            }
+    } else {
+        stage_load(0);
+        stage_write(0);
+    }
     __syncthreads();
     int f = 0;                                               // next fragment to consume
     for (int st = 0; st < nstages; ++st) {
-        const int buf = st & 1;
-        if (st + 1 < nstages) stage_load(st + 1);
+        const int buf = SB ? 0 : (st & 1);
+        // Vector-memory results return in order: a weight fragment requested BEHIND the next stage's window loads (HBM latency) cannot
+        // be used before they have landed.  The window loads are therefore issued in the middle of the stage, right behind the last
+        // fragment request this stage itself consumes (fragment i asks for i + PD): everything queued behind them belongs to the
+        // next stage, whose LDS write waits for them anyway.
+        constexpr int LOAD_AT = CPS * KS - PD;
 #pragma unroll
         for (int cb = 0; cb < CPS; ++cb) {
             const conv_u32x4* xb = blk_lds + ((buf * CPS + cb) * NPL) * CELLS;
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
-                const int slot = (cb * KS + kk) % PD;        // static after unrolling (PD divides the stage's fragments or the ring is re-based below)
+                if (cb * KS + kk == LOAD_AT && st + 1 < nstages) stage_load(st + 1);
+                const int slot = (cb * KS + kk) % PD;        // static after unrolling (PD divides the stage's fragments)
                 const int cell = bcell0 + (kk % S) * SLOTS + kk / S;
                 conv_u32x4 bh[4], bl[4];
 #pragma unroll
@@ -1843,18 +1927,22 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 3) void conv_bf16_blk_kernel(const
                 }
                 ++f;
                 const conv_bf16x8 av = __builtin_bit_cast(conv_bf16x8, a_h);
+                // product-major: the four column tiles' accumulators are independent, the three products of one accumulator are not
 #pragma unroll
-                for (int wn = 0; wn < 4; ++wn) {
-                    const conv_bf16x8 bv = __builtin_bit_cast(conv_bf16x8, bh[wn]);
-                    acc[wn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[wn], 0, 0, 0);
-                    if (SPLIT) {
+                for (int wn = 0; wn < 4; ++wn)
+                    acc[wn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(conv_bf16x8, bh[wn]), acc[wn], 0, 0, 0);
+                if (SPLIT) {
+#pragma unroll
+                    for (int wn = 0; wn < 4; ++wn)
                         acc[wn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(conv_bf16x8, bl[wn]), acc[wn], 0, 0, 0);
-                        acc[wn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(conv_bf16x8, a_l), bv, acc[wn], 0, 0, 0);
-                    }
+#pragma unroll
+                    for (int wn = 0; wn < 4; ++wn)
+                        acc[wn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(conv_bf16x8, a_l), __builtin_bit_cast(conv_bf16x8, bh[wn]), acc[wn], 0, 0, 0);
                 }
             }
         }
-        if (st + 1 < nstages) stage_write(buf ^ 1);
+        if (SB) __syncthreads();                           // every wave is done reading the only buffer
+        if (st + 1 < nstages) stage_write(SB ? 0 : (buf ^ 1));
         __syncthreads();
     }
     // ---- epilogue: lane <-> column, register r <-> channel (r & 3) + 8 (r >> 2) + 4 half of the 32-row tile
@@ -1905,7 +1993,7 @@ struct rca_codec {
     bool window_trim = false;   // batch windows: encode only what the kept frames can see (same codes)
     std::vector<ConvLayer> enc, dec;
     std::vector<Bf16Pack> bf16_packs;   // per encoder layer: weights of the blocked bf16 pipeline (built on first use)
-    bool bf16_blk_split = false;        // mode 3 on the blocked pipeline too (RCA_BF16_BLK_SPLIT=1: experiments)
+    bool bf16_blk_split = true;         // mode 3 on the blocked pipeline too (RCA_BF16_BLK_SPLIT=0: the round-3 kernel, for A/B runs)
     float *q_in_w = nullptr, *q_in_b = nullptr;
     float *cb = nullptr, *hc = nullptr, *cbp = nullptr;
     DevBuf act[2], zbuf, keys, io_a, io_b, tail;
@@ -2434,7 +2522,7 @@ static int run_conv(rca_codec* h, const ConvLayer& L, const float* x, float* y, 
         if (L.k == 8 && L.s == 4) return launch_conv_mfma<8, 4, RCA_CIC_K8>(L, x, y, B, Lin, Lout, slope, st, nullptr, act, h->mfma_mode);
         if (L.k == 10 && L.s == 5) return launch_conv_mfma<10, 5, 4>(L, x, y, B, Lin, Lout, slope, st, nullptr, act, h->mfma_mode);
         if (L.k == 16 && L.s == 8) return launch_conv_mfma<16, 8, RCA_CIC_K16>(L, x, y, B, Lin, Lout, slope, st, nullptr, act, h->mfma_mode);
-        if (L.k == 3 && L.s == 1) return launch_conv_mfma<3, 1, 8>(L, x, y, B, Lin, Lout, slope, st, nullptr, act, h->mfma_mode);
+        if (L.k == 3 && L.s == 1) return launch_conv_mfma<3, 1, RCA_CIC_K3>(L, x, y, B, Lin, Lout, slope, st, nullptr, act, h->mfma_mode);
     }
     if (in_activated) return fail(RCA_ERR_ARG, "internal: activated input handed to a kernel without that mode");
     const long total = (long)B * L.cout * Lout;
@@ -2471,25 +2559,27 @@ static int pack_weights_bf16(const ConvLayer& L, Bf16Pack* out) {
     return RCA_OK;
 }
 
-template <int KS, int S, int WGM, int CPS, int OUT>
+template <int KS, int S, int WGM, int CPS, int OUT, int FUSE = 0>
 static int launch_conv_bf16(bool split, const ConvLayer& L, const Bf16Pack& wp, const conv_bf16raw* xh, const conv_bf16raw* xl, conv_bf16raw* yh,
-                            conv_bf16raw* yl, float* yf, int B, int Lin, int act, float slope, hipStream_t st) {
+                            conv_bf16raw* yl, float* yf, int B, int Lin, int act, float slope, hipStream_t st, RowSrc fsrc = RowSrc{},
+                            const float* w_in8 = nullptr, int in_act = 0) {
     constexpr int WGN = 4 / WGM, NT = 128 * WGN;
     constexpr int SLOTS = NT + (KS - 1) / S;
     const int Lout = Lin / S;
-    const dim3 grid(cdiv(Lout, NT), L.cout / (32 * WGM), B);
+    const int n_ct = cdiv(Lout, NT), n_cot = L.cout / (32 * WGM);
+    const dim3 grid((unsigned)(((long)n_ct * B + 7) / 8 * 8 * n_cot));
     const int nstages = L.cin / 16 / CPS;
-    const size_t lds = (size_t)(nstages > 1 ? 2 : 1) * CPS * (split ? 2 : 1) * 2 * S * SLOTS * 16;   // one-stage layers never touch the second buffer
+    const size_t lds = (size_t)((nstages > 1 && !(split && S >= 5)) ? 2 : 1) * CPS * (split ? 2 : 1) * 2 * S * SLOTS * 16;   // one-stage layers and the single-buffered split layers never touch a second buffer
     if (split) {
-        auto k = conv_bf16_blk_kernel<KS, S, WGM, CPS, 1, OUT>;
+        auto k = conv_bf16_blk_kernel<KS, S, WGM, CPS, 1, OUT, FUSE>;
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-        k<<<grid, 256, lds, st>>>(xh, xl, wp.hi, wp.lo, L.b, yh, yl, yf, L.cin, Lin, L.cout, Lout, act, slope);
+        k<<<grid, 256, lds, st>>>(xh, xl, wp.hi, wp.lo, L.b, yh, yl, yf, L.cin, Lin, L.cout, Lout, act, slope, B, n_ct, n_cot, fsrc, w_in8, in_act);
     } else {
-        auto k = conv_bf16_blk_kernel<KS, S, WGM, CPS, 0, OUT>;
+        auto k = conv_bf16_blk_kernel<KS, S, WGM, CPS, 0, OUT, FUSE>;
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-        k<<<grid, 256, lds, st>>>(xh, xl, wp.hi, wp.lo, L.b, yh, yl, yf, L.cin, Lin, L.cout, Lout, act, slope);
+        k<<<grid, 256, lds, st>>>(xh, xl, wp.hi, wp.lo, L.b, yh, yl, yf, L.cin, Lin, L.cout, Lout, act, slope, B, n_ct, n_cot, fsrc, w_in8, in_act);
     }
     RCA_LAUNCH_CHECK();
     return RCA_OK;
@@ -2506,7 +2596,7 @@ static bool bf16_blk_layer_ok(const ConvLayer& L, bool last) {
 static bool bf16_blk_ok(const rca_codec* h, int tap_layer) {
     const size_t n = h->enc.size();
     if (h->mfma_mode == 0 || h->lat_mode || h->variant != 1 || n < 3) return false;
-    if (h->mfma_mode == 3 && !h->bf16_blk_split) return false;   // hi + lo: the round-3 kernel is the faster one today (2.49 vs 2.66 ms per step)
+    if (h->mfma_mode == 3 && !h->bf16_blk_split) return false;   // (RCA_BF16_BLK_SPLIT=0: the round-3 kernel, 2.43 ms per step against 2.18 here)
     if (tap_layer >= 0 && tap_layer != (int)n - 1) return false;
     if (h->enc[0].k != 7 || h->enc[0].cin != 1 || h->enc[0].cout % 16 || h->enc[0].cout > 64) return false;
     for (size_t li = 1; li < n; ++li)
@@ -2537,7 +2627,8 @@ static int run_encoder_bf16(rca_codec* h, RowSrc src, int B, int Tp, size_t max_
     auto lo_of = [&](int buf) { return h->act[buf].as<conv_bf16raw>() + max_elems; };   // second half of the 4-byte-per-element buffer
     const double esz = split ? 4.0 : 2.0;
     int cur = 0, L = Tp;
-    {
+    const bool fuse_in = h->enc[1].k == 4 && h->enc[1].s == 2 && h->enc[0].cout == 32 && !getenv("RCA_BF16_NO_FUSE_IN");
+    if (!fuse_in) {
         const ConvLayer& L0 = h->enc[0];
         const long total = (long)B * L;
         ProfScope ps(h, st, 2, 2.0 * L0.k * L0.cout * (double)total, 4.0 * (double)total + esz * (double)total * L0.cout);
@@ -2551,13 +2642,17 @@ static int run_encoder_bf16(rca_codec* h, RowSrc src, int B, int Tp, size_t max_
         const bool last = li + 1 == n;
         const int Lout = L / Ly.s;
         const int act = (!last && h->enc[li + 1].pre) ? 1 : 0;
-        ProfScope ps(h, st, 0, 2.0 * Ly.cin * Ly.k * Ly.cout * (double)B * Lout,
-                     esz * (double)B * Ly.cin * L + (last ? 4.0 : esz) * (double)B * Ly.cout * Lout + esz * (double)Ly.cin * Ly.k * Ly.cout);
+        const bool fused_li = li == 1 && fuse_in;   // reads PCM (f32), computes conv_in on the way
+        ProfScope ps(h, st, 0, 2.0 * Ly.cin * Ly.k * Ly.cout * (double)B * Lout + (fused_li ? 2.0 * h->enc[0].k * h->enc[0].cout * (double)B * L : 0.0),
+                     (fused_li ? 4.0 * (double)B * L : esz * (double)B * Ly.cin * L) + (last ? 4.0 : esz) * (double)B * Ly.cout * Lout +
+                         esz * (double)Ly.cin * Ly.k * Ly.cout);
         const Bf16Pack& wp = h->bf16_packs[li];
         const conv_bf16raw *xh = hi_of(cur), *xl = lo_of(cur);
         conv_bf16raw *yh = hi_of(cur ^ 1), *yl = lo_of(cur ^ 1);
         float* yf = h->act[cur ^ 1].as<float>();
         if (last) rc = launch_conv_bf16<3, 1, 4, 4, 1>(split, Ly, wp, xh, xl, yh, yl, yf, B, L, act, slope, st);
+        else if (Ly.k == 4 && li == 1 && fuse_in)
+            rc = launch_conv_bf16<4, 2, 2, 2, 0, 1>(split, Ly, wp, xh, xl, yh, yl, yf, B, L, act, slope, st, src, h->bf16_packs[0].w_in8, Ly.pre ? 1 : 0);
         else if (Ly.k == 4) rc = launch_conv_bf16<4, 2, 2, 2, 0>(split, Ly, wp, xh, xl, yh, yl, yf, B, L, act, slope, st);
         else if (Ly.k == 8) rc = launch_conv_bf16<8, 4, 4, 1, 0>(split, Ly, wp, xh, xl, yh, yl, yf, B, L, act, slope, st);
         else if (Ly.k == 10) rc = launch_conv_bf16<10, 5, 4, 1, 0>(split, Ly, wp, xh, xl, yh, yl, yf, B, L, act, slope, st);
@@ -3112,7 +3207,7 @@ extern "C" int rca_codec_set_mfma_mode(rca_codec_t* h, int32_t mode) {
             if (kv.second.exec) { (void)hipGraphExecDestroy(kv.second.exec); kv.second.exec = nullptr; }
     }
     h->mfma_mode = mode;
-    { const char* e = getenv("RCA_BF16_BLK_SPLIT"); h->bf16_blk_split = e && atoi(e) != 0; }
+    { const char* e = getenv("RCA_BF16_BLK_SPLIT"); h->bf16_blk_split = !(e && atoi(e) == 0); }
     return RCA_OK;
 }
 

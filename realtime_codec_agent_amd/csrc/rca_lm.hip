@@ -10,9 +10,11 @@
 //             accumulation, weights streamed once per step with non-temporal 16-B loads: HBM-bound, ~3 GB per step
 //   prefill   (> 8 tokens) 128-token tiles on bf16 MFMA with hi/lo-split activations (lm_gemm128_kernel)
 //   KV cache  fp16 [layer][pos][kv_head][64] (llama.cpp's default cache type)
-//   attention one MFMA kernel for both: 256-key splits x blocks of 32 query rows, then a merge of the splits
-//   sampler   histogram -> candidate gather -> rank-by-counting top-k -> top-p/min-p/temperature -> inverse CDF
-//             with a counter-based RNG and a polynomial exp, all on the device
+//   attention decode: 256-key splits x blocks of 32 query rows on MFMA (K / V in whole rows through wave-private LDS images), the
+//             splits merged inside the launch by data-tagged 8-byte granules; prefill: a flash-shaped kernel
+//   sampler   logit bias + repeat / frequency / presence penalties patched in place -> histogram -> candidate gather ->
+//             rank-by-counting top-k -> top-p/min-p/temperature -> inverse CDF (top_k 1..256), or the whole vocabulary by the
+//             Gumbel-max rule behind radix-select rank / mass thresholds; counter-based RNG, polynomial exp / log, all on the device
 //   the steady-state step (eval 1-2 tokens + sample) is captured once per context bucket into a hipGraph; the KV
 //   position, input ids and RNG counter live in device memory so the graph replays unchanged.
 #include <algorithm>

@@ -18,7 +18,7 @@ for f in glob.glob(f"{dst}/*_kernel_stats.csv") + glob.glob(f"{dst}/*_stdout.log
 head = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
 dirty = subprocess.run(["git", "status", "--porcelain", "--", "bench.py", "realtime_codec_agent_amd", "include"], capture_output=True, text=True).stdout.strip()
 open(f"{dst}/SUMMARY.txt", "w").write(f"git_head={head}{' +uncommitted changes' if dirty else ''}\n" + summary)
-for sub in ("bench", "lm", "lm_6k", "lm_q8", "lm_q4k"):
+for sub in ("bench", "bench_bf16", "lm", "lm_6k", "lm_q8", "lm_q4k"):
     ks = newest(f"{src}/{sub}/*/*kernel_stats.csv")
     if not ks:
         continue

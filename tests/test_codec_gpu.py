@@ -411,15 +411,15 @@ def test_bf16_mfma_modes_track_the_f32_path():
         equal = float((codes == ref_codes).mean())
         print(f"mfma mode {mode}: max |diff| / max |act| = {err:.2e}, code ids equal = {equal:.4f}")
         assert err < tol and equal >= min_equal
-    # mode 1 runs the blocked bf16 pipeline (channel-blocked bf16 activations, weights packed once: round 4); mode 3 can run there too
-    # (RCA_BF16_BLK_SPLIT=1; the round-3 kernel is the faster one and stays the default): same tolerances
+    # both modes run the blocked bf16 pipeline (channel-blocked bf16 activations, weights packed once: round 4); the round-3 kernel
+    # (conv1d_mfma_kernel<BF>) still serves mode 3 under RCA_BF16_BLK_SPLIT=0 and every shape the pipeline does not take: same tolerances
     import os
-    os.environ["RCA_BF16_BLK_SPLIT"] = "1"
+    os.environ["RCA_BF16_BLK_SPLIT"] = "0"
     try:
         hip.set_mfma_mode(0); hip.set_mfma_mode(3)
         codes, tap = hip.encode(pcm), hip.encode_tap(pcm, last)
         err, equal = float(np.abs(tap - ref_tap).max()) / scale, float((codes == ref_codes).mean())
-        print(f"mfma mode 3 on the blocked pipeline: max |diff| / max |act| = {err:.2e}, code ids equal = {equal:.4f}")
+        print(f"mfma mode 3 on the round-3 kernel: max |diff| / max |act| = {err:.2e}, code ids equal = {equal:.4f}")
         assert err < 2e-4 and equal >= 0.97
     finally:
         del os.environ["RCA_BF16_BLK_SPLIT"]
