@@ -1664,6 +1664,9 @@ static int conv_cic_ws(int k, int s) {
 //     per step against conv1d_mfma_kernel<BF = 3>, which RCA_BF16_BLK_SPLIT=0 brings back for A/B runs).
 // k order inside an MFMA differs from the f32 definition (tap-major over a 16-channel block), like every bf16 mode: not bit-exact,
 // the fraction of equal code ids is measured by the bench and the test.
+#ifndef RCA_BLK_ABL
+#define RCA_BLK_ABL 0
+#endif
 typedef unsigned short conv_bf16raw;
 typedef __attribute__((ext_vector_type(4))) unsigned conv_u32x4;
 
@@ -1870,6 +1873,9 @@ __global__ __launch_bounds__(256, (SPLIT || KS == 3) ? 2 : 3) void conv_bf16_blk
 #pragma unroll
                         for (int q = 0; q < NS; ++q) {
                             float a = bi;
+#if RCA_BLK_ABL == 1   // timing experiment: no conv_in arithmetic
+                            v[q][e] = xv[q][e]; continue;
+#endif
                             a = __builtin_fmaf(w0, xv[q][0], a); a = __builtin_fmaf(w1, xv[q][1], a); a = __builtin_fmaf(w2, xv[q][2], a);
                             a = __builtin_fmaf(w3, xv[q][3], a); a = __builtin_fmaf(w4, xv[q][4], a); a = __builtin_fmaf(w5, xv[q][5], a);
                             a = __builtin_fmaf(w6, xv[q][6], a);
@@ -1927,6 +1933,10 @@ __global__ __launch_bounds__(256, (SPLIT || KS == 3) ? 2 : 3) void conv_bf16_blk
                 }
                 ++f;
                 const conv_bf16x8 av = __builtin_bit_cast(conv_bf16x8, a_h);
+#if RCA_BLK_ABL == 2   // timing experiment: no MFMAs (operands kept alive)
+                asm volatile("" ::"v"(a_h), "v"(bh[0]), "v"(bh[1]), "v"(bh[2]), "v"(bh[3]));
+                continue;
+#endif
                 // product-major: the four column tiles' accumulators are independent, the three products of one accumulator are not
 #pragma unroll
                 for (int wn = 0; wn < 4; ++wn)
@@ -1946,6 +1956,10 @@ __global__ __launch_bounds__(256, (SPLIT || KS == 3) ? 2 : 3) void conv_bf16_blk
         __syncthreads();
     }
     // ---- epilogue: lane <-> column, register r <-> channel (r & 3) + 8 (r >> 2) + 4 half of the 32-row tile
+#if RCA_BLK_ABL == 3   // timing experiment: one store per wave instead of the tile
+    if (lane == 0 && acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.0f) y_hi[0] = 1;
+    return;
+#endif
 #pragma unroll
     for (int wn = 0; wn < 4; ++wn) {
         const int t = n0 + wn_w * 128 + wn * 32 + n;
