@@ -356,9 +356,11 @@ __host__ __device__ __forceinline__ long q8_sc_index(long pair, long kblock, lon
 // SIMD) although their live set is ~130: a streaming kernel wants the occupancy.
 constexpr int gemv_min_waves(int Q, int R, int NIT) { return (Q != WF_Q8 && Q != WF_Q4K && Q != WF_Q6K) ? 1 : (R * NIT >= 16 ? 2 : 4); }
 template <int M, int NIT, int R, int PRO, int EPI, int Q = 0>
-__global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel(const LmDevState* __restrict__ stt, const bf16_t* __restrict__ W,
-                                                      const float* __restrict__ x, float* __restrict__ y, int N, int K,
-                                                      int batches_per_wg, int ldy, GemvPro pro, GemvRope rope, GemvQ8 q8 = GemvQ8{nullptr, nullptr, nullptr}) {
+__global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel(const LmDevState* __restrict__ stt, const bf16_t* __restrict__ W, GemvQ8 q8,
+                                                      const float* __restrict__ x, int N, int K, float* __restrict__ y,
+                                                      int batches_per_wg, int ldy, GemvPro pro, GemvRope rope) {
+    // (argument order: the weight pointers of either form, x, N, K -- what the first loads need -- are the 14 dwords the dispatcher
+    //  preloads into SGPRs)
     constexpr int V = R * M;
     static_assert(V % 4 == 0 && R % 2 == 0, "R * M must be a multiple of 4");
     __shared__ float kred[2][4][V];
@@ -2611,9 +2613,9 @@ static void launch_gemv_r(const GemvGeom& g, rca_lm* h, const WMat& w, const flo
     const int grid = cdiv(cdiv(N, g.R), g.bpw);
     const GemvQ8 qa{w.qs, w.sc, w.dd};
     switch (g.R) {
-        case 4: lm_gemv_kernel<M, NIT, 4, PRO, EPI, Q><<<grid, 256, 0, st>>>(h->stt, w.w, x, y, N, K, g.bpw, ldy, pro, rope, qa); break;
-        case 8: lm_gemv_kernel<M, NIT, 8, PRO, EPI, Q><<<grid, 256, 0, st>>>(h->stt, w.w, x, y, N, K, g.bpw, ldy, pro, rope, qa); break;
-        default: lm_gemv_kernel<M, NIT, 16, PRO, EPI, Q><<<grid, 256, 0, st>>>(h->stt, w.w, x, y, N, K, g.bpw, ldy, pro, rope, qa); break;
+        case 4: lm_gemv_kernel<M, NIT, 4, PRO, EPI, Q><<<grid, 256, 0, st>>>(h->stt, w.w, qa, x, N, K, y, g.bpw, ldy, pro, rope); break;
+        case 8: lm_gemv_kernel<M, NIT, 8, PRO, EPI, Q><<<grid, 256, 0, st>>>(h->stt, w.w, qa, x, N, K, y, g.bpw, ldy, pro, rope); break;
+        default: lm_gemv_kernel<M, NIT, 16, PRO, EPI, Q><<<grid, 256, 0, st>>>(h->stt, w.w, qa, x, N, K, y, g.bpw, ldy, pro, rope); break;
     }
 }
 template <int PRO, int EPI, int Q>
@@ -2741,10 +2743,12 @@ __device__ long* rca_attn_tl = nullptr;
 
 #define ATTM_LDS (8 * 32 * 64 * 4 + 2 * 8 * 32 * 4)   // wo (aliases the K / V images) + wm + wl
 template <int G>
+// (argument order: what the first loads need -- the cache pointers, the head counts, n_ctx -- sits inside the 14 dwords the
+//  dispatcher preloads into SGPRs; `part` / `arrive` / `attn_out` are only needed at the end)
 __global__ __launch_bounds__(512) void lm_attn_mfma_kernel(const LmDevState* __restrict__ stt, const float* __restrict__ qkv,
                                                            const f16_t* __restrict__ kc, const f16_t* __restrict__ vc,
-                                                           float* __restrict__ part, int nh, int nkv, int n_splits, float scale, int n_ctx,
-                                                           int* __restrict__ arrive, float* __restrict__ attn_out) {
+                                                           int nh, int nkv, int n_splits, float scale, int n_ctx,
+                                                           float* __restrict__ part, int* __restrict__ arrive, float* __restrict__ attn_out) {
     // arrive != nullptr (decode steps: one query block, at most one workgroup per CU, at most 8 live query rows): the merge of the
     // splits happens HERE, by data-tagged granules (MI355X_MICROARCH.md, price list rows handoff-1to1 / allgather: "granule = one
     // naturally aligned 8-byte {data, tag} written by ONE sc1 store", polled with sc1 loads; R2: a granule needs no ordering).  Every
@@ -3502,7 +3506,7 @@ static void launch_attention_mfma(rca_lm* h, int M, int nsp_launch, const f16_t*
     const bool fuse = h->fuse_attn && !hi && agm.z == 1 && c.n_kv_heads * nsp_launch <= 256 && M * G <= 8 && nsp_launch <= ATT_TAG_MAXSP && c.n_kv_heads <= ATT_EPOCH_INTS;
     int* arrive = fuse ? h->att_arrive : nullptr;
 #define RCA_ATTN_LAUNCH(GG)                                                                                                                        \
-    lm_attn_mfma_kernel<GG><<<agm, 512, ATTM_LDS, st>>>(h->stt, h->qkv, kc, vc, h->att_part, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx, \
+    lm_attn_mfma_kernel<GG><<<agm, 512, ATTM_LDS, st>>>(h->stt, h->qkv, kc, vc, c.n_heads, c.n_kv_heads, h->n_splits, scale, c.n_ctx, h->att_part, \
                                                         arrive, h->attn);                                                                          \
     if (!fuse) lm_attn_mfma_combine_kernel<GG><<<M * c.n_heads, 64, 0, st>>>(h->stt, h->att_part, h->attn, c.n_heads, c.n_kv_heads, h->n_splits, nsp_launch, hi, lo);
     if (G == 4) { RCA_ATTN_LAUNCH(4) }
