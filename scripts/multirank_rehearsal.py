@@ -21,7 +21,9 @@ def main():
     out = {}
 
     # ---- 1. bench.py --gpus 2 (self-launch)
-    e1 = dict(env, RCA_BENCH_DEVICE="0", RCA_BENCH_BACKEND="gloo")
+    # RCCL is ASKED for (the driver's 8-GPU run does too); two ranks on one card make it refuse, so this also runs the control plane's
+    # fall-back to gloo inside the rank processes for real (dist_utils.ControlPlane; RCA_REHEARSE_BACKEND=gloo skips the attempt)
+    e1 = dict(env, RCA_BENCH_DEVICE="0", RCA_BENCH_BACKEND=os.environ.get("RCA_REHEARSE_BACKEND", "nccl"))
     t0 = time.perf_counter()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--duplex-secs", "10"], env=e1,
                        capture_output=True, text=True, timeout=900)
@@ -29,7 +31,10 @@ def main():
     assert r.returncode == 0 and line, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
     b = json.loads(line)
     assert b["n_gpus"] == 2 and b["duplex"]["sessions"] == 2 and len(b["duplex"]["per_gpu"]) == 2
+    cp = b["config"]["control_plane"]
+    assert cp["backend"] in ("gloo", "nccl") and (cp["backend"] == "nccl" or e1["RCA_BENCH_BACKEND"] == "gloo" or cp["fallback_reason"]), cp
     out["bench_gpus2"] = dict(wall_s=round(time.perf_counter() - t0, 1), n_gpus=b["n_gpus"], value=b["value"], ms_per_step=b["ms_per_step"], scaling=b["scaling"],
+                              control_plane=cp,
                               duplex_sessions=b["duplex"]["sessions"], duplex_per_rank=b["duplex"]["per_gpu"])
     print("1. bench.py --gpus 2:", json.dumps(out["bench_gpus2"]), flush=True)
 
@@ -54,14 +59,14 @@ def main():
             cmd = [sys.executable] + argv
         else:
             cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", "29611"] + argv
-        r = subprocess.run(cmd, env=dict(env, RCA_DEVICE="0", RCA_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900, cwd=ROOT)
+        r = subprocess.run(cmd, env=dict(env, RCA_DEVICE="0", RCA_DIST_BACKEND=os.environ.get("RCA_REHEARSE_BACKEND", "nccl")), capture_output=True, text=True, timeout=900, cwd=ROOT)
         line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
         assert r.returncode == 0 and line, (world, r.returncode, r.stdout[-2000:], r.stderr[-3000:])
         res[world] = json.loads(line)
 
     t1, t2 = tree(os.path.join(root, "codes1")), tree(os.path.join(root, "codes2"))
     assert t1.keys() == t2.keys() and all(t1[k] == t2[k] for k in t1) and res[1]["codes"] == res[2]["codes"] and res[2]["world_size"] == 2
-    out["audio_to_codes"] = dict(files=res[1]["files"], trees_identical=True, codes=res[1]["codes"],
+    out["audio_to_codes"] = dict(files=res[1]["files"], trees_identical=True, codes=res[1]["codes"], control_plane_2_ranks=res[2].get("control_plane"),
                                  audio_hours_per_hour={"1 rank": res[1]["audio_hours_per_hour"], "2 ranks on one card": res[2]["audio_hours_per_hour"]})
     print("2. audio_to_codes 1 vs 2 ranks:", json.dumps(out["audio_to_codes"]), flush=True)
     shutil.rmtree(root, ignore_errors=True)
