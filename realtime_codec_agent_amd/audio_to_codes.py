@@ -324,15 +324,18 @@ def _super_batches(files: Sequence[str], sr: int, stereo: bool, budget_samples: 
                 pending.put((p, pool.submit(_prepare, p, sr, stereo)))
                 inflight += 1
         submit_more()
-        group, size = [], 0
+        group, size, n_groups = [], 0, 0
         while inflight:
             p, fut = pending.get()
             audio = fut.result()
             inflight -= 1
             submit_more()
-            if group and size + audio.size > budget_samples:
+            # ramp-up: the first super-batches are small (1/8, 1/2 of the budget), so the GPU has work a few milliseconds after the
+            # start instead of after a whole budget has been read and packed; from the third on nothing is exposed any more
+            budget = budget_samples >> 3 if n_groups == 0 else budget_samples >> 1 if n_groups == 1 else budget_samples
+            if group and size + audio.size > budget:
                 yield group
-                group, size = [], 0
+                group, size, n_groups = [], 0, n_groups + 1
             group.append((p, audio))
             size += audio.size
         if group:
