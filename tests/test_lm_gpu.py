@@ -311,6 +311,52 @@ def test_big_path_sampler_matches_restatement(top_k, top_p, min_p, temp):
     llm.close()
 
 
+def test_sampler_random_configurations_and_ties_match_restatement():
+    """A sweep over the sampler surface the reference's config can reach (llamacpp_utils.py:39-77, realtime_agent_v2.py:172-185): 24
+    seeded random configurations -- top_k anywhere from 1 to beyond the vocabulary or <= 0, top_p, min_p, temperature, the three
+    penalties, a logit bias -- six graph steps each, token for token the C restatement given the device's logits and the history of
+    accepted tokens.  Then the case a radix select can get wrong: 4096 of the 8192 logits EXACTLY equal (masked head rows) with the rank
+    cut inside the tie group (ties rank by lowest index) and the mass cut behind it."""
+    from realtime_codec_agent_amd.llm import LlamaForAlternatingCodeChannels, LMConfig, get_logits_bias_processor
+    cfg = LMConfig(vocab_size=8192, hidden=512, n_layers=2, n_heads=8, n_kv_heads=2, head_dim=64, ffn=1024)
+    llm = LlamaForAlternatingCodeChannels(model_path="random:mid", config=cfg, n_ctx=512, random_seed=3, init_std=0.05, device=0)
+    ids = np.random.default_rng(4).integers(0, 8192, 80).tolist()
+    rng = np.random.default_rng(2024)
+
+    def run(p, bias, steps=6):
+        llm.reset()
+        llm.init_sampler_for_generate(logits_processor=get_logits_bias_processor(bias) if bias else None, **p)
+        llm.eval(ids[:30])
+        toks, hist = ids[30:32], []
+        for step in range(steps):
+            t = llm.step(toks)
+            want = lm_ref.sample(llm._scores[-1], p["top_k"], p["top_p"], p["min_p"], p["temp"], p["seed"], step, bias or None, prev_tokens=hist,
+                                 repeat_penalty=p["repeat_penalty"], frequency_penalty=p["frequency_penalty"], presence_penalty=p["presence_penalty"])
+            assert t == want, (p, bias, step, t, want)
+            hist.append(t)
+            toks = [t, ids[32 + step]]
+        return hist
+    kinds = set()
+    for i in range(24):
+        top_k = int(rng.choice([1, 7, 100, 256, 257, 300, 1000, 4000, 8191, 8192, 20000, 0, -1]))
+        p = dict(top_k=top_k, top_p=float(rng.choice([1.0, 1.0, 0.95, 0.6, 0.2, 0.02])), min_p=float(rng.choice([0.0, 0.0, 0.01, 0.2])),
+                 temp=float(rng.choice([1.0, 0.7, 1.5])), seed=int(rng.integers(0, 1 << 31)),
+                 repeat_penalty=float(rng.choice([1.0, 1.0, 1.15, 1.6])), frequency_penalty=float(rng.choice([0.0, 0.0, 0.3])),
+                 presence_penalty=float(rng.choice([0.0, 0.0, 0.5])))
+        bias = {int(rng.integers(0, 8192)): float(rng.normal(0, 3)) for _ in range(int(rng.integers(0, 3)))}
+        run(p, bias)
+        kinds.add(("serial" if 1 <= top_k <= 256 else "big" if (p["top_p"] < 1.0 or 256 < top_k < 8192) else "whole", p["repeat_penalty"] != 1.0 or p["frequency_penalty"] != 0.0 or p["presence_penalty"] != 0.0))
+    assert {k for k, _ in kinds} == {"serial", "big", "whole"} and {b for _, b in kinds} == {True, False}, kinds
+    # ties: 4096 logits exactly 0.0; about half of the others are positive, so a rank cut at 5000 ends INSIDE the tie group
+    llm.mask_head_rows(0, 4096)
+    for p in (dict(top_k=5000, top_p=1.0), dict(top_k=5000, top_p=0.97), dict(top_k=0, top_p=0.9), dict(top_k=7000, top_p=0.999)):
+        full = dict(min_p=0.0, temp=2.0, seed=5, repeat_penalty=1.0, frequency_penalty=0.0, presence_penalty=0.0, **p)
+        run(full, {}, steps=8)
+    lg = llm._scores[-1]
+    assert (lg[:4096] == 0).all() and 1000 < int((lg[4096:] > 0).sum()) < 3500
+    llm.close()
+
+
 def test_step_probe_equals_step_plus_token_probs():
     """rca_lm_step_probe (the agent's speculative <|end_audio|> step as one replay): same token, same probabilities, same state as
     step() followed by token_probs(), replayed and eager, across a graph-bucket boundary, and the rollback afterwards works."""
