@@ -1739,8 +1739,10 @@ __global__ __launch_bounds__(256) void conv_in_blk_kernel(RowSrc src, const floa
 // FUSE = 1 (the first strided layer): the input is not read from HBM but computed while staging as conv_in(PCM) -- conv_in_blk_kernel's
 // f32 chain per (sample, channel), LeakyReLU, bf16 -- so conv_in's 524 MB write and this layer's 524 MB read per 256-window step
 // disappear (a third of all bytes the blocked pipeline moved).
-template <int KS, int S, int WGM, int CPS, int SPLIT, int OUT, int FUSE = 0>
-__global__ __launch_bounds__(256, (SPLIT || KS == 3) ? 2 : 3) void conv_bf16_blk_kernel(const conv_bf16raw* __restrict__ x_hi, const conv_bf16raw* __restrict__ x_lo,
+// WMT = 2: a wave owns 64 channels x 128 columns (2 x 4 MFMA tiles): every B fragment read from LDS feeds two MFMAs (with 1 x 4 tiles
+// the MFMA phase of the wide layers ran against the LDS read rate: 1 KB per MFMA and wave).
+template <int KS, int S, int WGM, int CPS, int SPLIT, int OUT, int FUSE = 0, int WMT = 1>
+__global__ __launch_bounds__(256, (SPLIT || KS == 3 || WMT == 2) ? 2 : 3) void conv_bf16_blk_kernel(const conv_bf16raw* __restrict__ x_hi, const conv_bf16raw* __restrict__ x_lo,
                                                                const conv_bf16raw* __restrict__ w_hi, const conv_bf16raw* __restrict__ w_lo,
                                                                const float* __restrict__ bias, conv_bf16raw* __restrict__ y_hi,
                                                                conv_bf16raw* __restrict__ y_lo, float* __restrict__ y_f32, int Cin, int Lin, int Cout,
@@ -1761,7 +1763,8 @@ __global__ __launch_bounds__(256, (SPLIT || KS == 3) ? 2 : 3) void conv_bf16_blk
     // weight fragments in flight (taps ahead).  The k = 3 layer keeps a whole stage's fragments in flight (every request of a stage is
     // then for the NEXT stage and the window loads go out at the top: 44 -> 34 us); on the k = 10 / k = 16 layers the same ring
     // costs the third wave per SIMD and measured slower (169 vs 161 us, 154 vs 147 us)
-    constexpr int PD = (KS == 3 && !SPLIT) ? CPS * KS : (KS < 8 ? KS : ((CPS * KS) % 8 == 0 ? (SPLIT ? 4 : 8) : 5));
+    constexpr int PD = WMT == 2 ? ((CPS * KS) % 4 == 0 ? 4 : 5)          // two channel tiles: twice the registers per tap
+                                : (KS == 3 && !SPLIT) ? CPS * KS : (KS < 8 ? KS : ((CPS * KS) % 8 == 0 ? (SPLIT ? 4 : 8) : 5));
     static_assert((CPS * KS) % PD == 0, "the fragment ring keeps static slots across stages");
     extern __shared__ __attribute__((aligned(16))) conv_u32x4 blk_lds[];   // [2 buffers][CPS][NPL][CELLS]
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, n = lane & 31;
@@ -1776,7 +1779,7 @@ __global__ __launch_bounds__(256, (SPLIT || KS == 3) ? 2 : 3) void conv_bf16_blk
     if (ct >= n_ct * n_rows) return;
     const int b = ct / n_ct;
     const int n0 = (ct - b * n_ct) * NT;                  // first output column of the workgroup
-    const int co0 = (by * WGM + wm_w) * 32;               // first output channel of the wave
+    const int co0 = (by * WGM + wm_w) * 32 * WMT;         // first output channel of the wave
     const int Cbi = Cin / 16, nstages = Cbi / CPS;
     const int t_start = n0 * S - padL;
     // ---- staging role (fixed per thread): piece -> (sample, half) -> LDS cell; global offset in 16-byte units from the block's row.
@@ -1817,24 +1820,29 @@ __global__ __launch_bounds__(256, (SPLIT || KS == 3) ? 2 : 3) void conv_bf16_blk
             }
     };
     // ---- accumulators start at the bias
-    f32x16 acc[4];
+    f32x16 acc[WMT][4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float bv = bias[co0 + (r & 3) + 8 * (r >> 2) + 4 * half];
+    for (int wm = 0; wm < WMT; ++wm)
 #pragma unroll
-        for (int wn = 0; wn < 4; ++wn) acc[wn][r] = bv;
-    }
-    // weights: fragment (co tile, block, tap) = 64 lanes x 16 bytes; this wave's fragments are consecutive over (block, tap)
-    const conv_u32x4* wq_hi = reinterpret_cast<const conv_u32x4*>(w_hi) + (long)(co0 / 32) * Cbi * KS * 64 + lane;
-    const conv_u32x4* wq_lo = reinterpret_cast<const conv_u32x4*>(w_lo) + (long)(co0 / 32) * Cbi * KS * 64 + lane;
+        for (int r = 0; r < 16; ++r) {
+            const float bv = bias[co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+#pragma unroll
+            for (int wn = 0; wn < 4; ++wn) acc[wm][wn][r] = bv;
+        }
+    // weights: fragment (co tile, block, tap) = 64 lanes x 16 bytes; a channel tile's fragments are consecutive over (block, tap)
+    const long wtile = (long)Cbi * KS * 64;                  // 16-byte units per channel tile
+    const conv_u32x4* wq_hi = reinterpret_cast<const conv_u32x4*>(w_hi) + (long)(co0 / 32) * wtile + lane;
+    const conv_u32x4* wq_lo = reinterpret_cast<const conv_u32x4*>(w_lo) + (long)(co0 / 32) * wtile + lane;
     const int bcell0 = half * S * SLOTS + wn_w * 128 + n;   // + wn * 32 + (kk % S) * SLOTS + kk / S
     const int nfrag = Cbi * KS;                              // fragments of this wave, in the order they are consumed
-    conv_u32x4 ah[PD], al[SPLIT ? PD : 1];
+    conv_u32x4 ah[PD][WMT], al[SPLIT ? PD : 1][WMT];
 #pragma unroll
-    for (int i = 0; i < PD; ++i) {
-        ah[i] = wq_hi[(long)i * 64];
-        if (SPLIT) al[i] = wq_lo[(long)i * 64];
-    }
+    for (int i = 0; i < PD; ++i)
+#pragma unroll
+        for (int wm = 0; wm < WMT; ++wm) {
+            ah[i][wm] = wq_hi[wm * wtile + (long)i * 64];
+            if (SPLIT) al[i][wm] = wq_lo[wm * wtile + (long)i * 64];
+        }
     if constexpr (FUSE) {
         // conv_in for the workgroup's window: a thread takes samples tid, tid + 256, ... and every channel of them.  All PCM taps are
         // requested first; the channel loop is outermost, so a channel's 8 weights (wave-uniform: one s_load_dwordx8) serve every
@@ -1923,31 +1931,39 @@ __global__ __launch_bounds__(256, (SPLIT || KS == 3) ? 2 : 3) void conv_bf16_blk
                     bh[wn] = xb[cell + wn * 32];
                     if (SPLIT) bl[wn] = xb[CELLS + cell + wn * 32];
                 }
-                const conv_u32x4 a_h = ah[slot];
-                conv_u32x4 a_l;
-                if (SPLIT) a_l = al[slot];
+                conv_u32x4 a_h[WMT], a_l[WMT];
+#pragma unroll
+                for (int wm = 0; wm < WMT; ++wm) { a_h[wm] = ah[slot][wm]; if (SPLIT) a_l[wm] = al[slot][wm]; }
                 {   // refill the slot with the fragment PD taps ahead (past the end: the last fragment again, never used)
                     const long fn = (long)min(f + PD, nfrag - 1) * 64;
-                    ah[slot] = wq_hi[fn];
-                    if (SPLIT) al[slot] = wq_lo[fn];
+#pragma unroll
+                    for (int wm = 0; wm < WMT; ++wm) {
+                        ah[slot][wm] = wq_hi[wm * wtile + fn];
+                        if (SPLIT) al[slot][wm] = wq_lo[wm * wtile + fn];
+                    }
                 }
                 ++f;
-                const conv_bf16x8 av = __builtin_bit_cast(conv_bf16x8, a_h);
 #if RCA_BLK_ABL == 2   // timing experiment: no MFMAs (operands kept alive)
-                asm volatile("" ::"v"(a_h), "v"(bh[0]), "v"(bh[1]), "v"(bh[2]), "v"(bh[3]));
+                asm volatile("" ::"v"(a_h[0]), "v"(bh[0]), "v"(bh[1]), "v"(bh[2]), "v"(bh[3]));
                 continue;
 #endif
-                // product-major: the four column tiles' accumulators are independent, the three products of one accumulator are not
+                // product-major: the column / channel tiles' accumulators are independent, the three products of one accumulator are not
 #pragma unroll
-                for (int wn = 0; wn < 4; ++wn)
-                    acc[wn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(conv_bf16x8, bh[wn]), acc[wn], 0, 0, 0);
+                for (int wm = 0; wm < WMT; ++wm)
+#pragma unroll
+                    for (int wn = 0; wn < 4; ++wn)
+                        acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(conv_bf16x8, a_h[wm]), __builtin_bit_cast(conv_bf16x8, bh[wn]), acc[wm][wn], 0, 0, 0);
                 if (SPLIT) {
 #pragma unroll
-                    for (int wn = 0; wn < 4; ++wn)
-                        acc[wn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(conv_bf16x8, bl[wn]), acc[wn], 0, 0, 0);
+                    for (int wm = 0; wm < WMT; ++wm)
 #pragma unroll
-                    for (int wn = 0; wn < 4; ++wn)
-                        acc[wn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(conv_bf16x8, a_l), __builtin_bit_cast(conv_bf16x8, bh[wn]), acc[wn], 0, 0, 0);
+                        for (int wn = 0; wn < 4; ++wn)
+                            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(conv_bf16x8, a_h[wm]), __builtin_bit_cast(conv_bf16x8, bl[wn]), acc[wm][wn], 0, 0, 0);
+#pragma unroll
+                    for (int wm = 0; wm < WMT; ++wm)
+#pragma unroll
+                        for (int wn = 0; wn < 4; ++wn)
+                            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(conv_bf16x8, a_l[wm]), __builtin_bit_cast(conv_bf16x8, bh[wn]), acc[wm][wn], 0, 0, 0);
                 }
             }
         }
@@ -1957,17 +1973,19 @@ __global__ __launch_bounds__(256, (SPLIT || KS == 3) ? 2 : 3) void conv_bf16_blk
     }
     // ---- epilogue: lane <-> column, register r <-> channel (r & 3) + 8 (r >> 2) + 4 half of the 32-row tile
 #if RCA_BLK_ABL == 3   // timing experiment: one store per wave instead of the tile
-    if (lane == 0 && acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.0f) y_hi[0] = 1;
+    if (lane == 0 && acc[0][0][0] + acc[0][1][1] + acc[WMT - 1][2][2] + acc[WMT - 1][3][3] == 12345.0f) y_hi[0] = 1;
     return;
 #endif
 #pragma unroll
-    for (int wn = 0; wn < 4; ++wn) {
+    for (int wn = 0; wn < 4; ++wn)
+#pragma unroll
+    for (int wm = 0; wm < WMT; ++wm) {
         const int t = n0 + wn_w * 128 + wn * 32 + n;
         if (t >= Lout) continue;
         if (OUT == 1) {
-            float* yr = y_f32 + ((long)b * Cout + co0 + 4 * half) * Lout + t;
+            float* yr = y_f32 + ((long)b * Cout + co0 + wm * 32 + 4 * half) * Lout + t;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) yr[(long)((r & 3) + 8 * (r >> 2)) * Lout] = acc[wn][r];
+            for (int r = 0; r < 16; ++r) yr[(long)((r & 3) + 8 * (r >> 2)) * Lout] = acc[wm][wn][r];
         } else {
             const int Cbo = Cout / 16;
 #pragma unroll
@@ -1975,10 +1993,10 @@ __global__ __launch_bounds__(256, (SPLIT || KS == 3) ? 2 : 3) void conv_bf16_blk
                 float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float a = acc[wn][4 * g + j];
+                    const float a = acc[wm][wn][4 * g + j];
                     v[j] = act ? fmaxf(a, a * slope) : a;
                 }
-                const int ch = co0 + 8 * g + 4 * half;
+                const int ch = co0 + wm * 32 + 8 * g + 4 * half;
                 const long o = (((long)b * Cbo + ch / 16) * Lout + t) * 16 + (ch & 15);
                 const unsigned h0 = conv_pack_bf16x2(v[0], v[1]), h1 = conv_pack_bf16x2(v[2], v[3]);
                 *reinterpret_cast<uint2*>(y_hi + o) = make_uint2(h0, h1);
@@ -2573,24 +2591,24 @@ static int pack_weights_bf16(const ConvLayer& L, Bf16Pack* out) {
     return RCA_OK;
 }
 
-template <int KS, int S, int WGM, int CPS, int OUT, int FUSE = 0>
+template <int KS, int S, int WGM, int CPS, int OUT, int FUSE = 0, int WMT = 1>
 static int launch_conv_bf16(bool split, const ConvLayer& L, const Bf16Pack& wp, const conv_bf16raw* xh, const conv_bf16raw* xl, conv_bf16raw* yh,
                             conv_bf16raw* yl, float* yf, int B, int Lin, int act, float slope, hipStream_t st, RowSrc fsrc = RowSrc{},
                             const float* w_in8 = nullptr, int in_act = 0) {
     constexpr int WGN = 4 / WGM, NT = 128 * WGN;
     constexpr int SLOTS = NT + (KS - 1) / S;
     const int Lout = Lin / S;
-    const int n_ct = cdiv(Lout, NT), n_cot = L.cout / (32 * WGM);
+    const int n_ct = cdiv(Lout, NT), n_cot = L.cout / (32 * WGM * (split ? 1 : WMT));
     const dim3 grid((unsigned)(((long)n_ct * B + 7) / 8 * 8 * n_cot));
     const int nstages = L.cin / 16 / CPS;
     const size_t lds = (size_t)((nstages > 1 && !(split && S >= 5)) ? 2 : 1) * CPS * (split ? 2 : 1) * 2 * S * SLOTS * 16;   // one-stage layers and the single-buffered split layers never touch a second buffer
     if (split) {
-        auto k = conv_bf16_blk_kernel<KS, S, WGM, CPS, 1, OUT, FUSE>;
+        auto k = conv_bf16_blk_kernel<KS, S, WGM, CPS, 1, OUT, FUSE, 1>;
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
         k<<<grid, 256, lds, st>>>(xh, xl, wp.hi, wp.lo, L.b, yh, yl, yf, L.cin, Lin, L.cout, Lout, act, slope, B, n_ct, n_cot, fsrc, w_in8, in_act);
     } else {
-        auto k = conv_bf16_blk_kernel<KS, S, WGM, CPS, 0, OUT, FUSE>;
+        auto k = conv_bf16_blk_kernel<KS, S, WGM, CPS, 0, OUT, FUSE, WMT>;
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
         k<<<grid, 256, lds, st>>>(xh, xl, wp.hi, wp.lo, L.b, yh, yl, yf, L.cin, Lin, L.cout, Lout, act, slope, B, n_ct, n_cot, fsrc, w_in8, in_act);
@@ -2664,7 +2682,11 @@ static int run_encoder_bf16(rca_codec* h, RowSrc src, int B, int Tp, size_t max_
         const conv_bf16raw *xh = hi_of(cur), *xl = lo_of(cur);
         conv_bf16raw *yh = hi_of(cur ^ 1), *yl = lo_of(cur ^ 1);
         float* yf = h->act[cur ^ 1].as<float>();
-        if (last) rc = launch_conv_bf16<3, 1, 4, 4, 1>(split, Ly, wp, xh, xl, yh, yl, yf, B, L, act, slope, st);
+        // rounded mode: 64 x 128 wave tiles (WMT = 2) on the k10 / s5 layer, where one B fragment feeding two MFMAs pays
+        // (162 -> 147 us); measured equal on k8 and slower on k16 / k3 (profiles/r04/experiments/bf16_blk_ablations.txt).
+        // hi + lo keeps 32 x 128 everywhere (its registers hold two planes)
+        if (!split && Ly.k == 10 && Ly.cout % 256 == 0) rc = launch_conv_bf16<10, 5, 4, 1, 0, 0, 2>(split, Ly, wp, xh, xl, yh, yl, yf, B, L, act, slope, st);
+        else if (last) rc = launch_conv_bf16<3, 1, 4, 4, 1>(split, Ly, wp, xh, xl, yh, yl, yf, B, L, act, slope, st);
         else if (Ly.k == 4 && li == 1 && fuse_in)
             rc = launch_conv_bf16<4, 2, 2, 2, 0, 1>(split, Ly, wp, xh, xl, yh, yl, yf, B, L, act, slope, st, src, h->bf16_packs[0].w_in8, Ly.pre ? 1 : 0);
         else if (Ly.k == 4) rc = launch_conv_bf16<4, 2, 2, 2, 0>(split, Ly, wp, xh, xl, yh, yl, yf, B, L, act, slope, st);
