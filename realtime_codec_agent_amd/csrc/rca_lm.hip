@@ -943,6 +943,11 @@ __device__ __forceinline__ unsigned long long sample_key(float v, unsigned idx) 
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
     return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
 }
+// the float whose monotone image is the key's upper half (sample_key's inverse: same bits, -0.0 and NaN payloads included)
+__device__ __forceinline__ float sample_key_value(unsigned long long key) {
+    const unsigned u = (unsigned)(key >> 32);
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
 
 // Sampler = three launches (llama.cpp chain order top_k -> top_p -> min_p -> temp -> softmax -> draw;
 // llamacpp_utils.py:39-95; realtime_agent_config.py:11-20,29):
@@ -1064,27 +1069,42 @@ __global__ __launch_bounds__(256) void samp_hist_kernel(const float* __restrict_
 
 __global__ __launch_bounds__(256) void samp_gather_kernel(const float* __restrict__ logits, int V, const SamplerDev* __restrict__ sp,
                                                           SampWork* __restrict__ w) {
-    __shared__ unsigned grp[256];
+    __shared__ unsigned wtot[4];
     __shared__ unsigned thr_bin;
     const int k = samp_k(sp, V);
-    unsigned s8 = 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // The bin that holds the k-th largest value: the highest bin b with count(bins >= b) >= k, found as "group of 8 bins, then bin"
+    // from the top.  Thread t owns bins 8 t .. 8 t + 7; S[t] = count of the bins of threads >= t is a suffix scan over the 256
+    // threads (shuffles inside a wave + four wave totals), and the one thread whose group crosses k finishes inside its own
+    // registers.  (One thread walking the 256 group sums and then 8 bins -- dependent LDS and global reads in a loop with an early
+    // exit -- was ~7 of this kernel's 10 us.)  Unsigned integer sums: the same bin whatever the order.
+    unsigned h8[8];
+    {
+        const uint4 a = *reinterpret_cast<const uint4*>(w->hist + tid * 8), b = *reinterpret_cast<const uint4*>(w->hist + tid * 8 + 4);
+        h8[0] = a.x; h8[1] = a.y; h8[2] = a.z; h8[3] = a.w; h8[4] = b.x; h8[5] = b.y; h8[6] = b.z; h8[7] = b.w;
+    }
+    const unsigned s8 = ((h8[0] + h8[1]) + (h8[2] + h8[3])) + ((h8[4] + h8[5]) + (h8[6] + h8[7]));
+    unsigned suf = s8;   // inclusive suffix sum over the lanes >= lane of this wave
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s8 += w->hist[threadIdx.x * 8 + j];
-    grp[threadIdx.x] = s8;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_down(suf, off);
+        if (lane + off < 64) suf += o;
+    }
+    if (lane == 0) wtot[wave] = suf;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned acc = 0;
-        int g = 255;
-        for (; g > 0; --g) {
-            if (acc + grp[g] >= (unsigned)k) break;
-            acc += grp[g];
+    unsigned S = suf;
+    for (int q = wave + 1; q < 4; ++q) S += wtot[q];
+    // group g = the highest t >= 1 with S[t] >= k, or 0; the counts above it: S[t + 1] = S[t] - s8
+    const unsigned above = S - s8;
+    const bool mine = tid >= 1 ? (S >= (unsigned)k && above < (unsigned)k) : (above < (unsigned)k);
+    if (mine) {
+        unsigned acc = above;
+        int j = 7;
+        for (; j > 0; --j) {
+            if (acc + h8[j] >= (unsigned)k) break;
+            acc += h8[j];
         }
-        int b = g * 8 + 7;
-        for (; b > g * 8; --b) {
-            if (acc + w->hist[b] >= (unsigned)k) break;
-            acc += w->hist[b];
-        }
-        thr_bin = (unsigned)b;
+        thr_bin = (unsigned)(tid * 8 + j);
     }
     __syncthreads();
     const unsigned tb = thr_bin;
@@ -1123,6 +1143,8 @@ __global__ __launch_bounds__(1024) void samp_final_kernel(float* logits, int V, 
     const int tid = threadIdx.x;
     const bool greedy = sp->temp <= 0.0f;
     const int k = samp_k(sp, V);
+    // (requested together with the two counters it would otherwise wait for: slot tid exists whatever the count, SAMP_CAND_CAP >= 1024)
+    const unsigned long long my_cand = w->cand[tid];
     const bool full = w->overflow != 0u;
     const int NN = full ? V : (int)min(w->ncand, (unsigned)SAMP_CAND_CAP);
     auto key_at = [&](int i) -> unsigned long long {
@@ -1136,7 +1158,7 @@ __global__ __launch_bounds__(1024) void samp_final_kernel(float* logits, int V, 
         // the usual case, a few hundred candidates: every thread ranks its own key by counting the larger ones
         // (keys are unique), the k best land in sorted order -- two barriers instead of a radix select, a compaction
         // and a bitonic sort
-        if (tid < NN) ck[tid] = w->cand[tid];
+        if (tid < NN) ck[tid] = my_cand;
         __syncthreads();
         if (tid < NN) {
             const unsigned long long key = ck[tid];
@@ -1204,10 +1226,7 @@ __global__ __launch_bounds__(1024) void samp_final_kernel(float* logits, int V, 
             }
         }
     }
-    if (tid < n) {
-        const unsigned idx = 0xFFFFFFFFu - (unsigned)(cand[tid] & 0xFFFFFFFFull);
-        cval[tid] = samp_value(logits, sp, (int)idx);
-    }
+    if (tid < n) cval[tid] = sample_key_value(cand[tid]);   // the key's upper half IS the value (the bits samp_value read at gather time)
     __syncthreads();
     if (tid < n && !greedy) {   // the exponentials in parallel; the sums below stay serial (their order is the definition)
         const float mx = cval[0];
