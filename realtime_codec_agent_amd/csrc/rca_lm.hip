@@ -325,6 +325,19 @@ __device__ __forceinline__ unsigned q8_opaque(unsigned w) {
     return w;
 }
 __device__ __forceinline__ float q8_byte_to_f32(unsigned w, int b) { return (float)(signed char)((w >> (8 * b)) & 0xffu); }
+// (float) of UNSIGNED byte B of a dword as ONE instruction.  From the plain shift / mask / cast form this compiler selects
+// v_cvt_f32_ubyte0 for byte 0 only and v_bfe_u32 + v_cvt_f32_ubyte0 for bytes 1-3: 96 extra instructions per 128 weights in the
+// Q4_K body, whose VALU work (4.8 instructions per weight, not its bytes) is what bounds the Q4_K GEMVs: lm_head 70 -> 59.5 us,
+// gate/up 9.6 -> 8.6, the step 0.686 -> 0.638 ms at 6.6 k context (profiles/r04/experiments/lm_step_micro.txt).
+template <int B>
+__device__ __forceinline__ float ubyte_to_f32(unsigned w) {
+    float f;
+    if constexpr (B == 0) asm("v_cvt_f32_ubyte0_e32 %0, %1" : "=v"(f) : "v"(w));
+    else if constexpr (B == 1) asm("v_cvt_f32_ubyte1_e32 %0, %1" : "=v"(f) : "v"(w));
+    else if constexpr (B == 2) asm("v_cvt_f32_ubyte2_e32 %0, %1" : "=v"(f) : "v"(w));
+    else asm("v_cvt_f32_ubyte3_e32 %0, %1" : "=v"(f) : "v"(w));
+    return f;
+}
 struct GemvQ8 {          // the packed (quantised) forms: q8_0, and Q4_K (dd != nullptr)
     const u32x4* qs;      // q8_0: [N / 2][K / 8] 16-byte units.  Q4_K: [N / 4][K / 8] units = 8 nibbles x 4 slots (q4k_* below)
     const unsigned* sc;   // q8_0: [ceil(N / 16)][K / 32][8]: (fp16, fp16) per pair and 32-element block, pairs in groups of 8 -- the scales a
@@ -579,11 +592,13 @@ __global__ __launch_bounds__(256, gemv_min_waves(Q, R, NIT)) void lm_gemv_kernel
                     float pq[M];
 #pragma unroll
                     for (int m = 0; m < M; ++m) pq[m] = 0.0f;
+                    float fq[8];   // nibble j = byte j / 2 of lo (j even) / hi (j odd)
+                    fq[0] = ubyte_to_f32<0>(lo); fq[1] = ubyte_to_f32<0>(hi); fq[2] = ubyte_to_f32<1>(lo); fq[3] = ubyte_to_f32<1>(hi);
+                    fq[4] = ubyte_to_f32<2>(lo); fq[5] = ubyte_to_f32<2>(hi); fq[6] = ubyte_to_f32<3>(lo); fq[7] = ubyte_to_f32<3>(hi);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float fq = (float)(((j & 1) ? hi : lo) >> (8 * (j >> 1)) & 0xffu);   // v_cvt_f32_ubyteN
 #pragma unroll
-                        for (int m = 0; m < M; ++m) pq[m] = __builtin_fmaf(fq, xr[m][it][j], pq[m]);
+                        for (int m = 0; m < M; ++m) pq[m] = __builtin_fmaf(fq[j], xr[m][it][j], pq[m]);
                     }
                     const f16x2 d2 = __builtin_bit_cast(f16x2, dw[i]);
                     const unsigned scm = (sw[i >> 1] >> (16 * (i & 1))) & 0xffffu;
