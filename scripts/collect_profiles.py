@@ -25,6 +25,8 @@ for sub in ("bench", "bench_bf16", "lm", "lm_6k", "lm_q8", "lm_q4k"):
     shutil.copy(ks, f"{dst}/{sub}_kernel_stats.csv")
     lines = [l for l in open(f"{src}/{sub}_stdout.log") if l.startswith("{") or l.startswith("ctx=") or l.startswith("fmt=")]
     open(f"{dst}/{sub}_stdout.log", "w").writelines(lines)
+if os.path.exists(f"{src}/lm_6k_step_timeline.txt"):
+    shutil.copy(f"{src}/lm_6k_step_timeline.txt", f"{dst}/lm_6k_step_timeline.txt")
 for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
     cc = newest(f"{src}/{sub}/*/*counter_collection.csv")
     if not cc:

@@ -23,6 +23,8 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_A
 # 4. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes (TCC slots)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-duplex --no-trim-leg --no-bf16-leg --no-cli-leg > $OUT/pmc_fetch_stdout.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-duplex --no-trim-leg --no-bf16-leg --no-cli-leg > $OUT/pmc_write_stdout.log 2>&1
+# GPU-side timeline of the replayed 6.6 k step (span, gaps, the sampler's launches) from the raw trace, before it is dropped
+python3 $R/scripts/step_timeline.py $OUT/lm_6k > $OUT/lm_6k_step_timeline.txt 2>&1
 python3 $R/scripts/summarize_profile.py $OUT > $OUT/SUMMARY.txt 2>&1
 # the raw per-dispatch traces of the two --stats runs are large (gpurun merges at most 64 MiB back): keep the stats tables
 rm -f $OUT/bench/*/*kernel_trace.csv $OUT/bench_bf16/*/*kernel_trace.csv $OUT/lm/*/*kernel_trace.csv $OUT/lm_q8/*/*kernel_trace.csv $OUT/lm_q4k/*/*kernel_trace.csv $OUT/lm_6k/*/*kernel_trace.csv
