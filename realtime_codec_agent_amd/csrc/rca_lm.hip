@@ -4433,6 +4433,7 @@ static int lm_step_impl(rca_lm_t* h, const int32_t* ids, int32_t n, const int32_
         e2 = hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
         if (e2 != hipSuccess) { gexec = nullptr; return fail(RCA_ERR_HIP, "graph instantiate: %s", hipGetErrorString(e2)); }
+        (void)hipGraphUpload(gexec, st);   // the device-side copy now, not inside the first frame that replays it (pre-captured graphs: first trim frame, first frame of a bucket)
         if (n_probe) gs.gp_nprobe[n][bucket] = n_probe;
     }
     if (cap_bucket >= 0) return RCA_OK;      // rca_duplex_precapture: the graph exists now, nothing is launched
@@ -4521,6 +4522,7 @@ static int lm_frame_core(rca_lm_t* h, const int32_t* first_pair, const int32_t* 
             e2 = hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0);
             (void)hipGraphDestroy(g);
             if (e2 != hipSuccess) { gexec = nullptr; return fail(RCA_ERR_HIP, "graph instantiate: %s", hipGetErrorString(e2)); }
+            (void)hipGraphUpload(gexec, st);
         } else if (rc != RCA_OK) {
             return rc;
         }
@@ -4815,6 +4817,7 @@ static int duplex_frame_core(rca_lm_t* h, rca_codec_t* codec, const rca_duplex_f
         e2 = hipGraphInstantiate(&ent->exec, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
         if (e2 != hipSuccess) { ent->exec = nullptr; return fail(RCA_ERR_HIP, "duplex graph instantiate: %s", hipGetErrorString(e2)); }
+        (void)hipGraphUpload(ent->exec, st);
         // a workspace that moved under the eager run (first call of a shape) would have changed the signature: checked by the key
     }
     if (cap_only) return RCA_OK;

@@ -54,20 +54,36 @@ def run_duplex_bench(dev=None, secs: float = 125.0, chunk_size_secs: float = 0.0
     for s in range(0, 10 * cs, cs):
         agent.process_audio(sig[s:s + cs])
     agent.profilers.reset()
+    # What a serving process does once its model is loaded: everything allocated so far (the imported modules, the model objects --
+    # about a million Python objects) moves to the permanent generation, so a full collection inside a frame scans the session's own
+    # objects only.  Collections that still happen in the timed frames are recorded (generation, pause, frame) and reported: a frame
+    # that is tens of milliseconds long once in a few runs is attributable instead of "not reproducible".
     gc.collect()
+    gc.freeze()
+    gc_log, gc_t = [], [0.0]
+    def _gc_cb(phase, info):
+        if phase == "start":
+            gc_t[0] = time.perf_counter()
+        else:
+            gc_log.append((int(info.get("generation", -1)), (time.perf_counter() - gc_t[0]) * 1e3, nchunks))
+    gc.callbacks.append(_gc_cb)
     one_replay0 = agent.duplex_graph_frames
     t1 = time.perf_counter()
     nchunks = 0
     trims = []                                  # (audio second, frame latency ms, context tokens after the trim)
     last_trim = agent.trim_to_secs
     lat = agent.profilers.total_profiler.latencies_secs
-    for s in range(10 * cs, n - cs + 1, cs):
-        agent.process_audio(sig[s:s + cs])
-        nchunks += 1
-        if agent.trim_to_secs != last_trim:
-            last_trim = agent.trim_to_secs
-            trims.append(dict(at_audio_secs=round(s / 16000.0, 2), frame_ms=lat[-1] * 1e3 if lat else None, context_tokens_after=res.llm.n_tokens))
-    torch.cuda.synchronize()
+    try:
+        for s in range(10 * cs, n - cs + 1, cs):
+            agent.process_audio(sig[s:s + cs])
+            nchunks += 1
+            if agent.trim_to_secs != last_trim:
+                last_trim = agent.trim_to_secs
+                trims.append(dict(at_audio_secs=round(s / 16000.0, 2), frame_ms=lat[-1] * 1e3 if lat else None, context_tokens_after=res.llm.n_tokens))
+        torch.cuda.synchronize()
+    finally:
+        gc.callbacks.remove(_gc_cb)
+        gc.unfreeze()
     wall = time.perf_counter() - t1
     summ = agent.profilers.summary()
     lat_ms = np.asarray(lat) * 1e3
@@ -100,6 +116,9 @@ def run_duplex_bench(dev=None, secs: float = 125.0, chunk_size_secs: float = 0.0
         "frames_over_budget": int((lat_ms > budget_ms).sum()),
         "slowest_frames": [dict(frame=int(i), at_audio_secs=round((10 + int(i)) * chunk_size_secs, 2), ms=float(lat_ms[i])) for i in np.argsort(-lat_ms)[:5]] if lat_ms.size else [],
         "trims_in_timed_window": trims,
+        "gc": {"frozen_after_warmup": True, "collections_in_timed_frames": len(gc_log),
+               "max_pause_ms": max([g[1] for g in gc_log], default=0.0),
+               "pauses_over_1ms": [dict(generation=g[0], ms=round(g[1], 2), frame=g[2]) for g in gc_log if g[1] > 1.0][:8]},
         "kv_shadow": bool(getattr(agent, "kv_shadow_active", False)),
         "frame_graph": bool(getattr(agent, "frame_graph_active", False)),
         "one_replay_frames": agent.duplex_graph_frames - one_replay0,   # frames that ran as ONE graph replay (rca_duplex_frame)
