@@ -1930,6 +1930,9 @@ struct rca_lm {
     // captured kernel nodes, so a set remembers the cache it was captured over (at most two caches ever rotate through a handle).
     struct GraphSet { const f16_t* kc = nullptr; hipGraphExec_t g[3][LM_GRAPH_BUCKETS] = {}; hipGraphExec_t fg[LM_FRAME_MAX + 1][LM_GRAPH_BUCKETS] = {};
                       hipGraphExec_t gp[3][LM_GRAPH_BUCKETS] = {}; int gp_nprobe[3][LM_GRAPH_BUCKETS] = {};   // step + token probabilities (rca_lm_step_probe)
+                      // rca_lm_eval_async passes of ONE prefill tile (the shadow cache's background tiles): tokens of the pass -> graph.  The
+                      // flash attention of the tile path takes the context from the device state, so one graph serves every position.
+                      int tile_m[2] = {0, 0}; hipGraphExec_t tile_g[2] = {nullptr, nullptr}; int tile_seen[2] = {0, 0};
                       unsigned long long last_use = 0; };
     GraphSet gset[2];
     unsigned long long gset_clock = 0;
@@ -1980,6 +1983,10 @@ static void lm_drop_graph_set(rca_lm::GraphSet& gs) {
     for (int i = 0; i <= LM_FRAME_MAX; ++i)
         for (int b = 0; b < LM_GRAPH_BUCKETS; ++b)
             if (gs.fg[i][b]) { (void)hipGraphExecDestroy(gs.fg[i][b]); gs.fg[i][b] = nullptr; }
+    for (int i = 0; i < 2; ++i) {
+        if (gs.tile_g[i]) { (void)hipGraphExecDestroy(gs.tile_g[i]); gs.tile_g[i] = nullptr; }
+        gs.tile_m[i] = gs.tile_seen[i] = 0;
+    }
     gs.kc = nullptr;
 }
 static void lm_drop_graphs(rca_lm* h) {
@@ -4179,6 +4186,54 @@ static int lm_eval_impl(rca_lm_t* h, const int32_t* ids, int32_t n, bool wait_la
         // long evals (session prefill, recompute_kv_cache): 32-token tiles on the bf16 MFMA path
         const bool big = lm_can_gemm128(h);
         const int tile = big ? LM_MAXM : LM_TILE32;
+        // A background tile (rca_lm_eval_async of one pass: kv_shadow.py feeds one per few frames) is ~230 launches; issued eagerly
+        // they cost the calling frame ~2 ms of host time before its own replay is even launched (tile frames 9.5 ms against a median
+        // of 4.4).  The third pass of a size on this cache is captured and replayed from then on: one launch.  (First: eager --
+        // the launchers' one-time attribute calls; the geometry of a pass depends on its token count only, the context is read
+        // from the device state.)
+        static const bool tile_graphs = !(getenv("RCA_LM_TILE_GRAPHS") && atoi(getenv("RCA_LM_TILE_GRAPHS")) == 0) &&
+                                        !(getenv("RCA_LM_FLASH") && atoi(getenv("RCA_LM_FLASH")) == 0);   // (the split-attention A/B path launches per context)
+        if (!wait_last && big && n <= tile && h->graphs_enabled && tile_graphs) {
+            rca_lm::GraphSet& gs = lm_graph_set(h);
+            int slot = -1;
+            for (int i = 0; i < 2; ++i)
+                if (gs.tile_m[i] == n) slot = i;
+            if (slot < 0) {
+                slot = gs.tile_seen[0] <= gs.tile_seen[1] ? 0 : 1;
+                if (gs.tile_g[slot]) { (void)hipGraphExecDestroy(gs.tile_g[slot]); gs.tile_g[slot] = nullptr; }
+                gs.tile_m[slot] = n; gs.tile_seen[slot] = 0;
+            }
+            if (++gs.tile_seen[slot] >= 2) {
+                h->h_stt->n_tokens = h->n_tokens;
+                h->h_stt->m = n;
+                for (int i = 0; i < n; ++i) h->h_stt->ids[i] = ids[i];
+                if (!gs.tile_g[slot]) {
+                    hipGraph_t g = nullptr;
+                    RCA_HIP(hipStreamSynchronize(st));
+                    RCA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                    hipError_t e = hipMemcpyAsync(h->stt, h->h_stt, 8 + 4 * (size_t)std::max(n, 16), hipMemcpyHostToDevice, st);
+                    rc = e == hipSuccess ? lm_enqueue_prefill_tile128(h, n, st, 1) : fail(RCA_ERR_HIP, "tile capture memcpy: %s", hipGetErrorString(e));
+                    if (rc == RCA_OK) {
+                        const rca_lm_config_t& c = h->cfg;
+                        const GemvRope norope{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+                        launch_gemv<1, 0>(GEMV_HEAD, h, 1, h->head, nullptr, h->logits, c.vocab_size, c.hidden, c.vocab_size,
+                                          GemvPro{h->x, h->final_norm, c.rms_eps, 1}, norope, st);
+                    }
+                    hipError_t e2 = hipStreamEndCapture(st, &g);
+                    if (rc != RCA_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+                    if (e2 != hipSuccess) return fail(RCA_ERR_HIP, "tile capture: %s", hipGetErrorString(e2));
+                    e2 = hipGraphInstantiate(&gs.tile_g[slot], g, nullptr, nullptr, 0);
+                    (void)hipGraphDestroy(g);
+                    if (e2 != hipSuccess) { gs.tile_g[slot] = nullptr; return fail(RCA_ERR_HIP, "tile graph instantiate: %s", hipGetErrorString(e2)); }
+                    (void)hipGraphUpload(gs.tile_g[slot], st);
+                }
+                RCA_HIP(hipGraphLaunch(gs.tile_g[slot], st));
+                h->n_tokens += n;
+                h->logits_rows = 1;
+                h->async_pending = true;
+                return RCA_OK;
+            }
+        }
         for (int off = 0; off < n; off += tile) {
             const int m = std::min(tile, n - off);
             const bool last = off + m >= n;
