@@ -388,13 +388,9 @@ def main():
     }
     if roofline_bf16 is not None:
         out["roofline_bf16"] = roofline_bf16
-    if rank == 0 and world == 1 and not args.no_cli_leg:
-        out["config"]["batch_cli"] = batch_cli_leg()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_encode(cfg, weights, chunk, ctx, 64, C)
-        if not args.no_duplex:
-            from realtime_codec_agent_amd.llm import LMConfig
-            out["cpu_baseline"]["lm_step"] = cpu_baseline_lm_step(LMConfig.llama_3_2_1b())
+    # The duplex legs run BEFORE the batch-CLI and CPU-baseline legs: a session that started behind them (256 OpenMP threads, 32 torch
+    # threads, a 5 GB host model, the CLI's reader / writer threads and pinned ring, all just released) showed one 27-35 ms frame in
+    # three of five default runs and in none of 17 runs without those legs in front of it (scripts/duplex_outlier_ab.sh).
     if not args.no_duplex:
         # one independent duplex session per GPU (BASELINE configs[3]/[4]; no exchange between sessions)
         from realtime_codec_agent_amd.duplex_bench import run_duplex_bench
@@ -415,6 +411,13 @@ def main():
                 out[f"duplex_{fmt}"] = {k: q[k] for k in ("workload", "xRT", "p50_frame_step_ms", "p99_frame_step_ms", "max_frame_step_ms", "frames", "lm_step_ms",
                                                            "lm_ctx_tokens", "lm_hbm_gbs", "lm_weight_gb_per_step")}
                 out[f"duplex_{fmt}"]["roofline_lm"] = rq
+    if rank == 0 and world == 1 and not args.no_cli_leg:
+        out["config"]["batch_cli"] = batch_cli_leg()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_encode(cfg, weights, chunk, ctx, 64, C)
+        if not args.no_duplex:
+            from realtime_codec_agent_amd.llm import LMConfig
+            out["cpu_baseline"]["lm_step"] = cpu_baseline_lm_step(LMConfig.llama_3_2_1b())
     if rank == 0:
         print(json.dumps(out))
     cp.close()
