@@ -9,8 +9,10 @@ workspace and low-priority stream):
 
     plan      header KV copied device-to-device from the live cache (it is never recomputed by the reference either), the twin's
               position set behind it
-    advance   once per frame: if at least `tile` new tokens of the future suffix exist, one prefill tile is enqueued on the twin
-              (asynchronously: it overlaps the frame's own work); a tail of `keep_back` tokens is never fed early
+    advance   once per frame, at its END: if at least `tile` new tokens of the future suffix exist, one prefill tile is enqueued on the
+              twin (asynchronously, one graph replay: it runs in the idle time before the next chunk arrives; the next frame waits
+              for it before launching its own work -- a tile BESIDE a frame's latency-bound launches cost that frame 5-6 ms);
+              a tail of `keep_back` tokens is never fed early
     finish    at the trim: what was fed is compared with the sequence as it is NOW (text branches and edits may have rewritten
               it: the twin is rolled back to the first difference), the rest is evaluated, and the two handles trade caches
 

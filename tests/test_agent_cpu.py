@@ -114,3 +114,83 @@ def test_tokenizer_layout():
     assert tok.decode(tok.encode("héllo †", add_special_tokens=False)) == "héllo †"
     assert tok.convert_tokens_to_ids(chr(0xE000)) == 128266
     assert all(i > 128265 for i in tok.encode(chr(0xE005) * 4, add_special_tokens=False))
+
+
+def test_shadow_cache_host_logic_on_fakes():
+    """kv_shadow.py + the agent's use of it, on a fake LM that offers make_kv_shadow (no GPU): the session trims through the shadow
+    cache -- tiles fed to a twin ahead of time, caches traded at the trim -- and ends in the state the reference's recompute leaves
+    (same evaluated stream on the live handle up to the recompute evals, same sampled tokens, same final KV); a background tile is
+    enqueued at the END of a frame and the next frame waits for it before it launches anything of its own."""
+    from agent_fakes import FakeLLM, build_fakes, scenarios, user_audio
+    events = []
+
+    class Twin:
+        def __init__(self):
+            self.kv, self.n_tokens = [], 0
+
+        def set_mfma_prefill(self, on):
+            pass
+
+        def copy_kv_from(self, other, n):
+            self.kv = list(other.kv[:n])
+
+        def eval_async(self, tokens):
+            events.append(("tile", len(tokens)))
+            self.kv = self.kv[:self.n_tokens] + [int(t) for t in tokens]
+            self.n_tokens = len(self.kv)
+
+        def sync(self):
+            events.append(("settle",))
+
+    class ShadowLLM(FakeLLM):
+        def make_kv_shadow(self):
+            self.twin = Twin()
+            return self.twin
+
+        def swap_kv(self, other):
+            events.append(("swap",))
+            self.kv, other.kv = other.kv, self.kv
+
+        def eval(self, tokens):
+            events.append(("eval", len(list(tokens))))
+            super().eval(tokens)
+
+    cfg_kw, script, secs = scenarios(_TOK)["trim"]
+
+    def run(llm_cls, tile):
+        resources, tok = build_fakes(script)
+        resources.llm = llm_cls(tok.vocab_size, tok.codec_vocab_start, resources.audio_tokenizer.codebook_size, script)
+        agent = RealtimeAgent.__new__(RealtimeAgent)
+        RealtimeAgent.__init__(agent, resources=resources, config=RealtimeAgentConfig(**cfg_kw))
+        agent.kv_shadow_tile = tile
+        audio = user_audio(int(secs * 16000))
+        cs = agent.chunk_size_samples
+        marks = []
+        for s in range(0, len(audio) - cs + 1, cs):
+            marks.append(len(events))
+            agent.process_audio(audio[s:s + cs])
+        return agent, resources.llm, marks
+
+    ref_agent, ref_llm, _ = run(FakeLLM, 8)
+    events.clear()
+    agent, llm, marks = run(ShadowLLM, 8)
+    sh = agent._kv_shadow
+    assert sh is not None and sh.stats["swaps"] >= 2 and sh.stats["tiles"] >= 4 and sh.stats["fallbacks"] == 0
+    # same session: sequence, sampled stream, and the live cache after the swaps == after the reference's recomputes
+    assert agent.input_ids == ref_agent.input_ids and llm.n_samples == ref_llm.n_samples
+    assert llm.n_tokens == ref_llm.n_tokens and llm.kv[:llm.n_tokens] == ref_llm.kv[:ref_llm.n_tokens]
+    # the live handle evaluated no long suffix (the reference's recompute_kv_cache(0) evaluates hundreds of tokens at a trim)
+    long_ref = [n for op, _, t in ref_llm.log for n in [len(t)] if n > 16]
+    long_shadow = [n for op, _, t in llm.log for n in [len(t)] if n > 16]
+    assert long_ref and len(long_shadow) < len(long_ref)
+    # per frame: a tile is the LAST thing a frame does; the frame after it settles the twin before its own first eval
+    marks.append(len(events))
+    checked = 0
+    for a, b, c in zip(marks, marks[1:], marks[2:]):
+        frame, nxt = events[a:b], events[b:c]
+        if any(e[0] == "tile" for e in frame) and not any(e[0] == "swap" for e in frame):
+            assert frame[-1][0] == "tile"
+            first_eval = next(i for i, e in enumerate(nxt) if e[0] == "eval")
+            assert ("settle",) in nxt[:first_eval]
+            checked += 1
+    assert checked >= 4
